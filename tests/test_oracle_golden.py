@@ -1,0 +1,139 @@
+"""CPU: the oracle (torch restatement) against golden vectors produced by the imported reference
+(oracle/gen_golden.py) and against the reference's own known-answer test."""
+import numpy as np
+import pytest
+import torch
+
+from centernet_amd import rng, synth
+from oracle import ops_ref, models_ref
+from conftest import strided, summary
+
+torch.set_num_threads(8)
+
+
+def _decode_inputs(seed, B, C, realistic):
+    z = rng.t_normal(seed, "heat", (B, C, 128, 128))
+    if realistic:
+        z = 0.5 * z - 2.19
+    return (torch.sigmoid(z), rng.t_uniform(seed, "wh", (B, 2, 128, 128), 1.0, 40.0),
+            rng.t_uniform(seed, "reg", (B, 2, 128, 128), 0.0, 1.0))
+
+
+def test_encoder_matches_reference_fixture(golden):
+    g = golden("encode_fixture.npz")
+    boxes = [(list(b), int(c)) for b, c in zip(g["boxes"], g["cls"])]
+    e = synth.encode_ctdet(boxes)
+    hm = e["heatmap"].reshape(-1)
+    nz = np.nonzero(hm)[0]
+    assert np.array_equal(nz, g["heatmap_nz_idx"])
+    np.testing.assert_allclose(hm[nz], g["heatmap_nz_val"], rtol=1e-6)   # exp() differs in the last ulp (numpy vs torch)
+    assert np.array_equal(hm[nz] == 1, g["heatmap_nz_val"] == 1)        # peaks exactly 1 (focal-loss gt==1 test)
+    for k in ("indices", "width_height", "regression", "regression_mask"):
+        assert np.array_equal(e[k], g[k]), k
+
+
+def test_known_answer_encode_decode(golden):
+    """reference tests/test_sample_encode_decode.py:35-56 restated on the oracle."""
+    g = golden("known_answer.npz")
+    e = synth.encode_ctdet(synth.FIXTURE_BOXES)
+    hm = torch.from_numpy(e["heatmap"]).unsqueeze(0)
+    wh = torch.zeros(1, 2, 128, 128)
+    reg = torch.zeros(1, 2, 128, 128)
+    for k in range(2):
+        y, x = divmod(int(e["indices"][k]), 128)
+        wh[0, :, y, x] = torch.from_numpy(e["width_height"][k])
+        reg[0, :, y, x] = torch.from_numpy(e["regression"][k])
+    det = ops_ref.ctdet_decode(hm, wh, reg)[0].numpy()
+    det = 4 * det[det[:, 4] > 0.5]
+    assert len(det) == int(g["n_det"]) == 2
+    centers = (det[:, :2] + det[:, 2:4]) / 2
+    ann = sum(b[0] + b[2] / 2 + b[1] + b[3] / 2 for b, _ in synth.FIXTURE_BOXES)
+    assert abs(centers.sum() - ann) < 1e-3
+    assert np.array_equal(det[np.argsort(det[:, 0])], g["det_sorted"])
+
+
+@pytest.mark.parametrize("tag", ["rand", "real", "small"])
+def test_decode_bit_exact(golden, tag):
+    g = golden(f"decode_{tag}.npz")
+    heat, wh, reg = _decode_inputs(int(g["seed"]), int(g["B"]), int(g["C"]), bool(g["realistic"]))
+    det, inds, clses = ops_ref.ctdet_decode(heat, wh, reg, K=int(g["K"]), return_aux=True)
+    assert np.array_equal(inds.numpy(), g["inds"])
+    assert np.array_equal(clses.numpy(), g["clses"])
+    assert np.array_equal(det.numpy(), g["det"])
+    assert np.array_equal(ops_ref.ctdet_decode(heat, wh, None, K=int(g["K"])).numpy(), g["det_noreg"])
+    keep = ops_ref.peak_mask(heat) & (heat != 0)
+    assert np.array_equal(keep.flatten(2).sum(-1).numpy(), g["peak_popcount"])
+    assert np.array_equal(np.packbits(keep[0, 0].numpy()), g["peak_mask_b0c0"])
+    s, i, _, _ = ops_ref.topk_channel(ops_ref.nms(heat), int(g["K"]))
+    assert np.array_equal(s[:, :3].numpy(), g["chan_scores"]) and np.array_equal(i[:, :3].numpy(), g["chan_inds"])
+
+
+def test_losses(golden):
+    g = golden("losses.npz")
+    seed = int(g["seed"])
+    _, tgt = synth.ctdet_batch(seed, 2)
+    logits = (rng.t_normal(seed, "logit", (2, 80, 128, 128)) * 1.5 - 2.19).requires_grad_(True)
+    whp = rng.t_normal(seed, "whp", (2, 2, 128, 128), 0, 5).requires_grad_(True)
+    regp = rng.t_normal(seed, "regp", (2, 2, 128, 128)).requires_grad_(True)
+    loss, st = ops_ref.ctdet_loss({"heatmap": logits, "width_height": whp, "regression": regp}, tgt)
+    loss.backward()
+    for k, gk in (("hm_loss", "hm"), ("wh_loss", "wh"), ("off_loss", "off"), ("loss", "loss")):
+        assert st[k].item() == pytest.approx(float(g[gk]), rel=1e-6), k
+    np.testing.assert_allclose(strided(logits.grad).numpy(), g["dlogits_s"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(summary(whp.grad), g["dwh_sum"], rtol=1e-6)
+    np.testing.assert_allclose(summary(regp.grad), g["dreg_sum"], rtol=1e-6)
+    kpp = rng.t_normal(seed, "kpp", (2, 34, 128, 128), 0, 3)
+    kmask = rng.t_uniform(seed, "kmask", (2, 128, 34)) > 0.5
+    ktgt = rng.t_normal(seed, "ktgt", (2, 128, 34), 0, 3)
+    assert ops_ref.reg_weighted_l1_loss(kpp, kmask, tgt["indices"], ktgt).item() == pytest.approx(float(g["kp"]), rel=1e-6)
+    gt0 = tgt["heatmap"].clone()
+    gt0[gt0 == 1] = 0.99
+    assert ops_ref.focal_loss(ops_ref.sigmoid_clamped(logits.detach()), gt0).item() == pytest.approx(float(g["hm_nopos"]), rel=1e-6)
+
+
+def test_pose_decode(golden):
+    g = golden("pose_decode.npz")
+    seed, B, K = int(g["seed"]), int(g["B"]), int(g["K"])
+    heat = torch.sigmoid(rng.t_normal(seed, "heat", (B, 1, 128, 128)))
+    hm_hp = torch.sigmoid(rng.t_normal(seed, "hmhp", (B, 17, 128, 128)) * 0.7 - 1.0)
+    wh = rng.t_uniform(seed, "wh", (B, 2, 128, 128), 4.0, 60.0)
+    reg = rng.t_uniform(seed, "reg", (B, 2, 128, 128))
+    kps = rng.t_normal(seed, "kps", (B, 34, 128, 128), 0, 6.0)
+    hpo = rng.t_uniform(seed, "hpo", (B, 2, 128, 128))
+    det = ops_ref.multi_pose_decode(heat, wh, kps, reg=reg, hm_hp=hm_hp, hp_offset=hpo, K=K)
+    np.testing.assert_allclose(det.numpy(), g["det"], rtol=0, atol=0)
+    det2 = ops_ref.multi_pose_decode(heat, wh, kps, reg=None, hm_hp=hm_hp, hp_offset=None, K=K)
+    np.testing.assert_allclose(det2.numpy(), g["det_nooff"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("arch,size,train", [("res_18", 256, False), ("res_18", 256, True),
+                                             ("dla_34", 128, False), ("dla_34", 128, True)])
+def test_model_matches_reference_graph(golden, arch, size, train):
+    name = {"res_18": "res18", "dla_34": "dla34"}[arch] + ("_train" if train else "_eval") + ".npz"
+    g = golden(name)
+    seed = int(g["seed"])
+    net = models_ref.CenterNetRef(arch)
+    rng.fill_state_dict(net, seed)
+    net.train(train)
+    x, tgt = synth.ctdet_batch(seed, 2, size, size)
+    feat = net.backbone(x)[0]
+    out = net.heads[0](feat)
+    np.testing.assert_allclose(strided(feat).numpy(), g["feat_s"], rtol=1e-4, atol=1e-5)
+    for k in ("heatmap", "width_height", "regression"):
+        np.testing.assert_allclose(strided(out[k]).numpy(), g[f"{k}_s"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(summary(out[k]), g[f"{k}_sum"], rtol=1e-4)
+    loss, st = net.loss([out], tgt)
+    for k, gk in (("hm_loss", "hm"), ("wh_loss", "wh"), ("off_loss", "off"), ("loss", "loss")):
+        assert st[k].item() == pytest.approx(float(g[gk]), rel=1e-4), k
+    if train:
+        loss.backward()
+        params = dict(net.named_parameters())
+        for key in g.files:
+            if key.startswith("g:") and key.endswith(":s"):
+                n = key[2:-2]
+                np.testing.assert_allclose(strided(params[n].grad, 512).numpy(), g[key], rtol=2e-3, atol=1e-6, err_msg=n)
+        dead = sorted(n for n, p in params.items() if p.grad is None)
+        assert dead == sorted(str(s) for s in g["dead_params"])
+    else:
+        det = ops_ref.ctdet_decode(ops_ref.sigmoid_clamped(out["heatmap"]), out["width_height"], out["regression"])
+        np.testing.assert_allclose(det.detach().numpy(), g["det"], rtol=1e-4, atol=1e-4)
