@@ -1,0 +1,115 @@
+"""ctypes binding of libcenternet_hip.so (the C ABI declared in include/centernet_hip.h).
+
+The prototypes are parsed from the header itself, so the binding can never drift from the ABI.
+There is NO fallback: if the shared library is missing the import of any op fails loudly.
+PyTorch is used only as plumbing here (device memory, current stream).
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(_ROOT, "include", "centernet_hip.h")
+LIB_PATH = os.path.join(_PKG, "libcenternet_hip.so")
+
+CN_F32, CN_BF16 = 0, 1
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+    "int64_t": ctypes.c_int64, "int32_t": ctypes.c_int32, "void": None,
+}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype_str, [(type_str, arg_name), ...])} for every `cn_*` prototype."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t|const char\s*\*)\s+(cn_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                alist.append((mm.group(1).strip(), mm.group(2)))
+        protos[name] = (ret, alist)
+    return protos
+
+
+def _ctype(t):
+    if "*" in t:
+        return ctypes.c_void_p
+    return _CT[t.replace("const ", "").strip()]
+
+
+_lib = None
+_protos = None
+
+
+def lib():
+    global _lib, _protos
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (or `make -C centernet-pytorch-lightning_amd/csrc -j8`). There is no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _protos = parse_header()
+        for name, (ret, args) in _protos.items():
+            fn = getattr(_lib, name)
+            fn.restype = ctypes.c_char_p if "char" in ret else _CT[ret]
+            fn.argtypes = [_ctype(t) for t, _ in args]
+    return _lib
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return CN_F32
+    if dt == torch.bfloat16:
+        return CN_BF16
+    raise TypeError(f"unsupported activation dtype {dt}")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _arg(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        if not a.is_cuda:
+            raise RuntimeError("centernet_hip: tensor argument is not on the GPU (no CPU path exists)")
+        return a.data_ptr()
+    return a
+
+
+def call(name, *args):
+    """Invoke cn_<name>; tensors become device pointers; the current torch stream is appended."""
+    L = lib()
+    fn = getattr(L, name)
+    rc = fn(*[_arg(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (status {rc}): {L.cn_last_error().decode()}")
+
+
+def query(name, *args):
+    """size_t / int queries without a stream argument."""
+    return getattr(lib(), name)(*args)
+
+
+_ws = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Persistent per-device scratch buffer (stream-ordered reuse on the current stream)."""
+    key = (tag, torch.device(device).index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

@@ -1,0 +1,61 @@
+"""`CenterNetDetection` (reference: CenterNet/centernet_detection.py:28-265) — forward / loss / decode on the HIP path.
+TTA resize, COCO evaluation and the CLI are outside the hot-path scope."""
+import torch
+
+from .centernet import CenterNet
+from .decode.ctdet import ctdet_decode
+from .models.heads import CenterHead
+from .utils.decode import sigmoid_clamped
+from .utils.losses import FocalLoss, RegL1Loss
+
+
+class CenterNetDetection(CenterNet):
+    mean = [0.408, 0.447, 0.470]
+    std = [0.289, 0.274, 0.278]
+    max_objs = 128
+    valid_ids = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 27, 28, 31, 32, 33,
+                 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61,
+                 62, 63, 64, 65, 67, 70, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 84, 85, 86, 87, 88, 89, 90]
+
+    def __init__(self, arch, learning_rate=1e-4, learning_rate_milestones=None, hm_weight=1, wh_weight=0.1, off_weight=1,
+                 num_classes=80, test_coco=None, test_coco_ids=None, test_scales=None, test_flip=False,
+                 compute_dtype=torch.bfloat16):
+        super().__init__(arch, compute_dtype=compute_dtype)
+        self.num_classes = num_classes
+        heads = {"heatmap": self.num_classes, "width_height": 2, "regression": 2}
+        self.heads = torch.nn.ModuleList([CenterHead(heads, self.backbone.out_channels, self.head_conv)
+                                          for _ in range(self.num_stacks)])
+        self.learning_rate_milestones = learning_rate_milestones if learning_rate_milestones is not None else []
+        self.test_coco, self.test_coco_ids = test_coco, test_coco_ids
+        self.test_max_per_image = 100
+        self.test_scales = [1] if test_scales is None else test_scales
+        self.test_flip = test_flip
+        self.criterion = FocalLoss()
+        self.criterion_regression = RegL1Loss()
+        self.criterion_width_height = RegL1Loss()
+        self.save_hyperparameters()
+
+    def forward(self, x):
+        return [head(out) for head, out in zip(self.heads, self.backbone(x))]
+
+    def loss(self, outputs, target):
+        hm_loss, wh_loss, off_loss = 0, 0, 0
+        num_stacks = len(outputs)
+        for output in outputs:
+            output["heatmap"] = sigmoid_clamped(output["heatmap"])
+            hm_loss = hm_loss + self.criterion(output["heatmap"], target["heatmap"])
+            wh_loss = wh_loss + self.criterion_width_height(output["width_height"], target["regression_mask"],
+                                                            target["indices"], target["width_height"])
+            off_loss = off_loss + self.criterion_regression(output["regression"], target["regression_mask"],
+                                                            target["indices"], target["regression"])
+        loss = (self.hparams.hm_weight * hm_loss + self.hparams.wh_weight * wh_loss
+                + self.hparams.off_weight * off_loss) / num_stacks
+        return loss, {"loss": loss, "hm_loss": hm_loss, "wh_loss": wh_loss, "off_loss": off_loss}
+
+    @torch.no_grad()
+    def decode(self, output, K=100):
+        """The decode call of test_step_end (centernet_detection.py:183-187): sigmoid in place, then ctdet_decode."""
+        return ctdet_decode(output["heatmap"].sigmoid_(), output["width_height"], reg=output["regression"], K=K)
+
+    def test_step(self, batch, batch_idx):
+        raise NotImplementedError("TTA / COCO evaluation are outside the hot-path scope of this build; use `decode`")

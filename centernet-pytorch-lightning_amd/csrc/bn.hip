@@ -1,0 +1,275 @@
+// BatchNorm2d (training statistics, running-stat update, backward) + ReLU + residual add on NHWC.
+// All kernels are HBM-bound: 16-byte vector accesses, fp32 accumulation, deterministic two-level
+// reduction (per-workgroup partials -> one finalize workgroup in fp64), no atomics.
+#include "common.h"
+
+#define BN_MAX_BLOCKS 1024
+
+struct BnLayout {
+    int CV;    // 16-byte channel vectors per pixel
+    int CVB;   // vectors handled per workgroup column (<= 256)
+    int RPB;   // pixel rows per workgroup pass = 256 / CVB
+    int ycols; // grid.y
+    int nblk;  // grid.x
+    int64_t rows_per_blk;
+};
+
+static BnLayout bn_layout(int64_t npix, int C, int vec) {
+    BnLayout L;
+    L.CV = C / vec;
+    L.CVB = L.CV < 256 ? L.CV : 256;
+    L.RPB = 256 / L.CVB;
+    L.ycols = (L.CV + L.CVB - 1) / L.CVB;
+    int64_t want = (npix + (int64_t)L.RPB * 8 - 1) / ((int64_t)L.RPB * 8);  // >= 8 passes per workgroup
+    L.nblk = (int)(want < 1 ? 1 : (want > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : want));
+    L.rows_per_blk = (npix + L.nblk - 1) / L.nblk;
+    return L;
+}
+
+extern "C" size_t cn_bn_workspace_bytes(int64_t npix, int C) {
+    (void)npix;
+    // partials [BN_MAX_BLOCKS][2][C] fp32 + coefficients [4][C] fp32
+    return ((size_t)BN_MAX_BLOCKS * 2 * C + 4 * (size_t)C) * sizeof(float);
+}
+
+// MODE 0: (sum x, sum x^2)      MODE 1: (sum dy', sum dy' * xhat)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         const T* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, float* __restrict__ part,
+                                                         int64_t npix, int C, BnLayout L, int relu) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float red[2][256][V + 1];
+    const int tid = threadIdx.x;
+    const int cvl = tid % L.CVB, prow = tid / L.CVB;
+    const int cv = blockIdx.y * L.CVB + cvl;
+    const bool active = prow < L.RPB && cv < L.CV;
+    float s0[V], s1[V], mu[V], is[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s0[j] = 0.f; s1[j] = 0.f; mu[j] = 0.f; is[j] = 1.f; }
+    if (active) {
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { mu[j] = mean[cv * V + j]; is[j] = invstd[cv * V + j]; }
+        }
+        const int64_t r0 = (int64_t)blockIdx.x * L.rows_per_blk;
+        const int64_t r1 = r0 + L.rows_per_blk < npix ? r0 + L.rows_per_blk : npix;
+        for (int64_t r = r0 + prow; r < r1; r += L.RPB) {
+            float xv[V];
+            Vec16<T>::load(x + r * C + cv * V, xv);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { s0[j] += xv[j]; s1[j] = fmaf(xv[j], xv[j], s1[j]); }
+            } else {
+                float gv[V], yv[V];
+                Vec16<T>::load(dy + r * C + cv * V, gv);
+                if (relu) {
+                    Vec16<T>::load(y + r * C + cv * V, yv);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < V; ++j) { s0[j] += gv[j]; s1[j] = fmaf(gv[j], (xv[j] - mu[j]) * is[j], s1[j]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[0][tid][j] = s0[j]; red[1][tid][j] = s1[j]; }
+    __syncthreads();
+    if (prow == 0 && cv < L.CV) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float a = 0.f, b = 0.f;
+            for (int p = 0; p < L.RPB; ++p) { a += red[0][p * L.CVB + cvl][j]; b += red[1][p * L.CVB + cvl][j]; }
+            part[((int64_t)blockIdx.x * 2 + 0) * C + cv * V + j] = a;
+            part[((int64_t)blockIdx.x * 2 + 1) * C + cv * V + j] = b;
+        }
+    }
+}
+
+// coef layout (after the partials): [0]=scale|a  [1]=shift|b  [2]=c  [3]=unused
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ part, int nblk, int C, int64_t npix,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar,
+                                                              float* __restrict__ smean, float* __restrict__ sinvstd,
+                                                              float* __restrict__ coef, float momentum, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    const double m = s / (double)npix;
+    double var = q / (double)npix - m * m;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    smean[c] = (float)m;
+    sinvstd[c] = invstd;
+    if (rmean) {
+        const double unb = npix > 1 ? var * (double)npix / (double)(npix - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+    const float sc = gamma[c] * invstd;
+    coef[c] = sc;
+    coef[C + c] = beta[c] - (float)m * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int C, int64_t npix,
+                                                              const float* __restrict__ gamma, const float* __restrict__ sinvstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    coef[c] = gamma[c] * sinvstd[c];
+    coef[C + c] = (float)(s / (double)npix);
+    coef[2 * C + c] = (float)(q / (double)npix);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                              T* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int64_t nvec, int CV, int relu) {
+    constexpr int V = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        float xv[V], rv[V];
+        Vec16<T>::load(x + i * V, xv);
+        if (res) Vec16<T>::load(res + i * V, rv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float v = fmaf(xv[j], scale[cv * V + j], shift[cv * V + j]);
+            if (res) v += rv[j];
+            if (relu) v = fmaxf(v, 0.f);
+            xv[j] = v;
+        }
+        Vec16<T>::store(y + i * V, xv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           T* __restrict__ dx, T* __restrict__ dres, int64_t nvec, int CV,
+                                                           int C, int relu) {
+    constexpr int V = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        float gv[V], xv[V], yv[V];
+        Vec16<T>::load(dy + i * V, gv);
+        Vec16<T>::load(x + i * V, xv);
+        if (relu) {
+            Vec16<T>::load(y + i * V, yv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+        }
+        if (dres) Vec16<T>::store(dres + i * V, gv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = cv * V + j;
+            const float xh = (xv[j] - mean[c]) * invstd[c];
+            xv[j] = coef[c] * (gv[j] - coef[C + c] - xh * coef[2 * C + c]);
+        }
+        Vec16<T>::store(dx + i * V, xv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                                       int64_t nvec) {
+    constexpr int V = Vec16<T>::N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        float gv[V], yv[V];
+        Vec16<T>::load(dy + i * V, gv);
+        Vec16<T>::load(y + i * V, yv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+        Vec16<T>::store(dx + i * V, gv);
+    }
+}
+
+static int ew_grid(int64_t nvec) {
+    int64_t g = (nvec + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                               int64_t npix, int C, float momentum, float eps, int relu, int dtype,
+                               void* ws, size_t ws_bytes, void* stream) {
+    CN_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && ws && npix > 0 && C > 0, "cn_bn_train_fwd: bad args");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0, "cn_bn_train_fwd: C=%d must be a multiple of %d", C, V);
+    if (ws_bytes < cn_bn_workspace_bytes(npix, C)) { cn_set_error("cn_bn_train_fwd: workspace too small"); return CN_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    BnLayout L = bn_layout(npix, C, V);
+    float* part = (float*)ws;
+    float* coef = part + (size_t)BN_MAX_BLOCKS * 2 * C;
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3(L.nblk, L.ycols), dim3(256), 0, st,
+                                                   (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
+                                                   (const float*)nullptr, part, npix, C, L, 0));
+    CN_LAUNCH_CHECK("cn_bn_train_fwd(partial)");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, coef, momentum, eps);
+    CN_LAUNCH_CHECK("cn_bn_train_fwd(finalize)");
+    int64_t nvec = npix * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, st,
+                                                   (const T*)x, (const T*)residual, (T*)y, coef, coef + C, nvec, C / V, relu));
+    CN_LAUNCH_CHECK("cn_bn_train_fwd(apply)");
+    return CN_OK;
+}
+
+extern "C" int cn_scale_shift_act(const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                                  int64_t npix, int C, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(x && y && scale && shift && npix > 0 && C > 0, "cn_scale_shift_act: bad args");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0, "cn_scale_shift_act: C=%d must be a multiple of %d", C, V);
+    int64_t nvec = npix * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)x, (const T*)residual, (T*)y, scale, shift,
+                                                   nvec, C / V, relu));
+    CN_LAUNCH_CHECK("cn_scale_shift_act");
+    return CN_OK;
+}
+
+extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                               const float* save_invstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                               int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    CN_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && npix > 0 && C > 0,
+                 "cn_bn_train_bwd: bad args");
+    CN_CHECK_ARG(!relu || y, "cn_bn_train_bwd: relu needs the forward output");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0, "cn_bn_train_bwd: C=%d must be a multiple of %d", C, V);
+    if (ws_bytes < cn_bn_workspace_bytes(npix, C)) { cn_set_error("cn_bn_train_bwd: workspace too small"); return CN_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    BnLayout L = bn_layout(npix, C, V);
+    float* part = (float*)ws;
+    float* coef = part + (size_t)BN_MAX_BLOCKS * 2 * C;
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3(L.nblk, L.ycols), dim3(256), 0, st,
+                                                   (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, part, npix,
+                                                   C, L, relu));
+    CN_LAUNCH_CHECK("cn_bn_train_bwd(partial)");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, save_invstd,
+                       dgamma, dbeta, coef);
+    CN_LAUNCH_CHECK("cn_bn_train_bwd(finalize)");
+    int64_t nvec = npix * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, st,
+                                                   (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, coef,
+                                                   (T*)dx, (T*)dres, nvec, C / V, C, relu));
+    CN_LAUNCH_CHECK("cn_bn_train_bwd(apply)");
+    return CN_OK;
+}
+
+extern "C" int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream) {
+    CN_CHECK_ARG(dy && y && dx && n > 0, "cn_relu_bwd: bad args");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(n % V == 0, "cn_relu_bwd: n must be a multiple of %d", V);
+    int64_t nvec = n / V;
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dy, (const T*)y, (T*)dx, nvec));
+    CN_LAUNCH_CHECK("cn_relu_bwd");
+    return CN_OK;
+}

@@ -1,0 +1,138 @@
+// Shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include "../../include/centernet_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+
+void cn_set_error(const char* fmt, ...);
+
+#define CN_CHECK_ARG(cond, ...)                                                                     \
+    do {                                                                                            \
+        if (!(cond)) {                                                                              \
+            cn_set_error(__VA_ARGS__);                                                              \
+            return CN_EINVAL;                                                                       \
+        }                                                                                           \
+    } while (0)
+
+#define CN_UNSUPPORTED(...)                                                                         \
+    do {                                                                                            \
+        cn_set_error(__VA_ARGS__);                                                                  \
+        return CN_EUNSUPPORTED;                                                                     \
+    } while (0)
+
+#define CN_LAUNCH_CHECK(name)                                                                       \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) {                                                                     \
+            cn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));                     \
+            return (int)e_;                                                                         \
+        }                                                                                           \
+    } while (0)
+
+#define CN_HIP(call)                                                                                \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            cn_set_error("%s failed: %s", #call, hipGetErrorString(e_));                            \
+            return (int)e_;                                                                         \
+        }                                                                                           \
+    } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- bf16 <-> f32 (round-to-nearest-even) -------------------------------------------------------
+__host__ __device__ static inline float bf2f(bf16_t b) {
+    union { uint32_t u; float f; } v;
+    v.u = ((uint32_t)b) << 16;
+    return v.f;
+}
+__host__ __device__ static inline bf16_t f2bf(float f) {
+    union { uint32_t u; float f; } v;
+    v.f = f;
+    uint32_t u = v.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kDtype = CN_F32;
+    static constexpr int kVec = 4;  // elements per 16-byte vector
+    __device__ static inline float ld(const float* p) { return *p; }
+    __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kDtype = CN_BF16;
+    static constexpr int kVec = 8;
+    __device__ static inline float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static inline void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte vector <-> float[kVec]
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static inline void load(const float* p, float* out) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    }
+    __device__ static inline void store(float* p, const float* in) {
+        *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
+    }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static inline void load(const bf16_t* p, float* out) {
+        uint4 v = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[2 * i] = __uint_as_float(w[i] << 16);
+            out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static inline void store(bf16_t* p, const float* in) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(in[2 * i]) | ((uint32_t)f2bf(in[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ---- wave / block reductions (wave = 64 lanes) -----------------------------------------------------
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ static inline double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ static inline unsigned wave_sum_u(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// dispatch on dtype
+#define CN_DISPATCH_DTYPE(dtype, T, ...)                                                            \
+    do {                                                                                            \
+        if ((dtype) == CN_F32) {                                                                    \
+            typedef float T;                                                                        \
+            __VA_ARGS__;                                                                            \
+        } else if ((dtype) == CN_BF16) {                                                            \
+            typedef bf16_t T;                                                                       \
+            __VA_ARGS__;                                                                            \
+        } else {                                                                                    \
+            cn_set_error("bad dtype %d", (int)(dtype));                                             \
+            return CN_EINVAL;                                                                       \
+        }                                                                                           \
+    } while (0)

@@ -1,0 +1,279 @@
+// Weight-gradient GEMM for gfx950:  dWp[co][tap*Ci + ci] += sum_p dY[p][co] * Xg[p, tap][ci]
+//
+// The contraction runs over PIXELS, which is the slow axis of both NHWC operands, so MFMA
+// fragments (k-contiguous per lane) need a transpose on the way in:
+//   * bf16: each thread loads 16 B (8 channels of one pixel) and scatters them as 8 ds_write_b16
+//     into a channel-major LDS image [channel][32 pixels]; the four 8-pixel chunks of a row are
+//     XOR-swizzled with (channel>>3)&3 so both the scattered writes and the ds_read_b128 fragment
+//     reads spread over the banks.  MFMA: v_mfma_f32_32x32x16_bf16.
+//   * fp32 (parity mode): v_mfma_f32_32x32x2_f32 takes ONE f32 per lane, so the natural
+//     [pixel][channel] image is already conflict-free — no transpose.
+// Split-K over pixel chunks (blockIdx.x) with fp32 atomics into the (pre-zeroed) packed gradient;
+// blockIdx.z = tap, blockIdx.y = (co tile, ci tile).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct WgradGeom {
+    const void* x;
+    const void* dy;
+    float* dwp;
+    int N, H, W, Ci, x_ld;
+    int OH, OW, Co, dy_ld;
+    int KW, stride, pad;
+    int ktot, co_pad;
+    int ci_tiles;
+    int64_t P;          // N*OH*OW
+    int64_t chunk;      // pixels per split-K chunk (multiple of the K tile)
+};
+
+template <typename T, int BMW, int BNW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int BKP = BF ? 32 : 16;              // pixels per K tile
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int YV = BKP * BMW / VEC / 256;      // 16-byte loads per thread for the dY tile
+    constexpr int XV = BKP * BNW / VEC / 256;
+    constexpr int YCG = BMW / VEC, XCG = BNW / VEC;  // channel groups per pixel row
+    constexpr int WM = BMW / 2, WN = BNW / 2;      // 2x2 waves
+    constexpr int MI = WM / 32, NJ = WN / 32;
+    constexpr int KSTEPS = BF ? 2 : 8;
+    static_assert(YV >= 1 && XV >= 1, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) T lds[2 * (BMW + BNW) * BKP];
+    constexpr int BUF = (BMW + BNW) * BKP;  // elements per pipeline stage: [dY tile | X tile]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tap = blockIdx.z;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const int co0 = (blockIdx.y / g.ci_tiles) * BMW;
+    const int ci0 = (blockIdx.y % g.ci_tiles) * BNW;
+    const int64_t pbeg = (int64_t)blockIdx.x * g.chunk;
+    const int64_t pend = (pbeg + g.chunk < g.P) ? pbeg + g.chunk : g.P;
+    if (pbeg >= g.P) return;
+    const int ntiles = (int)((pend - pbeg + BKP - 1) / BKP);
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(g.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(g.dy);
+
+    // per-thread load slots: slot v -> (pixel-in-tile, channel group)
+    int y_px[YV], y_cg[YV], x_px[XV], x_cg[XV];
+    // running (n, oh, ow) of the X-loader pixels (advance by BKP per tile)
+    int xo_n[XV], xo_h[XV], xo_w[XV];
+#pragma unroll
+    for (int v = 0; v < YV; ++v) {
+        int idx = tid + v * 256;
+        y_px[v] = idx / YCG;
+        y_cg[v] = idx % YCG;
+    }
+#pragma unroll
+    for (int v = 0; v < XV; ++v) {
+        int idx = tid + v * 256;
+        x_px[v] = idx / XCG;
+        x_cg[v] = idx % XCG;
+        int64_t p = pbeg + x_px[v];
+        int n = (int)(p / ((int64_t)g.OH * g.OW));
+        int r = (int)(p - (int64_t)n * g.OH * g.OW);
+        xo_n[v] = n;
+        xo_h[v] = r / g.OW;
+        xo_w[v] = r - xo_h[v] * g.OW;
+    }
+
+    uint4 ry[YV], rx[XV];
+    auto gload = [&](int tile) {
+        const int64_t p0 = pbeg + (int64_t)tile * BKP;
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            int64_t p = p0 + y_px[v];
+            int c = co0 + y_cg[v] * VEC;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (p < pend && c < g.Co) val = *reinterpret_cast<const uint4*>(DY + p * g.dy_ld + c);  // dy_ld padded to VEC
+            ry[v] = val;
+        }
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            int64_t p = p0 + x_px[v];
+            int c = ci0 + x_cg[v] * VEC;
+            int ih = xo_h[v] * g.stride - g.pad + kh, iw = xo_w[v] * g.stride - g.pad + kw;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (p < pend && c < g.Ci && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+                val = *reinterpret_cast<const uint4*>(X + (((int64_t)xo_n[v] * g.H + ih) * g.W + iw) * g.x_ld + c);
+            rx[v] = val;
+            // advance this slot's pixel by one K tile
+            xo_w[v] += BKP;
+            while (xo_w[v] >= g.OW) { xo_w[v] -= g.OW; xo_h[v] += 1; }
+            while (xo_h[v] >= g.OH) { xo_h[v] -= g.OH; xo_n[v] += 1; }
+        }
+    };
+    auto lstore = [&](int buf) {
+        if constexpr (BF) {
+            unsigned short* ys = reinterpret_cast<unsigned short*>((lds + buf * BUF));
+            unsigned short* xs = reinterpret_cast<unsigned short*>((lds + buf * BUF + BMW * BKP));
+#pragma unroll
+            for (int v = 0; v < YV; ++v) {
+                const uint32_t w[4] = {ry[v].x, ry[v].y, ry[v].z, ry[v].w};
+                const int col = (((y_px[v] >> 3) ^ (y_cg[v] & 3)) << 3) + (y_px[v] & 7);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    ys[(y_cg[v] * 8 + j) * BKP + col] = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+            }
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                const uint32_t w[4] = {rx[v].x, rx[v].y, rx[v].z, rx[v].w};
+                const int col = (((x_px[v] >> 3) ^ (x_cg[v] & 3)) << 3) + (x_px[v] & 7);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    xs[(x_cg[v] * 8 + j) * BKP + col] = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < YV; ++v)
+                *reinterpret_cast<uint4*>(reinterpret_cast<float*>((lds + buf * BUF)) + y_px[v] * BMW + y_cg[v] * 4) = ry[v];
+#pragma unroll
+            for (int v = 0; v < XV; ++v)
+                *reinterpret_cast<uint4*>(reinterpret_cast<float*>((lds + buf * BUF + BMW * BKP)) + x_px[v] * BNW + x_cg[v] * 4) = rx[v];
+        }
+    };
+
+    f32x16_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const bool more = tile + 1 < ntiles;
+        if (more) gload(tile + 1);
+        if constexpr (BF) {
+            const bf16_t* yt = reinterpret_cast<const bf16_t*>((lds + cur * BUF));
+            const bf16_t* xt = reinterpret_cast<const bf16_t*>((lds + cur * BUF + BMW * BKP));
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                bf16x8_t fa[MI], fb[NJ];
+                const int chunk = kk * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int row = wm + i * 32 + (lane & 31);
+                    fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(yt + row * BKP + ((chunk ^ ((row >> 3) & 3)) << 3)));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    int row = wn + j * 32 + (lane & 31);
+                    fb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xt + row * BKP + ((chunk ^ ((row >> 3) & 3)) << 3)));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const float* yt = reinterpret_cast<const float*>((lds + cur * BUF));
+            const float* xt = reinterpret_cast<const float*>((lds + cur * BUF + BMW * BKP));
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                float fa[MI], fb[NJ];
+                const int k = kk * 2 + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = yt[k * BMW + wm + i * 32 + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = xt[k * BNW + wn + j * 32 + (lane & 31)];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // D rows = co: (r&3) + 8*(r>>2) + 4*(lane>>5); D col = ci: lane&31
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int ci = ci0 + wn + j * 32 + (lane & 31);
+            if (ci >= g.Ci) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.Co) atomicAdd(g.dwp + (int64_t)co * g.ktot + (int64_t)tap * g.Ci + ci, acc[i][j][r]);
+            }
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t P, int C,
+                                                     int ld, int64_t chunk) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+    float s = 0.f;
+    for (int64_t p = p0; p < p1; ++p) s += Elem<T>::ld(dy + p * ld + c);
+    atomicAdd(db + c, s);
+}
+
+template <typename T, int BMW, int BNW>
+static void launch_wgrad(WgradGeom& g, int taps, hipStream_t st) {
+    constexpr int BKP = sizeof(T) == 2 ? 32 : 16;
+    int co_tiles = cdiv(g.Co, BMW);
+    g.ci_tiles = cdiv(g.Ci, BNW);
+    int base = co_tiles * g.ci_tiles * taps;
+    int64_t want = (2048 + base - 1) / base;           // target >= ~2048 workgroups
+    int64_t maxk = (g.P + 8 * BKP - 1) / (8 * BKP);    // at least 8 K tiles per workgroup
+    if (want > maxk) want = maxk;
+    if (want < 1) want = 1;
+    g.chunk = ((g.P + want - 1) / want + BKP - 1) / BKP * BKP;
+    int kchunks = (int)((g.P + g.chunk - 1) / g.chunk);
+    dim3 grid(kchunks, co_tiles * g.ci_tiles, taps);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW>), grid, dim3(256), 0, st, g);
+}
+
+extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
+                               int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                               int KH, int KW, int stride, int pad, int dtype, void* stream) {
+    CN_CHECK_ARG(x && dy && dwp, "cn_conv2d_wgrad: null pointer");
+    CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0 && Ci > 0, "cn_conv2d_wgrad: bad dims");
+    int V = dtype == CN_F32 ? 4 : 8;
+    if (Ci % V != 0) CN_UNSUPPORTED("cn_conv2d_wgrad: Ci=%d must be a multiple of %d", Ci, V);
+    CN_CHECK_ARG(x_ld % V == 0 && dy_ld % V == 0 && x_ld >= Ci && dy_ld >= ((Co + V - 1) / V) * V,
+                 "cn_conv2d_wgrad: pitches must be multiples of %d and cover the (vector-padded) channels: x_ld=%d dy_ld=%d Co=%d",
+                 V, x_ld, dy_ld, Co);
+    CN_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "cn_conv2d_wgrad: pointers must be 16-byte aligned");
+    WgradGeom g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.dy = dy; g.dwp = dwp;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = OH; g.OW = OW; g.Co = Co; g.dy_ld = dy_ld;
+    g.KW = KW; g.stride = stride; g.pad = pad; g.ktot = KH * KW * Ci; g.co_pad = (Co + 31) / 32 * 32;
+    g.P = (int64_t)N * OH * OW;
+    hipStream_t st = (hipStream_t)stream;
+    const bool bigm = Co > 64, bign = Ci > 64;
+#define CN_WG(T) \
+    do { if (bigm && bign) launch_wgrad<T, 128, 128>(g, KH * KW, st); \
+         else if (bigm) launch_wgrad<T, 128, 64>(g, KH * KW, st); \
+         else if (bign) launch_wgrad<T, 64, 128>(g, KH * KW, st); \
+         else launch_wgrad<T, 64, 64>(g, KH * KW, st); } while (0)
+    if (dtype == CN_F32) CN_WG(float);
+    else if (dtype == CN_BF16) CN_WG(bf16_t);
+    else CN_CHECK_ARG(false, "cn_conv2d_wgrad: bad dtype %d", dtype);
+#undef CN_WG
+    CN_LAUNCH_CHECK("cn_conv2d_wgrad");
+    if (db) {
+        int64_t chunk = 512;
+        dim3 grid(cdiv(g.P, chunk), cdiv(Co, 256));
+        CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, db, g.P, Co,
+                                                       dy_ld, chunk));
+        CN_LAUNCH_CHECK("cn_conv2d_wgrad(bias)");
+    }
+    return CN_OK;
+}

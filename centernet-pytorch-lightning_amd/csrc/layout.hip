@@ -1,0 +1,166 @@
+// Layout boundary + trivial element-wise kernels (HBM-bound; 16-byte vector accesses).
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void cn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int cn_version(void) { return 100; }
+extern "C" const char* cn_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// NCHW fp32 -> NHWC T, tile = 64 pixels x 32 channels through LDS (both sides coalesced).
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                           int C, int HW, int Cpad) {
+    __shared__ float tile[32][65];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = (tid >> 6) + 4 * i, p = tid & 63;
+        float v = 0.f;
+        if (c0 + c < C && p0 + p < HW) v = src[((int64_t)n * C + c0 + c) * HW + p0 + p];
+        tile[c][p] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int p = (tid >> 5) + 8 * i, c = tid & 31;
+        if (c0 + c < Cpad && p0 + p < HW) Elem<T>::st(dst + ((int64_t)n * HW + p0 + p) * Cpad + c0 + c, tile[c][p]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int ld) {
+    __shared__ float tile[32][65];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int p = (tid >> 5) + 8 * i, c = tid & 31;
+        float v = 0.f;
+        if (c0 + c < C && p0 + p < HW) v = Elem<T>::ld(src + ((int64_t)n * HW + p0 + p) * ld + c0 + c);
+        tile[c][p] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int c = (tid >> 6) + 4 * i, p = tid & 63;
+        if (c0 + c < C && p0 + p < HW) dst[((int64_t)n * C + c0 + c) * HW + p0 + p] = tile[c][p];
+    }
+}
+
+extern "C" int cn_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype,
+                               void* stream) {
+    CN_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "cn_nchw_to_nhwc: bad args");
+    int HW = H * W;
+    dim3 grid(cdiv(HW, 64), cdiv(Cpad, 32), N);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
+                                                   src, (T*)dst, C, HW, Cpad));
+    CN_LAUNCH_CHECK("cn_nchw_to_nhwc");
+    return CN_OK;
+}
+
+extern "C" int cn_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int ld, int dtype,
+                               void* stream) {
+    CN_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C, "cn_nhwc_to_nchw: bad args");
+    int HW = H * W;
+    dim3 grid(cdiv(HW, 64), cdiv(C, 32), N);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)src, dst, C, HW, ld));
+    CN_LAUNCH_CHECK("cn_nhwc_to_nchw");
+    return CN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const T* __restrict__ src, int src_ld, int src_off,
+                                                            T* __restrict__ dst, int dst_ld, int dst_off,
+                                                            int64_t npix, int nvec /* vectors per pixel */) {
+    constexpr int V = Vec16<T>::N;
+    int64_t total = npix * nvec;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = i / nvec;
+        int v = (int)(i - p * nvec);
+        uint4 val = *reinterpret_cast<const uint4*>(src + p * src_ld + src_off + v * V);
+        *reinterpret_cast<uint4*>(dst + p * dst_ld + dst_off + v * V) = val;
+    }
+}
+
+extern "C" int cn_copy_channels(const void* src, int src_ld, int src_off, void* dst, int dst_ld, int dst_off,
+                                int64_t npix, int nch, int dtype, void* stream) {
+    CN_CHECK_ARG(src && dst && npix > 0 && nch > 0, "cn_copy_channels: bad args");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(nch % V == 0 && src_ld % V == 0 && dst_ld % V == 0 && src_off % V == 0 && dst_off % V == 0,
+                 "cn_copy_channels: channel counts/offsets must be multiples of %d (got nch=%d src %d+%d dst %d+%d)", V,
+                 nch, src_ld, src_off, dst_ld, dst_off);
+    int nvec = nch / V;
+    int grid = (int)((npix * nvec + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)src, src_ld, src_off, (T*)dst, dst_ld, dst_off, npix, nvec));
+    CN_LAUNCH_CHECK("cn_copy_channels");
+    return CN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                  int64_t n) {
+    constexpr int V = Vec16<T>::N;
+    int64_t nv = n / V;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float x[V], y[V];
+        Vec16<T>::load(a + i * V, x);
+        Vec16<T>::load(b + i * V, y);
+#pragma unroll
+        for (int j = 0; j < V; ++j) x[j] += y[j];
+        Vec16<T>::store(out + i * V, x);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - nv * V)) {
+        int64_t i = nv * V + threadIdx.x;
+        Elem<T>::st(out + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
+    }
+}
+
+extern "C" int cn_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+    CN_CHECK_ARG(a && b && out && n > 0, "cn_add: bad args");
+    int V = dtype == CN_F32 ? 4 : 8;
+    int grid = (int)((n / V + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(add_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)a, (const T*)b, (T*)out, n));
+    CN_LAUNCH_CHECK("cn_add");
+    return CN_OK;
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<D>::st(d + i, Elem<S>::ld(s + i));
+}
+
+extern "C" int cn_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+    CN_CHECK_ARG(src && dst && n > 0, "cn_cast: bad args");
+    int grid = (int)((n + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (sd == CN_F32 && dd == CN_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == CN_BF16 && dd == CN_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == CN_F32 && dd == CN_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else if (sd == CN_BF16 && dd == CN_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else
+        CN_CHECK_ARG(false, "cn_cast: bad dtypes %d -> %d", sd, dd);
+    CN_LAUNCH_CHECK("cn_cast");
+    return CN_OK;
+}

@@ -1,0 +1,226 @@
+// Losses of the CenterNet heads (utils/losses.py) on the public NCHW fp32 head maps.
+// Focal loss: one streaming pass (16-byte loads), per-workgroup partials -> fp64 finalize on device, so there is
+// no host sync on `num_pos == 0` (utils/losses.py:35).  Gather-L1: reads only the <=N indexed rows, never
+// materialises the NHWC transpose the reference makes (utils/decode.py:59-63).
+#include "common.h"
+
+#define FOCAL_MAX_BLOCKS 2048
+
+__global__ __launch_bounds__(256) void sigmoid_clamp_fwd_kernel(float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                                float lo) {
+    const float hi = 1.f - lo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = 1.f / (1.f + expf(-x[i]));
+        x[i] = s;
+        y[i] = fminf(fmaxf(s, lo), hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_clamp_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                                float* __restrict__ dz, int64_t n, float lo) {
+    const float hi = 1.f - lo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = s[i];
+        dz[i] = (p >= lo && p <= hi) ? dy[i] * p * (1.f - p) : 0.f;
+    }
+}
+
+extern "C" int cn_sigmoid_clamp_fwd(float* x, float* y, int64_t n, float lo, void* stream) {
+    CN_CHECK_ARG(x && y && n > 0, "cn_sigmoid_clamp_fwd: bad args");
+    int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(sigmoid_clamp_fwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, x, y, n, lo);
+    CN_LAUNCH_CHECK("cn_sigmoid_clamp_fwd");
+    return CN_OK;
+}
+
+extern "C" int cn_sigmoid_clamp_bwd(const float* dy, const float* x_sig, float* dz, int64_t n, float lo, void* stream) {
+    CN_CHECK_ARG(dy && x_sig && dz && n > 0, "cn_sigmoid_clamp_bwd: bad args");
+    int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(sigmoid_clamp_bwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, dy, x_sig, dz, n, lo);
+    CN_LAUNCH_CHECK("cn_sigmoid_clamp_bwd");
+    return CN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ focal
+extern "C" size_t cn_focal_workspace_bytes(int64_t n) {
+    (void)n;
+    return (size_t)FOCAL_MAX_BLOCKS * 3 * sizeof(float);
+}
+
+__device__ static inline int64_t gt_index(int64_t i, int64_t HW, int C, int gtB, int gtC) {
+    // pred index i = (b*C + c)*HW + s  ->  gt index with size-1 broadcast on batch / channel
+    const int64_t s = i % HW;
+    const int64_t bc = i / HW;
+    const int c = (int)(bc % C);
+    const int64_t b = bc / C;
+    return ((gtB == 1 ? 0 : b) * gtC + (gtC == 1 ? 0 : c)) * HW + s;
+}
+
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                        float* __restrict__ part, int64_t n, int64_t HW, int C, int gtB,
+                                                        int gtC, int same) {
+    float pos = 0.f, neg = 0.f, np = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = pred[i];
+        const float g = gt[same ? i : gt_index(i, HW, C, gtB, gtC)];
+        if (g == 1.f) {
+            const float q = 1.f - p;
+            pos += logf(p) * q * q;
+            np += 1.f;
+        } else if (g < 1.f) {
+            const float w = 1.f - g;
+            const float w2 = w * w;
+            neg += logf(1.f - p) * p * p * (w2 * w2);
+        }
+    }
+    __shared__ float red[3][4];
+    pos = wave_sum(pos); neg = wave_sum(neg); np = wave_sum(np);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = pos; red[1][wv] = neg; red[2][wv] = np; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[blockIdx.x * 3 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        part[blockIdx.x * 3 + 2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+}
+
+__global__ __launch_bounds__(64) void focal_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out4) {
+    double pos = 0.0, neg = 0.0, np = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) { pos += part[b * 3]; neg += part[b * 3 + 1]; np += part[b * 3 + 2]; }
+    pos = wave_sum_d(pos); neg = wave_sum_d(neg); np = wave_sum_d(np);
+    if (threadIdx.x == 0) {
+        out4[0] = (float)(np == 0.0 ? -neg : -(pos + neg) / np);
+        out4[1] = (float)pos;
+        out4[2] = (float)neg;
+        out4[3] = (float)np;
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                        const float* __restrict__ out4, const float* __restrict__ gout,
+                                                        float* __restrict__ dpred, int64_t n, int64_t HW, int C, int gtB,
+                                                        int gtC, int same) {
+    const float np = out4[3];
+    const float scale = -gout[0] / (np == 0.f ? 1.f : np);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = pred[i];
+        const float g = gt[same ? i : gt_index(i, HW, C, gtB, gtC)];
+        float d = 0.f;
+        if (g == 1.f) {
+            const float q = 1.f - p;
+            d = q * q / p - 2.f * q * logf(p);
+        } else if (g < 1.f) {
+            const float w = 1.f - g;
+            const float w2 = w * w;
+            d = (w2 * w2) * (2.f * p * logf(1.f - p) - p * p / (1.f - p));
+        }
+        dpred[i] = d * scale;
+    }
+}
+
+static int focal_grid(int64_t n) {
+    int64_t g = (n + 256 * 8 - 1) / (256 * 8);
+    return (int)(g > FOCAL_MAX_BLOCKS ? FOCAL_MAX_BLOCKS : (g < 1 ? 1 : g));
+}
+
+extern "C" int cn_focal_fwd(const float* pred, const float* gt, float* out4, int B, int C, int64_t HW, int gtB, int gtC,
+                            void* ws, size_t ws_bytes, void* stream) {
+    CN_CHECK_ARG(pred && gt && out4 && ws && B > 0 && C > 0 && HW > 0, "cn_focal_fwd: bad args");
+    CN_CHECK_ARG((gtB == B || gtB == 1) && (gtC == C || gtC == 1), "cn_focal_fwd: gt [%d,%d] does not broadcast to [%d,%d]", gtB, gtC, B, C);
+    if (ws_bytes < cn_focal_workspace_bytes(0)) { cn_set_error("cn_focal_fwd: workspace too small"); return CN_EWORKSPACE; }
+    const int64_t n = (int64_t)B * C * HW;
+    const int grid = focal_grid(n);
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, gt, (float*)ws, n, HW, C, gtB, gtC,
+                       (int)(gtB == B && gtC == C));
+    CN_LAUNCH_CHECK("cn_focal_fwd");
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, grid, out4);
+    CN_LAUNCH_CHECK("cn_focal_fwd(finalize)");
+    return CN_OK;
+}
+
+extern "C" int cn_focal_bwd(const float* pred, const float* gt, const float* out4, const float* gout, float* dpred, int B,
+                            int C, int64_t HW, int gtB, int gtC, void* stream) {
+    CN_CHECK_ARG(pred && gt && out4 && gout && dpred && B > 0 && C > 0 && HW > 0, "cn_focal_bwd: bad args");
+    CN_CHECK_ARG((gtB == B || gtB == 1) && (gtC == C || gtC == 1), "cn_focal_bwd: gt does not broadcast");
+    const int64_t n = (int64_t)B * C * HW;
+    int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, pred, gt, out4,
+                       gout, dpred, n, HW, C, gtB, gtC, (int)(gtB == B && gtC == C));
+    CN_LAUNCH_CHECK("cn_focal_bwd");
+    return CN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ gather L1
+__global__ __launch_bounds__(1024) void gather_l1_fwd_kernel(const float* __restrict__ feat, const int64_t* __restrict__ ind,
+                                                             const uint8_t* __restrict__ mask, const float* __restrict__ tgt,
+                                                             float* __restrict__ out3, int B, int C, int64_t HW, int N,
+                                                             int mask_has_c) {
+    const int64_t total = (int64_t)B * N * C;
+    double s = 0.0, ms = 0.0;
+    for (int64_t i = threadIdx.x; i < total; i += 1024) {
+        const int c = (int)(i % C);
+        const int64_t bn = i / C;
+        const int b = (int)(bn / N);
+        const float m = mask[mask_has_c ? i : bn] ? 1.f : 0.f;
+        int64_t id = ind[bn];
+        id = id < 0 ? 0 : (id >= HW ? HW - 1 : id);
+        const float p = feat[((int64_t)b * C + c) * HW + id];
+        s += (double)fabsf(p * m - tgt[i] * m);
+        ms += (double)m;
+    }
+    __shared__ double red[2][16];
+    s = wave_sum_d(s); ms = wave_sum_d(ms);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = s; red[1][wv] = ms; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b2 = 0.0;
+        for (int w = 0; w < 16; ++w) { a += red[0][w]; b2 += red[1][w]; }
+        out3[0] = (float)a / ((float)b2 + 1e-4f);
+        out3[1] = (float)a;
+        out3[2] = (float)b2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_l1_bwd_kernel(const float* __restrict__ feat, const int64_t* __restrict__ ind,
+                                                            const uint8_t* __restrict__ mask, const float* __restrict__ tgt,
+                                                            const float* __restrict__ out3, const float* __restrict__ gout,
+                                                            float* __restrict__ dfeat, int B, int C, int64_t HW, int N,
+                                                            int mask_has_c) {
+    const int64_t total = (int64_t)B * N * C;
+    const float scale = gout[0] / (out3[2] + 1e-4f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t bn = i / C;
+        const int b = (int)(bn / N);
+        if (!mask[mask_has_c ? i : bn]) continue;
+        int64_t id = ind[bn];
+        id = id < 0 ? 0 : (id >= HW ? HW - 1 : id);
+        const int64_t a = ((int64_t)b * C + c) * HW + id;
+        const float d = feat[a] - tgt[i];
+        const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        if (sg != 0.f) atomicAdd(dfeat + a, sg * scale);
+    }
+}
+
+extern "C" int cn_gather_l1_fwd(const float* feat, const int64_t* ind, const uint8_t* mask, const float* target, float* out3,
+                                int B, int C, int64_t HW, int N, int mask_has_c, void* stream) {
+    CN_CHECK_ARG(feat && ind && mask && target && out3 && B > 0 && C > 0 && HW > 0 && N > 0, "cn_gather_l1_fwd: bad args");
+    hipLaunchKernelGGL(gather_l1_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, feat, ind, mask, target, out3, B, C, HW,
+                       N, mask_has_c);
+    CN_LAUNCH_CHECK("cn_gather_l1_fwd");
+    return CN_OK;
+}
+
+extern "C" int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uint8_t* mask, const float* target,
+                                const float* out3, const float* gout, float* dfeat, int B, int C, int64_t HW, int N,
+                                int mask_has_c, void* stream) {
+    CN_CHECK_ARG(feat && ind && mask && target && out3 && gout && dfeat && B > 0 && C > 0, "cn_gather_l1_bwd: bad args");
+    int64_t total = (int64_t)B * N * C;
+    int64_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(gather_l1_bwd_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, feat, ind, mask,
+                       target, out3, gout, dfeat, B, C, HW, N, mask_has_c);
+    CN_LAUNCH_CHECK("cn_gather_l1_bwd");
+    return CN_OK;
+}

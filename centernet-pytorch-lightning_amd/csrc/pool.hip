@@ -1,0 +1,251 @@
+// Max-pool (DLA Tree.downsample 2x2/s2: pose_dla_dcn.py:243; ResNet stem 3x3/s2/p1: msra_resnet.py:113) and the
+// depthwise bilinear ConvTranspose2d of IDAUp (pose_dla_dcn.py:466-475).  NHWC, one 16-byte channel
+// vector per lane: pure HBM-bound gathers, no LDS needed (neighbouring taps hit L1/L2).
+#include "common.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                                          int CV, int k, int s, int p, int OH, int OW) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t total = (int64_t)N * OH * OW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        const int ow = (int)(pix % OW);
+        pix /= OW;
+        const int oh = (int)(pix % OH), n = (int)(pix / OH);
+        float m[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) m[j] = -INFINITY;
+        for (int kh = 0; kh < k; ++kh) {
+            const int ih = oh * s - p + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int iw = ow * s - p + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float v[V];
+                Vec16<T>::load(x + ((((int64_t)n * H + ih) * W + iw) * CV + cv) * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+            }
+        }
+        Vec16<T>::store(y + i * V, m);
+    }
+}
+
+// gather form: every input element sums dy of the windows whose FIRST maximum (scan order kh, kw) it is.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, int N, int H, int W, int CV, int k, int s,
+                                                          int p, int OH, int OW) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        const int iw = (int)(pix % W);
+        pix /= W;
+        const int ih = (int)(pix % H), n = (int)(pix / H);
+        float g[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) g[j] = 0.f;
+        int oh_lo = ih + p - k + 1;
+        oh_lo = oh_lo > 0 ? (oh_lo + s - 1) / s : 0;
+        int oh_hi = (ih + p) / s;
+        if (oh_hi > OH - 1) oh_hi = OH - 1;
+        int ow_lo = iw + p - k + 1;
+        ow_lo = ow_lo > 0 ? (ow_lo + s - 1) / s : 0;
+        int ow_hi = (iw + p) / s;
+        if (ow_hi > OW - 1) ow_hi = OW - 1;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                float m[V];
+                int am[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) { m[j] = -INFINITY; am[j] = -1; }
+                for (int kh = 0; kh < k; ++kh) {
+                    const int hh = oh * s - p + kh;
+                    if ((unsigned)hh >= (unsigned)H) continue;
+                    for (int kw = 0; kw < k; ++kw) {
+                        const int ww = ow * s - p + kw;
+                        if ((unsigned)ww >= (unsigned)W) continue;
+                        float v[V];
+                        Vec16<T>::load(x + ((((int64_t)n * H + hh) * W + ww) * CV + cv) * V, v);
+#pragma unroll
+                        for (int j = 0; j < V; ++j)
+                            if (v[j] > m[j] || am[j] < 0) { m[j] = v[j]; am[j] = hh * W + ww; }
+                    }
+                }
+                float d[V];
+                Vec16<T>::load(dy + ((((int64_t)n * OH + oh) * OW + ow) * CV + cv) * V, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    if (am[j] == ih * W + iw) g[j] += d[j];
+            }
+        Vec16<T>::store(dx + i * V, g);
+    }
+}
+
+// y[n,oh,ow,c] = sum_{kh,kw : (oh+p-kh) % s == 0 ...} x[n,(oh+p-kh)/s,(ow+p-kw)/s,c] * w[c,kh,kw]
+template <typename T>
+__global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           T* __restrict__ y, int N, int H, int W, int CV, int k, int s,
+                                                           int p, int OH, int OW) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t total = (int64_t)N * OH * OW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        const int ow = (int)(pix % OW);
+        pix /= OW;
+        const int oh = (int)(pix % OH), n = (int)(pix / OH);
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (int kh = (oh + p) % s; kh < k; kh += s) {
+            const int ih = (oh + p - kh) / s;
+            if (oh + p - kh < 0 || ih >= H) continue;
+            for (int kw = (ow + p) % s; kw < k; kw += s) {
+                const int iw = (ow + p - kw) / s;
+                if (ow + p - kw < 0 || iw >= W) continue;
+                float v[V];
+                Vec16<T>::load(x + ((((int64_t)n * H + ih) * W + iw) * CV + cv) * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], w[((cv * V + j) * k + kh) * k + kw], acc[j]);
+            }
+        }
+        Vec16<T>::store(y + i * V, acc);
+    }
+}
+
+// dx[n,ih,iw,c] = sum_{kh,kw} dy[n, ih*s-p+kh, iw*s-p+kw, c] * w[c,kh,kw]
+template <typename T>
+__global__ __launch_bounds__(256) void dwdeconv_bwd_input_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                                 T* __restrict__ dx, int N, int H, int W, int CV, int k,
+                                                                 int s, int p, int OH, int OW) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        const int iw = (int)(pix % W);
+        pix /= W;
+        const int ih = (int)(pix % H), n = (int)(pix / H);
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        for (int kh = 0; kh < k; ++kh) {
+            const int oh = ih * s - p + kh;
+            if ((unsigned)oh >= (unsigned)OH) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int ow = iw * s - p + kw;
+                if ((unsigned)ow >= (unsigned)OW) continue;
+                float v[V];
+                Vec16<T>::load(dy + ((((int64_t)n * OH + oh) * OW + ow) * CV + cv) * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], w[((cv * V + j) * k + kh) * k + kw], acc[j]);
+            }
+        }
+        Vec16<T>::store(dx + i * V, acc);
+    }
+}
+
+// dw[c,kh,kw] += sum_{n,ih,iw} x[n,ih,iw,c] * dy[n, ih*s-p+kh, iw*s-p+kw, c]; lane = (tap, channel vector)
+template <typename T>
+__global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                  float* __restrict__ dw, int N, int H, int W, int CV, int k,
+                                                                  int s, int p, int OH, int OW, int64_t chunk) {
+    constexpr int V = Vec16<T>::N;
+    const int pair = blockIdx.y * 256 + threadIdx.x;
+    if (pair >= CV * k * k) return;
+    const int cv = pair % CV, tap = pair / CV;
+    const int kh = tap / k, kw = tap - kh * k;
+    const int64_t P = (int64_t)N * H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int64_t pix = p0; pix < p1; ++pix) {
+        const int iw = (int)(pix % W);
+        const int64_t t = pix / W;
+        const int ih = (int)(t % H), n = (int)(t / H);
+        const int oh = ih * s - p + kh, ow = iw * s - p + kw;
+        if ((unsigned)oh >= (unsigned)OH || (unsigned)ow >= (unsigned)OW) continue;
+        float a[V], b[V];
+        Vec16<T>::load(x + (pix * CV + cv) * V, a);
+        Vec16<T>::load(dy + ((((int64_t)n * OH + oh) * OW + ow) * CV + cv) * V, b);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], b[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) atomicAdd(dw + ((int64_t)(cv * V + j) * k + kh) * k + kw, acc[j]);
+}
+
+static int pool_grid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g));
+}
+
+#define POOL_ARGS_CHECK(name)                                                                                      \
+    CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && k > 0 && stride > 0, name ": bad dims"); \
+    const int V = dtype == CN_F32 ? 4 : 8;                                                                         \
+    CN_CHECK_ARG(C % V == 0, name ": C=%d must be a multiple of %d", C, V)
+
+extern "C" int cn_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, int OH, int OW,
+                              int dtype, void* stream) {
+    CN_CHECK_ARG(x && y, "cn_maxpool_fwd: null");
+    POOL_ARGS_CHECK("cn_maxpool_fwd");
+    int64_t total = (int64_t)N * OH * OW * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)x, (T*)y, N, H, W, C / V, k, stride, pad, OH, OW));
+    CN_LAUNCH_CHECK("cn_maxpool_fwd");
+    return CN_OK;
+}
+
+extern "C" int cn_maxpool_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
+                              int OH, int OW, int dtype, void* stream) {
+    CN_CHECK_ARG(x && dy && dx, "cn_maxpool_bwd: null");
+    POOL_ARGS_CHECK("cn_maxpool_bwd");
+    int64_t total = (int64_t)N * H * W * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H, W, C / V, k,
+                                                   stride, pad, OH, OW));
+    CN_LAUNCH_CHECK("cn_maxpool_bwd");
+    return CN_OK;
+}
+
+extern "C" int cn_dwdeconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int k, int stride, int pad,
+                               int OH, int OW, int dtype, void* stream) {
+    CN_CHECK_ARG(x && w && y, "cn_dwdeconv_fwd: null");
+    POOL_ARGS_CHECK("cn_dwdeconv_fwd");
+    int64_t total = (int64_t)N * OH * OW * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_fwd_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)x, w, (T*)y, N, H, W, C / V, k, stride, pad, OH, OW));
+    CN_LAUNCH_CHECK("cn_dwdeconv_fwd");
+    return CN_OK;
+}
+
+extern "C" int cn_dwdeconv_bwd_input(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int k, int stride,
+                                     int pad, int OH, int OW, int dtype, void* stream) {
+    CN_CHECK_ARG(dy && w && dx, "cn_dwdeconv_bwd_input: null");
+    POOL_ARGS_CHECK("cn_dwdeconv_bwd_input");
+    int64_t total = (int64_t)N * H * W * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_bwd_input_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
+                                                   (hipStream_t)stream, (const T*)dy, w, (T*)dx, N, H, W, C / V, k, stride, pad, OH, OW));
+    CN_LAUNCH_CHECK("cn_dwdeconv_bwd_input");
+    return CN_OK;
+}
+
+extern "C" int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw, int N, int H, int W, int C, int k, int stride,
+                                      int pad, int OH, int OW, int dtype, void* stream) {
+    CN_CHECK_ARG(x && dy && dw, "cn_dwdeconv_bwd_weight: null");
+    POOL_ARGS_CHECK("cn_dwdeconv_bwd_weight");
+    int64_t P = (int64_t)N * H * W;
+    int64_t chunk = (P + 511) / 512;
+    if (chunk < 64) chunk = 64;
+    dim3 grid(cdiv(P, chunk), cdiv((C / V) * k * k, 256));
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_bwd_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (const T*)dy, dw, N, H, W, C / V, k, stride, pad, OH, OW, chunk));
+    CN_LAUNCH_CHECK("cn_dwdeconv_bwd_weight");
+    return CN_OK;
+}

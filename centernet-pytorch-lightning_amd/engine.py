@@ -1,0 +1,199 @@
+"""Training runtime around the hot path: fused flat-buffer Adam, RCCL data-parallel gradient exchange, a small trainer.
+
+Data parallelism follows Lightning-DDP semantics: one process per GPU, each rank normalises its loss by
+its LOCAL num_pos / mask sums, gradients are SUM-all-reduced over RCCL (torch.distributed backend "nccl") in flat
+~25 MB buckets launched from grad-ready hooks so they overlap the rest of backward, and the 1/world average is folded
+into the Adam kernel's gradient scale (no extra pass).  BN statistics stay per-rank (no SyncBN in the reference).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _hip
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(defaults) semantics on ONE contiguous fp32 parameter buffer -> one cn_adam_step launch.
+
+    Parameters are re-pointed at views of `flat_p` and their `.grad` at views of `flat_g`, so autograd accumulates
+    straight into the flat gradient buffer that the bucketed all-reduce and the Adam kernel consume.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.params = params
+        dev = params[0].device
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.offsets, self.numel = offs, n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = self.flat_p[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+        self.t = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):   # autograd may have replaced .grad (e.g. after set_to_none elsewhere)
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self.t += 1
+        b1, b2 = g["betas"]
+        if self.flat_p.is_cuda:
+            _hip.call("cn_adam_step", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.numel, float(g["lr"]),
+                      float(b1), float(b2), float(g["eps"]), 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, float(self.grad_scale))
+        else:  # host logic tests (gloo / CPU): same arithmetic with torch ops
+            gr = self.flat_g * self.grad_scale
+            self.flat_m.mul_(b1).add_(gr, alpha=1 - b1)
+            self.flat_v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+            denom = self.flat_v.sqrt() / (1.0 - b2 ** self.t) ** 0.5 + g["eps"]
+            self.flat_p.addcdiv_(self.flat_m, denom, value=-g["lr"] / (1.0 - b1 ** self.t))
+        for p in self.params:
+            p._version  # noqa: B018  (views share storage with flat_p; nothing to copy back)
+
+
+class GradSync:
+    """Bucketed, backward-overlapped SUM all-reduce of FlatAdam.flat_g across ranks (RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, opt, bucket_bytes=25 << 20, group=None):
+        self.opt, self.group = opt, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        opt.grad_scale = 1.0 / self.world
+        self.buckets = []      # (start, end, [param indices]) over the flat buffer, built in REVERSE parameter order
+        cur, size, end = [], 0, opt.numel
+        for i in reversed(range(len(opt.params))):
+            cur.append(i)
+            size += opt.params[i].numel() * 4
+            if size >= bucket_bytes or i == 0:
+                self.buckets.append((opt.offsets[i], end, cur))
+                end, cur, size = opt.offsets[i], [], 0
+        self.bucket_of = {}
+        for b, (_, _, idx) in enumerate(self.buckets):
+            for i in idx:
+                self.bucket_of[i] = b
+        self.live = None       # params that receive gradients (learned on the first backward)
+        self._seen, self._pending, self._works, self._launched = set(), [], [], set()
+        if self.world > 1:
+            for i, p in enumerate(opt.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            self._seen.add(i)
+            b = self.bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and self.live is not None:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        if b in self._launched:
+            return
+        self._launched.add(b)
+        s, e, _ = self.buckets[b]
+        self._works.append(dist.all_reduce(self.opt.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def begin(self):
+        """Call before backward."""
+        self._seen, self._works, self._launched = set(), [], set()
+        live = self.live
+        self._pending = [sum(1 for i in idx if live is None or i in live) for _, _, idx in self.buckets]
+
+    def finish(self):
+        """Call after backward: launches whatever is left (first step / dead parameters) and waits for all buckets."""
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            self._launch(b)
+        for w in self._works:
+            w.wait()
+        if self.live is None:
+            self.live = set(self._seen)
+
+    def broadcast_state(self, module):
+        """DDP init: parameters (flat) + buffers from rank 0."""
+        if self.world == 1:
+            return
+        dist.broadcast(self.opt.flat_p, 0, group=self.group)
+        for buf in module.buffers():
+            dist.broadcast(buf, 0, group=self.group)
+
+
+def init_distributed():
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and join the RCCL world."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    return rank, local, world
+
+
+class TrainStep:
+    """forward + loss + backward (+ overlapped gradient exchange) + Adam, i.e. what Lightning's loop does around
+    `CenterNet.training_step` (centernet.py:70-80)."""
+
+    def __init__(self, model, lr=None, distributed=None):
+        self.model = model
+        lr = lr if lr is not None else getattr(model.hparams, "learning_rate", 1e-4)
+        self.opt = FlatAdam(model.parameters(), lr=lr)
+        self.sync = GradSync(self.opt) if (dist.is_initialized() if distributed is None else distributed) else None
+        if self.sync is not None:
+            self.sync.broadcast_state(model)
+
+    def __call__(self, batch, batch_idx=0):
+        self.opt.zero_grad()
+        loss = self.model.training_step(batch, batch_idx)
+        if self.sync is not None:
+            self.sync.begin()
+        loss.backward()
+        if self.sync is not None:
+            self.sync.finish()
+        self.opt.step()
+        return loss
+
+
+class Trainer:
+    """Minimal stand-in for pl.Trainer.fit on this package's modules (Lightning is not available offline)."""
+
+    def __init__(self, max_epochs=1, limit_train_batches=None, limit_val_batches=None):
+        self.max_epochs, self.limit_train_batches, self.limit_val_batches = max_epochs, limit_train_batches, limit_val_batches
+
+    def fit(self, model, train_loader, val_loader=None):
+        step = TrainStep(model)
+        dev = next(model.parameters()).device
+        to = lambda b: (b[0].to(dev), {k: v.to(dev) for k, v in b[1].items()})
+        history = []
+        for _ in range(self.max_epochs):
+            model.train()
+            for i, batch in enumerate(train_loader):
+                if self.limit_train_batches is not None and i >= self.limit_train_batches:
+                    break
+                history.append(step(to(batch), i))
+            if val_loader is not None:
+                model.eval()
+                with torch.no_grad():
+                    for i, batch in enumerate(val_loader):
+                        if self.limit_val_batches is not None and i >= self.limit_val_batches:
+                            break
+                        model.validation_step(to(batch), i)
+        return history

@@ -1,0 +1,177 @@
+"""Layer modules over the HIP operators.  Parameters keep the reference's names/shapes (NCHW fp32),
+so `state_dict`s are interchangeable with the reference; activations flowing between layers are NHWC in the
+backbone's compute dtype.
+
+Training: conv -> (batch-stat BN + residual + ReLU) as separate HBM passes (statistics need the whole
+conv output first).  Inference: BN is folded into the packed conv weights and residual/ReLU ride in the conv
+epilogue, so a conv+BN+ReLU(+add) block is ONE kernel; folded weights are cached per parameter version.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Conv2d(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=False):
+        super().__init__()
+        self.stride, self.padding, self.k = stride, padding, k
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(cin * k * k)
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+        self._cache = {}
+
+    def extra_repr(self):
+        co, ci, k, _ = self.weight.shape
+        return f"{ci}, {co}, kernel_size={k}, stride={self.stride}, padding={self.padding}, bias={self.bias is not None}"
+
+    def forward(self, x, relu=False):
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu)
+        return self.infer(x, None, None, None, relu)
+
+    def infer(self, x, scale, shift, residual, relu):
+        """No-grad path: y = act(conv(x)*scale + shift + residual); packed (folded) weights are cached."""
+        key = (x.dtype, self.weight._version, None if scale is None else (scale.data_ptr(), scale._version))
+        hit = self._cache.get("k")
+        if hit != key:
+            wp = ops.pack_weight(self.weight, 1, x.dtype, scale)
+            b = self.bias.detach() if self.bias is not None else None
+            if shift is not None:
+                b = shift if b is None else (b * scale + shift)   # tiny [Co] host-side fold (once per weight version)
+            self._cache = {"k": key, "wp": wp, "b": b}
+        c = self._cache
+        Co, _, KH, KW = self.weight.shape
+        N, H, W, _ = x.shape
+        OH, OW = ops.conv_out(H, KH, self.stride, self.padding), ops.conv_out(W, KW, self.stride, self.padding)
+        return ops._igemm(x, c["wp"], c["b"], residual, Co, KH, KW, self.stride, self.padding, False, relu, OH, OW)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """Parameter/buffer holder with nn.BatchNorm2d's state_dict; the arithmetic lives in ops.BatchNormActFn."""
+
+    def __init__(self, c):
+        super().__init__(c, momentum=ops.BN_MOMENTUM)
+        self._pending = 0
+        self._fold = None
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending:
+            self.num_batches_tracked += self._pending
+            self._pending = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def folded(self):
+        """(scale, shift) fp32 of the eval-mode affine; cached per buffer/parameter version."""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version)
+        if self._fold is None or self._fold[0] != key:
+            with torch.no_grad():
+                scale = self.weight * torch.rsqrt(self.running_var + self.eps)   # [C] vectors, once per weight version
+                shift = self.bias - self.running_mean * scale
+            self._fold = (key, scale.contiguous(), shift.contiguous())
+        return self._fold[1], self._fold[2]
+
+    def forward(self, x, residual=None, relu=True):
+        if self.training:
+            self._pending += 1
+            return ops.batch_norm_act(x, self, residual, relu)
+        s, b = self.folded()
+        return ops.scale_shift_act(x, s, b, residual, relu)
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=True):
+    """conv -> BN -> (+residual) -> ReLU.  One fused kernel in eval/no-grad mode."""
+    if bn.training:
+        return bn(conv(x), residual, relu)
+    if torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):
+        return bn(conv(x), residual, relu)          # eval-mode BN but gradients wanted: unfused affine pass
+    s, b = bn.folded()
+    return conv.infer(x, s, b, residual, relu)
+
+
+class StemConv(nn.Module):
+    """7x7 conv on the NCHW fp32 image -> NHWC activations in `dtype`."""
+
+    def __init__(self, cin, cout, k, stride, padding):
+        super().__init__()
+        self.stride, self.padding = stride, padding
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def forward(self, img, dtype):
+        return ops.StemConvFn.apply(img, self.weight, self.stride, self.padding, dtype)
+
+
+class ConvTranspose2d(nn.Module):
+    def __init__(self, cin, cout, k, stride, padding):
+        super().__init__()
+        self.stride, self.padding = stride, padding
+        self.weight = nn.Parameter(torch.empty(cin, cout, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def forward(self, x):
+        return ops.conv_transpose2d(x, self.weight, self.stride, self.padding)
+
+
+class DepthwiseUp(nn.Module):
+    """ConvTranspose2d(o, o, 2f, stride=f, padding=f//2, groups=o, bias=False), bilinear init (pose_dla_dcn.py:424-432,466-476)."""
+
+    def __init__(self, c, f):
+        super().__init__()
+        self.stride, self.padding = f, f // 2
+        k = 2 * f
+        fc = math.ceil(k / 2)
+        cc = (2 * fc - 1 - fc % 2) / (2.0 * fc)
+        g = torch.tensor([1 - abs(i / fc - cc) for i in range(k)])
+        self.weight = nn.Parameter(torch.outer(g, g).expand(c, 1, k, k).clone())
+
+    def forward(self, x):
+        return ops.DwDeconvFn.apply(x, self.weight, self.stride, self.padding)
+
+
+class DCN(nn.Module):
+    """Drop-in for DCN.dcn_v2.DCN(chi, cho, (3,3), stride=1, padding=1, dilation=1, deformable_groups=1)."""
+
+    def __init__(self, cin, cout, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1):
+        super().__init__()
+        if tuple(kernel_size) != (3, 3) or stride != 1 or padding != 1 or dilation != 1 or deformable_groups != 1:
+            raise NotImplementedError("DCN: only the 3x3/s1/p1/d1/g1 configuration the reference uses is implemented")
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
+        bound = 1.0 / math.sqrt(cin * 9)
+        nn.init.uniform_(self.weight, -bound, bound)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.conv_offset_mask = Conv2d(cin, 27, 3, 1, 1, bias=True)
+        nn.init.zeros_(self.conv_offset_mask.weight)
+        nn.init.zeros_(self.conv_offset_mask.bias)
+
+        self._cache = {}
+
+    def forward(self, x):
+        return ops.DCNv2Fn.apply(x, self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias)
+
+    def infer(self, x, scale, shift, relu):
+        """No-grad path with the following BN folded in: offset conv -> sampling -> ONE 1x1 GEMM (+shift, ReLU)."""
+        key = (x.dtype, self.weight._version, self.bias._version, scale.data_ptr(), scale._version)
+        if self._cache.get("k") != key:
+            wp = ops.pack_weight(self.weight, 1, x.dtype, scale)
+            self._cache = {"k": key, "wp": wp, "b": (self.bias.detach() * scale + shift).contiguous()}
+        N, H, W, Ci = x.shape
+        om = self.conv_offset_mask.infer(x, None, None, None, False)
+        col = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
+        ops.call("cn_dcn_im2col", x, om, col, N, H, W, Ci, Ci, om.shape[-1], ops.dtype_code(x.dtype))
+        return ops._igemm(col, self._cache["wp"], self._cache["b"], None, self.weight.shape[0], 1, 1, 1, 0, False, relu, H, W)
+
+
+class MaxPool2d(nn.Module):
+    def __init__(self, k, stride, padding=0):
+        super().__init__()
+        self.k, self.stride, self.padding = k, stride, padding
+
+    def forward(self, x):
+        return ops.max_pool(x, self.k, self.stride, self.padding)

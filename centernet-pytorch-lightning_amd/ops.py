@@ -1,0 +1,523 @@
+"""Host-side operators: thin autograd glue over the C ABI (no arithmetic happens in Python/ATen).
+
+Activations are contiguous NHWC tensors in the compute dtype (torch.bfloat16 or torch.float32) whose channel
+count is padded to a multiple of 16; parameters, images, head maps and gradients stay NCHW fp32 like the
+reference.  Every op enqueues hand-written HIP kernels on the current stream through `_hip.call`.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _hip
+from ._hip import call, dtype_code
+
+BN_MOMENTUM = 0.1  # msra_resnet.py:11, pose_dla_dcn.py:13
+BN_EPS = 1e-5
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def _empty_like_shape(x, shape):
+    return torch.empty(shape, dtype=x.dtype, device=x.device)
+
+
+def _bn_ws(npix, C, device):
+    n = _hip.query("cn_bn_workspace_bytes", int(npix), int(C))
+    return _hip.workspace(n, device, "bn"), n
+
+
+# ------------------------------------------------------------------------------------------------ packing
+def pack_weight(w, mode, dtype, row_scale=None):
+    """w: fp32 [A,B,KH,KW] parameter -> packed GEMM operand (see cn_pack_weight)."""
+    A, B, KH, KW = w.shape
+    taps = KH * KW
+    if mode == 0:
+        rows, inner = B, A
+    elif mode == 1:
+        rows, inner = A, B
+    else:
+        rows, inner = taps * B, A
+    rows_pad, inner_pad = rup(rows, 32), rup(inner, 16)
+    cols = inner_pad if mode == 2 else taps * inner_pad
+    wp = torch.empty((rows_pad, cols), dtype=dtype, device=w.device)
+    call("cn_pack_weight", w.detach().contiguous(), wp, A, B, KH, KW, mode, rows_pad, inner_pad, row_scale, dtype_code(dtype))
+    return wp
+
+
+def unpack_wgrad(dwp, A, B, KH, KW):
+    dw = torch.empty((A, B, KH, KW), dtype=torch.float32, device=dwp.device)
+    call("cn_unpack_wgrad", dwp, dw, A, B, KH, KW, rup(B, 16))
+    return dw
+
+
+def conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW):
+    N, H, W, Ci = x.shape
+    cp = rup(Co, 16)
+    alloc = torch.empty if cp == Co else torch.zeros
+    y = alloc((N, OH, OW, cp), dtype=x.dtype, device=x.device)
+    call("cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
+         residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
+         dtype_code(x.dtype))
+    return y
+
+
+def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias):
+    """-> (dwp fp32 [rup32(Co)][KH*KW*Ci], db fp32[Co] | None); x [N,H,W,Ci], dy [N,OH,OW,>=Co]."""
+    N, H, W, Ci = x.shape
+    _, OH, OW, ld = dy.shape
+    dwp = torch.zeros((rup(Co, 32), KH * KW * Ci), dtype=torch.float32, device=x.device)
+    db = torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None
+    call("cn_conv2d_wgrad", x, dy, dwp, db, N, H, W, Ci, Ci, OH, OW, Co, ld, KH, KW, stride, pad, dtype_code(x.dtype))
+    return dwp, db
+
+
+# ------------------------------------------------------------------------------------------------ conv
+class Conv2dFn(Function):
+    """nn.Conv2d (+bias, +ReLU) on NHWC.  weight fp32 [Co,Ci,KH,KW]; x channels = rup(Ci,16) (zero padded)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu):
+        Co, Ci, KH, KW = weight.shape
+        N, H, W, Cx = x.shape
+        assert Cx == rup(Ci, 16), f"conv input has {Cx} channels, weight expects {Ci}"
+        wp = pack_weight(weight, 1, x.dtype)
+        OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
+        y = _igemm(x, wp, bias, None, Co, KH, KW, stride, pad, False, relu, OH, OW)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.cfg = (stride, pad, relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        stride, pad, relu, has_bias = ctx.cfg
+        Co, Ci, KH, KW = weight.shape
+        N, H, W, Cx = x.shape
+        dy = dy.contiguous()
+        if relu:
+            g = torch.empty_like(dy)
+            call("cn_relu_bwd", dy, y, g, dy.numel(), dtype_code(dy.dtype))
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, has_bias and ctx.needs_input_grad[2])
+            dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
+        if ctx.needs_input_grad[0]:
+            wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
+            if Cx != Ci:
+                raise RuntimeError("data gradient through a channel-padded conv input is not supported")
+            dx = _igemm(dy, wpd, None, None, Ci, KH, KW, stride, pad, True, False, H, W)
+        return dx, dw, db, None, None, None
+
+
+class ConvTranspose2dFn(Function):
+    """nn.ConvTranspose2d(Ci,Co,4,stride=2,padding=1,bias=False) — msra_resnet.py:178-187.  weight [Ci,Co,KH,KW]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        Ci, Co, KH, KW = weight.shape
+        N, H, W, _ = x.shape
+        wp = pack_weight(weight, 0, x.dtype)               # rows = Co, k = tap*Ci + ci
+        OH, OW = (H - 1) * stride - 2 * pad + KH, (W - 1) * stride - 2 * pad + KW
+        y = _igemm(x, wp, None, None, Co, KH, KW, stride, pad, True, False, OH, OW)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        Ci, Co, KH, KW = weight.shape
+        N, H, W, _ = x.shape
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            # dW[ci][co][t] = sum x[n,ih,iw,ci] * dy[n, ih*s-p+kh, iw*s-p+kw, co]: the wgrad kernel with roles swapped
+            dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
+            dw = unpack_wgrad(dwp, Ci, Co, KH, KW)
+        if ctx.needs_input_grad[0]:
+            wpd = pack_weight(weight, 1, x.dtype)          # rows = Ci, k = tap*Co + co
+            dx = _igemm(dy, wpd, None, None, Ci, KH, KW, stride, pad, False, False, H, W)
+        return dx, dw, None, None
+
+
+class StemConvFn(Function):
+    """7x7 conv on the NCHW fp32 image (3 channels) -> NHWC activations; no data gradient (it is the input)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, stride, pad, dtype):
+        Co, Ci, KH, KW = weight.shape
+        N, _, H, W = img.shape
+        OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
+        img = img.contiguous()
+        y = torch.empty((N, OH, OW, Co), dtype=dtype, device=img.device)
+        call("cn_stem_conv_fwd", img, weight.detach().contiguous(), y, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, dtype_code(dtype))
+        ctx.save_for_backward(img, weight)
+        ctx.cfg = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        img, weight = ctx.saved_tensors
+        stride, pad = ctx.cfg
+        Co, Ci, KH, KW = weight.shape
+        N, _, H, W = img.shape
+        dy = dy.contiguous()
+        dw = torch.zeros_like(weight, dtype=torch.float32)
+        call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))
+        return None, dw, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+class BatchNormActFn(Function):
+    """Training-mode BatchNorm2d + optional residual add + optional ReLU (one fused apply pass)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu):
+        C = x.shape[-1]
+        npix = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws, n = _bn_ws(npix, C, x.device)
+        call("cn_bn_train_fwd", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd,
+             npix, C, BN_MOMENTUM, BN_EPS, int(relu), dtype_code(x.dtype), ws, n)
+        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        ctx.cfg = (relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        C = x.shape[-1]
+        npix = x.numel() // C
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws, n = _bn_ws(npix, C, x.device)
+        call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, dx, dres, dgamma, dbeta, npix, C, int(relu),
+             dtype_code(x.dtype), ws, n)
+        return dx, dgamma, dbeta, None, None, dres, None
+
+
+class ScaleShiftActFn(Function):
+    """Eval-mode BN as a per-channel affine (+residual, +ReLU).  Gradients flow to x / residual only: the statistics
+    and the affine are frozen in eval mode."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        call("cn_scale_shift_act", x, residual, y, scale, shift, x.numel() // C, C, int(relu), dtype_code(x.dtype))
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.cfg = (relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        dy = dy.contiguous()
+        C = dy.shape[-1]
+        if relu:
+            g = torch.empty_like(dy)
+            call("cn_relu_bwd", dy, y, g, dy.numel(), dtype_code(dy.dtype))
+            dy = g
+        dx = torch.empty_like(dy)
+        zero = torch.zeros_like(scale)
+        call("cn_scale_shift_act", dy, None, dx, scale, zero, dy.numel() // C, C, 0, dtype_code(dy.dtype))
+        return dx, None, None, (dy if has_res else None), None
+
+
+def scale_shift_act(x, scale, shift, residual, relu):
+    """Affine + residual + ReLU (eval BN that was not folded into a conv)."""
+    return ScaleShiftActFn.apply(x, scale, shift, residual, relu)
+
+
+# ------------------------------------------------------------------------------------------------ pool / up-sample / glue
+class MaxPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        N, H, W, C = x.shape
+        OH, OW = conv_out(H, k, stride, pad), conv_out(W, k, stride, pad)
+        y = _empty_like_shape(x, (N, OH, OW, C))
+        call("cn_maxpool_fwd", x, y, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        ctx.save_for_backward(x)
+        ctx.cfg = (k, stride, pad, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        k, stride, pad, OH, OW = ctx.cfg
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        call("cn_maxpool_bwd", x, dy.contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        return dx, None, None, None
+
+
+class DwDeconvFn(Function):
+    """Depthwise ConvTranspose2d(o,o,2f,stride=f,padding=f//2,groups=o,bias=False); weight fp32 [C,1,k,k]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        N, H, W, C = x.shape
+        k = weight.shape[-1]
+        OH, OW = (H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k
+        y = _empty_like_shape(x, (N, OH, OW, C))
+        call("cn_dwdeconv_fwd", x, weight.detach().contiguous(), y, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, OH, OW = ctx.cfg
+        N, H, W, C = x.shape
+        k = weight.shape[-1]
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("cn_dwdeconv_bwd_input", dy, weight.detach().contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(weight, dtype=torch.float32)
+            call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        return dx, dw, None, None
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        call("cn_add", a, b, out, a.numel(), dtype_code(a.dtype))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class ConcatFn(Function):
+    """torch.cat(xs, channel) on NHWC (pose_dla_dcn.py:182)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        N, H, W, _ = xs[0].shape
+        chans = [t.shape[-1] for t in xs]
+        out = _empty_like_shape(xs[0], (N, H, W, sum(chans)))
+        off, npix = 0, N * H * W
+        for t, c in zip(xs, chans):
+            call("cn_copy_channels", t, c, 0, out, sum(chans), off, npix, c, dtype_code(t.dtype))
+            off += c
+        ctx.chans = chans
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        N, H, W, tot = dy.shape
+        outs, off = [], 0
+        for i, c in enumerate(ctx.chans):
+            if ctx.needs_input_grad[i]:
+                g = _empty_like_shape(dy, (N, H, W, c))
+                call("cn_copy_channels", dy, tot, off, g, c, 0, N * H * W, c, dtype_code(dy.dtype))
+                outs.append(g)
+            else:
+                outs.append(None)
+            off += c
+        return tuple(outs)
+
+
+class ToNCHWFn(Function):
+    """NHWC activations -> public NCHW fp32 tensor with C real channels (drops channel padding)."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        N, H, W, ld = x.shape
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+        call("cn_nhwc_to_nchw", x, out, N, C, H, W, ld, dtype_code(x.dtype))
+        ctx.cfg = (ld, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        ld, dt = ctx.cfg
+        N, C, H, W = dy.shape
+        dx = torch.empty((N, H, W, ld), dtype=dt, device=dy.device)
+        call("cn_nchw_to_nhwc", dy.contiguous(), dx, N, C, H, W, ld, dtype_code(dt))
+        return dx, None
+
+
+def to_nhwc(x_nchw, dtype, cpad=None):
+    """Public NCHW fp32 tensor -> NHWC activations (no autograd: used for inputs)."""
+    N, C, H, W = x_nchw.shape
+    cpad = cpad or rup(C, 16)
+    out = torch.empty((N, H, W, cpad), dtype=dtype, device=x_nchw.device)
+    call("cn_nchw_to_nhwc", x_nchw.contiguous(), out, N, C, H, W, cpad, dtype_code(dtype))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ DCNv2
+class DCNv2Fn(Function):
+    """DCN(chi, cho, 3x3, stride 1, pad 1, dilation 1, deformable_groups 1) — pose_dla_dcn.py:441-449.
+    weight [Co,Ci,3,3], bias [Co], om_weight [27,Ci,3,3], om_bias [27]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, om_weight, om_bias):
+        Co, Ci, _, _ = weight.shape
+        N, H, W, _ = x.shape
+        dt = dtype_code(x.dtype)
+        om = _igemm(x, pack_weight(om_weight, 1, x.dtype), om_bias.detach(), None, 27, 3, 3, 1, 1, False, False, H, W)
+        col = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
+        call("cn_dcn_im2col", x, om, col, N, H, W, Ci, Ci, om.shape[-1], dt)
+        wp = pack_weight(weight, 1, x.dtype)                  # [Co_pad][9*Ci]: a 1x1 conv over the columns
+        y = _igemm(col, wp, bias.detach(), None, Co, 1, 1, 1, 0, False, False, H, W)
+        ctx.save_for_backward(x, om, col, weight, om_weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, om, col, weight, om_weight = ctx.saved_tensors
+        Co, Ci, _, _ = weight.shape
+        N, H, W, _ = x.shape
+        dt = dtype_code(x.dtype)
+        dy = dy.contiguous()
+        # main weight / bias: 1x1 wgrad over the sampled columns
+        dwp, db = _wgrad(col, dy, Co, 1, 1, 1, 0, True)
+        dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
+        # column gradient: dcol[p][t*Ci+ci] = sum_co dy[p][co] * W[co][ci][t]
+        wpd = pack_weight(weight, 2, x.dtype)                 # [9*Ci][Co]
+        dcol = _igemm(dy, wpd, None, None, 9 * Ci, 1, 1, 1, 0, False, False, H, W)
+        dx32 = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
+        dom = torch.zeros_like(om)
+        call("cn_dcn_col2im", dcol, x, om, dx32, dom, N, H, W, Ci, Ci, om.shape[-1], dt)
+        del dcol
+        if x.dtype == torch.float32:
+            dx_s = dx32
+        else:
+            dx_s = torch.empty_like(x)
+            call("cn_cast", dx32, 0, dx_s, dt, dx32.numel())
+        # offset/mask conv backward (its data gradient is added to the sampling gradient through `residual`)
+        dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)
+        dw_om = unpack_wgrad(dwp_om, 27, Ci, 3, 3)
+        wpo = pack_weight(om_weight, 0, x.dtype)              # rows = Ci, k = tap*32 + c
+        dx = torch.empty_like(x)
+        call("cn_conv2d_fwd", dom, wpo, None, dx_s, dx, N, H, W, om.shape[-1], om.shape[-1], H, W, Ci, Ci, Ci,
+             3, 3, 1, 1, 1, 0, dt)
+        return dx, dw, db, dw_om, db_om
+
+
+# ------------------------------------------------------------------------------------------------ losses
+class SigmoidClampFn(Function):
+    """utils/decode.py:43-45: sigmoid IN PLACE on x, returns clamp(x, 1e-4, 1-1e-4)."""
+
+    @staticmethod
+    def forward(ctx, x, lo):
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        y = torch.empty_like(x)
+        call("cn_sigmoid_clamp_fwd", x, y, x.numel(), float(lo))
+        ctx.mark_dirty(x)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x)       # x now holds sigmoid(z): the clamp passes gradient where lo <= x <= 1-lo
+        ctx.lo = float(lo)
+        return x, y
+
+    @staticmethod
+    def backward(ctx, dx_unused, dy):
+        (s,) = ctx.saved_tensors
+        if dx_unused is not None:
+            raise RuntimeError("gradient through the in-place sigmoid alias is not supported; use the clamped output")
+        if dy is None:
+            return None, None
+        dz = torch.empty_like(s)
+        call("cn_sigmoid_clamp_bwd", dy.contiguous(), s, dz, s.numel(), ctx.lo)
+        return dz, None
+
+
+class FocalLossFn(Function):
+    """utils/losses.py:14-39 on sigmoid-clamped predictions."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        pred, gt = pred.contiguous(), gt.contiguous().float()
+        B, C = pred.shape[:2]
+        HW = pred[0, 0].numel()
+        out = torch.empty(4, dtype=torch.float32, device=pred.device)
+        n = _hip.query("cn_focal_workspace_bytes", pred.numel())
+        ws = _hip.workspace(n, pred.device, "focal")
+        call("cn_focal_fwd", pred, gt, out, B, C, HW, gt.shape[0], gt.shape[1], ws, n)
+        ctx.save_for_backward(pred, gt, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt, out = ctx.saved_tensors
+        B, C = pred.shape[:2]
+        dpred = torch.empty_like(pred)
+        call("cn_focal_bwd", pred, gt, out, g.contiguous().float().reshape(1), dpred, B, C, pred[0, 0].numel(), gt.shape[0], gt.shape[1])
+        return dpred, None
+
+
+class GatherL1Fn(Function):
+    """utils/losses.py:53-63 / 81-91: masked L1 between rows gathered at `ind` and the targets."""
+
+    @staticmethod
+    def forward(ctx, feat, mask, ind, target):
+        feat = feat.contiguous()
+        B, C = feat.shape[:2]
+        HW = feat[0, 0].numel()
+        N = ind.shape[1]
+        mask8 = mask.contiguous().to(torch.uint8)
+        has_c = int(mask.dim() == 3)
+        ind = ind.contiguous().long()
+        target = target.contiguous().float()
+        out = torch.empty(3, dtype=torch.float32, device=feat.device)
+        call("cn_gather_l1_fwd", feat, ind, mask8, target, out, B, C, HW, N, has_c)
+        ctx.save_for_backward(feat, ind, mask8, target, out)
+        ctx.has_c = has_c
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, ind, mask8, target, out = ctx.saved_tensors
+        B, C = feat.shape[:2]
+        dfeat = torch.zeros_like(feat)
+        call("cn_gather_l1_bwd", feat, ind, mask8, target, out, g.contiguous().float().reshape(1), dfeat, B, C,
+             feat[0, 0].numel(), ind.shape[1], ctx.has_c)
+        return dfeat, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ functional aliases
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
+    return Conv2dFn.apply(x, weight, bias, stride, pad, relu)
+
+
+def conv_transpose2d(x, weight, stride=2, pad=1):
+    return ConvTranspose2dFn.apply(x, weight, stride, pad)
+
+
+def batch_norm_act(x, bn, residual=None, relu=True):
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu)
+
+
+def max_pool(x, k, stride, pad=0):
+    return MaxPoolFn.apply(x, k, stride, pad)
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+def concat(xs):
+    return xs[0] if len(xs) == 1 else ConcatFn.apply(*xs)

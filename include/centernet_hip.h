@@ -1,0 +1,176 @@
+/* libcenternet_hip.so — C ABI of the MI355X-native CenterNet hot path.
+ *
+ * The reference (tteepe/CenterNet-pytorch-lightning) has no FFI of its own: its hot path is
+ * ATen ops + the DCNv2 CUDA extension.  Each entry point below replaces the ATen/DCNv2 call the
+ * cited reference line makes; Python host code (centernet-pytorch-lightning_amd/_hip.py) binds
+ * them with ctypes.  Conventions:
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless noted
+ *   - activations are NHWC in `dtype` (CN_F32 | CN_BF16); public tensors (images, head maps,
+ *     targets, parameters, gradients) are NCHW fp32 exactly like the reference
+ *   - nothing allocates, frees or synchronises: work is enqueued on `stream` (hipStream_t),
+ *     so every call is hipGraph-capturable; scratch comes from the caller (`ws`, `ws_bytes`)
+ *   - returns 0 on success, <0 for a rejected argument/shape (cn_last_error() explains),
+ *     >0 = hipError_t of the failed launch
+ */
+#ifndef CENTERNET_HIP_H
+#define CENTERNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CN_F32 0
+#define CN_BF16 1
+
+#define CN_OK 0
+#define CN_EINVAL (-1)
+#define CN_EUNSUPPORTED (-2)
+#define CN_EWORKSPACE (-3)
+
+int cn_version(void);
+const char* cn_last_error(void); /* thread-local, host pointer */
+
+/* ---- layout boundary (NCHW fp32 public tensors <-> NHWC activations) -------------------- */
+/* dst[n,h,w,c] = src[n,c,h,w] (c < C), zero for C <= c < Cpad */
+int cn_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int Cpad, int dtype, void* stream);
+/* dst[n,c,h,w] = src[n,h,w,c]; src row pitch = ld channels */
+int cn_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int ld, int dtype, void* stream);
+/* dst[p, dst_off + c] = src[p, src_off + c], c < nch  (torch.cat / slicing along channels: pose_dla_dcn.py:182) */
+int cn_copy_channels(const void* src, int src_ld, int src_off, void* dst, int dst_ld, int dst_off,
+                     int64_t npix, int nch, int dtype, void* stream);
+/* out = a + b (pose_dla_dcn.py:488 `layers[i] + layers[i-1]`); accumulate: out += a */
+int cn_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+int cn_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* ---- dense convolution engine (replaces nn.Conv2d / nn.ConvTranspose2d + their backward) -- */
+/* Pack a 4-D fp32 parameter W[A][B][KH][KW] (t = kh*KW+kw) into the GEMM layout the engine reads:
+ *   mode 0: Wp[b][t*inner_pad + a] = W[a][b][t]   rows = B   -- Conv2d data-gradient / ConvTranspose2d forward
+ *   mode 1: Wp[a][t*inner_pad + b] = W[a][b][t]   rows = A   -- Conv2d forward / ConvTranspose2d data-gradient
+ *   mode 2: Wp[t*B + b][a]         = W[a][b][t]   rows = KH*KW*B, row length inner_pad -- DCN column gradient
+ * rows are zero padded to rows_pad (multiple of 32), the inner (reduction) channel count to inner_pad (multiple
+ * of 16).  row_scale (nullable, fp32[rows]) multiplies each row (eval-mode BN folding). */
+int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, int KW, int mode, int rows_pad, int inner_pad,
+                   const float* row_scale, int dtype, void* stream);
+/* inverse of mode 1 for gradients: dw[a][b][t] = dwp[a][t*inner_pad + b] (fp32 -> fp32) */
+int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, void* stream);
+
+/* Implicit-GEMM convolution, NHWC.  y[n,oh,ow,co] = act(bias[co] + res[..] + sum_{t,ci} xg * Wp[co][t*Ci+ci])
+ *   transposed == 0: xg = x[n, oh*stride - pad + kh, ow*stride - pad + kw, ci]       (nn.Conv2d)
+ *   transposed == 1: xg = x[n, (oh + pad - kh)/stride, (ow + pad - kw)/stride, ci]   (nn.ConvTranspose2d /
+ *                    data-gradient of a strided conv), taps that do not divide are skipped
+ * x pitch = x_ld channels, y pitch = y_ld, residual pitch = res_ld (same dtype as y); bias fp32 nullable.
+ * Requires Ci % 16 == 0. */
+int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
+                  int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
+                  int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, void* stream);
+/* Weight gradient: dwp[co][t*Ci+ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*stride-pad+kh, ow*stride-pad+kw, ci]
+ * dwp is fp32 [Co_pad32][KH*KW*Ci] and must be zeroed by the caller (split-K uses atomics).  db (nullable,
+ * fp32[Co], zeroed) accumulates the bias gradient. */
+int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
+                    int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                    int KH, int KW, int stride, int pad, int dtype, void* stream);
+
+/* Stem convolution for tiny Ci (3 input channels, 7x7): direct kernel on the NCHW fp32 image
+ * (msra_resnet.py:110, pose_dla_dcn.py:282).  w is the raw fp32 parameter [Co,Ci,KH,KW]. */
+int cn_stem_conv_fwd(const float* x_nchw, const float* w, void* y, int N, int Ci, int H, int W, int Co,
+                     int KH, int KW, int stride, int pad, int OH, int OW, int dtype, void* stream);
+int cn_stem_conv_wgrad(const float* x_nchw, const void* dy, float* dw, int N, int Ci, int H, int W, int Co,
+                       int KH, int KW, int stride, int pad, int OH, int OW, int dtype, void* stream);
+
+/* ---- batch norm (nn.BatchNorm2d, momentum 0.1) + ReLU + residual add ---------------------- */
+size_t cn_bn_workspace_bytes(int64_t npix, int C);
+/* training forward: batch statistics over npix rows; y = act(gamma*(x-mean)*invstd + beta [+ residual]);
+ * updates running stats (unbiased var) in place; saves mean / invstd for backward. */
+int cn_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                    int64_t npix, int C, float momentum, float eps, int relu, int dtype,
+                    void* ws, size_t ws_bytes, void* stream);
+/* y = act(x*scale[c] + shift[c] [+ residual])  (eval-mode BN when it cannot be folded into a conv) */
+int cn_scale_shift_act(const void* x, const void* residual, void* y, const float* scale, const float* shift,
+                       int64_t npix, int C, int relu, int dtype, void* stream);
+/* training backward.  y = forward output (for the ReLU mask).  dres (nullable) receives the gradient that flows
+ * to the residual input (= dy masked by ReLU). */
+int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                    const float* save_invstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                    int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* dx = dy * (y > 0)  (ReLU backward for conv+bias+ReLU heads) */
+int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
+
+/* ---- pooling / depthwise up-sampling -------------------------------------------------------- */
+int cn_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad,
+                   int OH, int OW, int dtype, void* stream);
+int cn_maxpool_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
+                   int OH, int OW, int dtype, void* stream);
+/* depthwise ConvTranspose2d(o,o,2f,stride=f,padding=f/2,groups=o) — pose_dla_dcn.py:466-475; w fp32 [C,1,k,k] */
+int cn_dwdeconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int k, int stride, int pad,
+                    int OH, int OW, int dtype, void* stream);
+int cn_dwdeconv_bwd_input(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int k, int stride,
+                          int pad, int OH, int OW, int dtype, void* stream);
+int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp32 [C,k,k] */, int N, int H, int W,
+                           int C, int k, int stride, int pad, int OH, int OW, int dtype, void* stream);
+
+/* ---- DCNv2 (DCN.dcn_v2.DCN, pose_dla_dcn.py:441-449) --------------------- */
+/* om = conv_offset_mask(x) as NHWC [P][om_ld] (channels 0..17 interleaved dy,dx per tap; 18..26 mask logits).
+ * col[p][k*Ci + c] = sigmoid(om[p][18+k]) * bilinear(x[n,:,:,c], h-1+i+dy, w-1+j+dx), k = 3i+j. */
+int cn_dcn_im2col(const void* x, const void* om, void* col, int N, int H, int W, int Ci, int x_ld, int om_ld,
+                  int dtype, void* stream);
+/* Given dcol (gradient of col), accumulate dx (fp32 [P][Ci], zeroed by caller, atomics) and write dom [P][om_ld]. */
+int cn_dcn_col2im(const void* dcol, const void* x, const void* om, float* dx_f32, void* dom,
+                  int N, int H, int W, int Ci, int x_ld, int om_ld, int dtype, void* stream);
+
+/* ---- losses (utils/losses.py) ---------------------------------------------------------------- */
+/* in-place sigmoid on x, y = clamp(x, lo, 1-lo)  (utils/decode.py:43-45) */
+int cn_sigmoid_clamp_fwd(float* x, float* y, int64_t n, float lo, void* stream);
+/* dz = dy * p*(1-p) * [lo <= p <= 1-lo] where p = x (the in-place sigmoid result) */
+int cn_sigmoid_clamp_bwd(const float* dy, const float* x_sig, float* dz, int64_t n, float lo, void* stream);
+size_t cn_focal_workspace_bytes(int64_t n);
+/* penalty-reduced focal loss (utils/losses.py:14-39).  pred [B,C,HW], gt [Bg,Cg,HW] with broadcasting when
+ * Bg/Cg == 1.  out[0] = loss, out[1] = pos_sum, out[2] = neg_sum, out[3] = num_pos (device fp32[4]). */
+int cn_focal_fwd(const float* pred, const float* gt, float* out4, int B, int C, int64_t HW, int gtB, int gtC,
+                 void* ws, size_t ws_bytes, void* stream);
+/* dpred = gout[0] * dloss/dpred, using out4 from the forward */
+int cn_focal_bwd(const float* pred, const float* gt, const float* out4, const float* gout, float* dpred,
+                 int B, int C, int64_t HW, int gtB, int gtC, void* stream);
+/* masked gather-L1 (utils/losses.py:53-63, 81-91): feat NCHW fp32 [B,C,HW]; ind int64 [B,N]; mask uint8 [B,N]
+ * (mask_has_c == 0) or [B,N,C]; target fp32 [B,N,C].  out[0] = loss, out[1] = sum|.|, out[2] = sum(mask). */
+int cn_gather_l1_fwd(const float* feat, const int64_t* ind, const uint8_t* mask, const float* target, float* out3,
+                     int B, int C, int64_t HW, int N, int mask_has_c, void* stream);
+/* dfeat must be zeroed by the caller; scatter-adds gout[0] * dloss/dfeat */
+int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uint8_t* mask, const float* target,
+                     const float* out3, const float* gout, float* dfeat,
+                     int B, int C, int64_t HW, int N, int mask_has_c, void* stream);
+
+/* ---- decode (utils/decode.py, decode/ctdet.py, decode/multi_pose.py) -------------------------- */
+/* keep[b,c,h,w] = heat * (maxpool3x3(heat) == heat)   (utils/decode.py:5-10) */
+int cn_nms3x3(const float* heat, float* out, int B, int C, int H, int W, void* stream);
+/* per (b,c): top-K of (apply_nms ? nms3x3(heat) : heat) over H*W, descending, ties -> lower index.
+ * scores fp32 [B,C,K], inds int32 [B,C,K].  K <= 256.  (utils/decode.py:16, :34) */
+int cn_topk_channel(const float* heat, float* scores, int32_t* inds, int B, int C, int H, int W, int K,
+                    int apply_nms, void* stream);
+/* generic row top-K: x fp32 [R][L] -> vals [R][K], idx int32 [R][K]; L <= 65536 (utils/decode.py:22) */
+int cn_topk_rows(const float* x, float* vals, int32_t* idx, int R, int L, int K, void* stream);
+/* out[b,n,c] = feat[b,c,ind[b,n]]  (utils/decode.py:59-63); ind int64 */
+int cn_gather_rows(const float* feat, const int64_t* ind, float* out, int B, int C, int64_t HW, int N, void* stream);
+/* fused ctdet_decode (decode/ctdet.py:6-38): heat is post-sigmoid.  det fp32 [B,K,6]; inds int64 [B,K] and
+ * clses int32 [B,K] are optional outputs (nullable).  ws >= cn_ctdet_decode_workspace_bytes. */
+size_t cn_ctdet_decode_workspace_bytes(int B, int C, int K);
+int cn_ctdet_decode(const float* heat, const float* wh, const float* reg /* nullable */, float* det,
+                    int64_t* inds, int32_t* clses, int B, int C, int H, int W, int K,
+                    void* ws, size_t ws_bytes, void* stream);
+/* fused multi_pose_decode (decode/multi_pose.py:7-96): det fp32 [B,K,5+2J+1+J] */
+size_t cn_multi_pose_decode_workspace_bytes(int B, int J, int K);
+int cn_multi_pose_decode(const float* heat, const float* wh, const float* kps, const float* reg /* nullable */,
+                         const float* hm_hp, const float* hp_offset /* nullable */, float* det,
+                         int B, int J, int H, int W, int K, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- optimiser (torch.optim.Adam defaults, centernet.py:94-95) -------------------------------- */
+/* flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t are computed by the host */
+int cn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                 float eps, float bc1, float bc2, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""GPU parity of the decode and loss kernels: bit-exact indices / peak masks / detections against the golden vectors
+made by the imported reference and against the oracle; losses within 1e-4 relative (north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from centernet_amd import rng, synth
+from oracle import ops_ref
+from conftest import strided, summary
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _decode_inputs(seed, B, C, realistic, H=128, W=128):
+    z = rng.t_normal(seed, "heat", (B, C, H, W))
+    if realistic:
+        z = 0.5 * z - 2.19
+    return (torch.sigmoid(z), rng.t_uniform(seed, "wh", (B, 2, H, W), 1.0, 40.0), rng.t_uniform(seed, "reg", (B, 2, H, W)))
+
+
+@pytest.mark.parametrize("tag", ["rand", "real", "small"])
+def test_ctdet_decode_golden_bit_exact(golden, tag):
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.utils.decode import _nms, _topk, _topk_channel
+    g = golden(f"decode_{tag}.npz")
+    heat, wh, reg = _decode_inputs(int(g["seed"]), int(g["B"]), int(g["C"]), bool(g["realistic"]))
+    K = int(g["K"])
+    det, inds, clses = ctdet_decode(heat.to(DEV), wh.to(DEV), reg.to(DEV), K=K, return_aux=True)
+    assert np.array_equal(inds.cpu().numpy(), g["inds"]), "top-k indices must be bit-identical"
+    assert np.array_equal(clses.cpu().numpy(), g["clses"])
+    assert np.array_equal(det.cpu().numpy(), g["det"])
+    assert np.array_equal(ctdet_decode(heat.to(DEV), wh.to(DEV), None, K=K).cpu().numpy(), g["det_noreg"])
+    # peak mask (max-pool pseudo NMS) bit-exact
+    nm = _nms(heat.to(DEV)).cpu()
+    keep = (nm == heat) & (heat != 0)
+    assert np.array_equal(keep.flatten(2).sum(-1).numpy(), g["peak_popcount"])
+    assert np.array_equal(np.packbits(keep[0, 0].numpy()), g["peak_mask_b0c0"])
+    assert torch.equal(nm, ops_ref.nms(heat))
+    # reference-named primitives
+    s, i, ys, xs = _topk_channel(nm.to(DEV), K)
+    assert np.array_equal(s[:, :3].cpu().numpy(), g["chan_scores"]) and np.array_equal(i[:, :3].cpu().numpy(), g["chan_inds"])
+    s2, i2, c2, y2, x2 = _topk(nm.to(DEV), K)
+    assert np.array_equal(s2.cpu().numpy(), g["scores"]) and np.array_equal(i2.cpu().numpy(), g["inds"])
+    assert np.array_equal(c2.cpu().numpy(), g["clses"])
+
+
+def test_known_answer_encode_decode(golden):
+    """The reference's own known-answer test (tests/test_sample_encode_decode.py:35-56) through the HIP decode."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    g = golden("known_answer.npz")
+    e = synth.encode_ctdet(synth.FIXTURE_BOXES)
+    hm = torch.from_numpy(e["heatmap"]).unsqueeze(0)
+    wh = torch.zeros(1, 2, 128, 128); reg = torch.zeros(1, 2, 128, 128)
+    for k in range(2):
+        y, x = divmod(int(e["indices"][k]), 128)
+        wh[0, :, y, x] = torch.from_numpy(e["width_height"][k]); reg[0, :, y, x] = torch.from_numpy(e["regression"][k])
+    det = ctdet_decode(hm.to(DEV), wh.to(DEV), reg.to(DEV))[0].cpu().numpy()
+    assert np.array_equal(det, ops_ref.ctdet_decode(hm, wh, reg)[0].numpy()), "tie rule (2 peaks at 1.0, zeros elsewhere)"
+    det = 4 * det[det[:, 4] > 0.5]
+    assert len(det) == 2
+    centers = (det[:, :2] + det[:, 2:4]) / 2
+    assert abs(centers.sum() - float(g["ann_center_sum"])) < 1e-3
+    assert np.array_equal(det[np.argsort(det[:, 0])], g["det_sorted"])
+
+
+@pytest.mark.parametrize("case", ["plateau", "all_equal", "few_peaks", "negative", "odd_size", "k1", "k256"])
+def test_topk_edge_cases_match_oracle(case):
+    """Ties, plateaus (max-pool keeps ALL equal maxima), fewer than K peaks, non-square / non-multiple-of-4 maps."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    B, C, H, W, K = 2, 3, 32, 32, 40
+    heat = torch.sigmoid(rng.t_normal(50, case, (B, C, H, W)))
+    if case == "plateau":
+        heat = (heat * 8).round() / 8          # heavy ties + plateaus
+    elif case == "all_equal":
+        heat = torch.full_like(heat, 0.25)
+    elif case == "few_peaks":
+        heat = torch.zeros_like(heat); heat[:, :, 5, 7] = 0.9; heat[:, 1, 20, 3] = 0.9; heat[0, 2, 31, 31] = 0.4
+    elif case == "negative":
+        heat = rng.t_normal(50, "neg", (B, C, H, W))   # raw (un-sigmoided) maps: negative peaks lose to masked zeros
+    elif case == "odd_size":
+        H, W = 34, 27
+        heat = torch.sigmoid(rng.t_normal(50, "odd", (B, C, H, W)))
+    elif case == "k1":
+        K = 1
+    elif case == "k256":
+        K = 256
+    wh = rng.t_uniform(51, case, (B, 2, H, W), 1, 9); reg = rng.t_uniform(52, case, (B, 2, H, W))
+    det, inds, clses = ctdet_decode(heat.to(DEV), wh.to(DEV), reg.to(DEV), K=K, return_aux=True)
+    rdet, rinds, rcls = ops_ref.ctdet_decode(heat, wh, reg, K=K, return_aux=True)
+    assert torch.equal(inds.cpu(), rinds) and torch.equal(clses.cpu(), rcls)
+    assert torch.equal(det.cpu(), rdet)
+
+
+def test_decode_full_size_properties():
+    """BASELINE config size (B=64, C=80, 128x128): size-independent properties instead of a CPU oracle run."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    B, C, H, W, K = 64, 80, 128, 128, 100
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    heat = torch.sigmoid(torch.randn(B, C, H, W, generator=gen) * 0.5 - 2.19).to(DEV)
+    wh = torch.rand(B, 2, H, W, generator=gen).to(DEV) * 30; reg = torch.rand(B, 2, H, W, generator=gen).to(DEV)
+    det, inds, clses = ctdet_decode(heat, wh, reg, K=K, return_aux=True)
+    sc = det[..., 4]
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all()), "scores sorted descending"
+    flat = heat.flatten(2)
+    picked = torch.gather(flat.view(B, -1), 1, clses.long() * H * W + inds)
+    assert torch.equal(picked, sc), "score == heat[class, index]"
+    # every pick is a 3x3 local maximum, and nothing outside the picks beats the K-th score as a peak
+    pooled = torch.nn.functional.max_pool2d(heat, 3, 1, 1)
+    peaks = torch.where(pooled == heat, heat, torch.zeros_like(heat)).view(B, -1)
+    assert torch.equal(torch.gather(peaks, 1, clses.long() * H * W + inds), sc)
+    kth = sc[:, -1:]
+    assert bool(((peaks > kth).sum(1) <= K - 1).all())
+    # idempotence / determinism
+    det2 = ctdet_decode(heat, wh, reg, K=K)
+    assert torch.equal(det, det2)
+    # sub-batch consistency with the oracle on 2 images
+    r = ops_ref.ctdet_decode(heat[:2].cpu(), wh[:2].cpu(), reg[:2].cpu(), K=K)
+    assert torch.equal(det[:2].cpu(), r)
+
+
+def test_multi_pose_decode_golden(golden):
+    from centernet_amd.decode.multi_pose import multi_pose_decode
+    g = golden("pose_decode.npz")
+    seed, B, K = int(g["seed"]), int(g["B"]), int(g["K"])
+    heat = torch.sigmoid(rng.t_normal(seed, "heat", (B, 1, 128, 128)))
+    hm_hp = torch.sigmoid(rng.t_normal(seed, "hmhp", (B, 17, 128, 128)) * 0.7 - 1.0)
+    wh = rng.t_uniform(seed, "wh", (B, 2, 128, 128), 4.0, 60.0); reg = rng.t_uniform(seed, "reg", (B, 2, 128, 128))
+    kps = rng.t_normal(seed, "kps", (B, 34, 128, 128), 0, 6.0); hpo = rng.t_uniform(seed, "hpo", (B, 2, 128, 128))
+    d = lambda t: t.to(DEV)
+    det = multi_pose_decode(d(heat), d(wh), d(kps), reg=d(reg), hm_hp=d(hm_hp), hp_offset=d(hpo), K=K).cpu().numpy()
+    np.testing.assert_array_equal(det, g["det"])
+    det2 = multi_pose_decode(d(heat), d(wh), d(kps), reg=None, hm_hp=d(hm_hp), hp_offset=None, K=K).cpu().numpy()
+    np.testing.assert_array_equal(det2, g["det_nooff"])
+
+
+def test_losses_golden_and_grads(golden):
+    from centernet_amd.utils.decode import sigmoid_clamped
+    from centernet_amd.utils.losses import FocalLoss, RegL1Loss, RegWeightedL1Loss
+    g = golden("losses.npz")
+    seed = int(g["seed"])
+    _, tgt = synth.ctdet_batch(seed, 2)
+    tg = {k: v.to(DEV) for k, v in tgt.items()}
+    logits = (rng.t_normal(seed, "logit", (2, 80, 128, 128)) * 1.5 - 2.19)
+    whp = rng.t_normal(seed, "whp", (2, 2, 128, 128), 0, 5); regp = rng.t_normal(seed, "regp", (2, 2, 128, 128))
+    lg = logits.to(DEV).requires_grad_(True); wg = whp.to(DEV).requires_grad_(True); rg = regp.to(DEV).requires_grad_(True)
+    x = lg.clone()                                   # sigmoid_clamped works in place on its argument (like the reference)
+    pred = sigmoid_clamped(x)
+    assert torch.allclose(x.detach().cpu(), torch.sigmoid(logits), rtol=1e-6, atol=1e-7), "in-place sigmoid must be observable"
+    hm = FocalLoss()(pred, tg["heatmap"])
+    wh = RegL1Loss()(wg, tg["regression_mask"], tg["indices"], tg["width_height"])
+    off = RegL1Loss()(rg, tg["regression_mask"], tg["indices"], tg["regression"])
+    loss = hm + 0.1 * wh + off
+    loss.backward()
+    for v, k in ((hm, "hm"), (wh, "wh"), (off, "off"), (loss, "loss")):
+        assert v.item() == pytest.approx(float(g[k]), rel=1e-4), k
+    np.testing.assert_allclose(strided(lg.grad).cpu().numpy(), g["dlogits_s"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(summary(lg.grad), g["dlogits_sum"], rtol=1e-4)
+    np.testing.assert_allclose(summary(wg.grad), g["dwh_sum"], rtol=1e-5)
+    np.testing.assert_allclose(summary(rg.grad), g["dreg_sum"], rtol=1e-5)
+    kpp = rng.t_normal(seed, "kpp", (2, 34, 128, 128), 0, 3).to(DEV)
+    kmask = (rng.t_uniform(seed, "kmask", (2, 128, 34)) > 0.5).to(DEV)
+    ktgt = rng.t_normal(seed, "ktgt", (2, 128, 34), 0, 3).to(DEV)
+    assert RegWeightedL1Loss()(kpp, kmask, tg["indices"], ktgt).item() == pytest.approx(float(g["kp"]), rel=1e-4)
+    gt0 = tg["heatmap"].clone(); gt0[gt0 == 1] = 0.99
+    p0 = sigmoid_clamped(logits.to(DEV).clone())
+    assert FocalLoss()(p0, gt0).item() == pytest.approx(float(g["hm_nopos"]), rel=1e-4), "num_pos == 0 branch"
+
+
+def test_focal_broadcast_gt():
+    """tests/test_train_multi_pose.py relies on _neg_loss broadcasting an 80-channel gt against a 1-channel prediction
+    the other way round is what the kernel supports: gt with a size-1 batch/channel broadcast onto pred."""
+    from centernet_amd.utils.losses import FocalLoss
+    pred = torch.sigmoid(rng.t_normal(60, "p", (2, 5, 16, 16))).clamp(1e-4, 1 - 1e-4)
+    gt = rng.t_uniform(60, "g", (1, 1, 16, 16)); gt[0, 0, 3, 3] = 1.0
+    ref = ops_ref.focal_loss(pred, gt.expand_as(pred))
+    out = FocalLoss()(pred.to(DEV), gt.to(DEV))
+    assert out.item() == pytest.approx(ref.item(), rel=1e-5)

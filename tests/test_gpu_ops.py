@@ -1,0 +1,278 @@
+"""GPU parity of every HIP operator (through the C ABI) against plain torch-CPU fp32 references of the same op
+(the oracle's building blocks).  fp32 compute: tight tolerances; bf16 compute: reference built from
+bf16-rounded operands with fp32 accumulation."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from centernet_amd import rng
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def ops():
+    from centernet_amd import ops as o
+    return o
+
+
+def to_nhwc(x, dt):
+    return x.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
+
+
+def to_nchw(y):
+    return y.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, dt):
+    """operand as the kernel sees it"""
+    return x.to(dt).float()
+
+
+def close(a, b, dt, what, scale=None):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    s = float(b.abs().max()) if scale is None else scale
+    s = max(s, 1e-6)
+    tol = 2e-5 if dt == torch.float32 else 1.5e-2
+    err = float((a - b).abs().max()) / s
+    assert err < tol, f"{what}: max err / max|ref| = {err:.3e} (tol {tol})"
+
+
+CONVS = [  # N,H,W,Ci,Co,k,s,p,bias,relu
+    (2, 16, 16, 16, 16, 3, 1, 1, False, False),
+    (2, 17, 19, 32, 48, 3, 1, 1, True, True),
+    (1, 16, 16, 64, 128, 3, 2, 1, False, False),
+    (1, 15, 13, 64, 64, 3, 2, 1, False, False),
+    (2, 8, 8, 128, 256, 1, 1, 0, False, False),
+    (2, 16, 16, 64, 128, 1, 2, 0, False, False),
+    (2, 12, 12, 256, 27, 3, 1, 1, True, False),
+    (1, 9, 9, 256, 2, 1, 1, 0, True, False),
+    (2, 4, 4, 512, 256, 3, 1, 1, False, False),
+    (1, 24, 24, 448, 128, 1, 1, 0, False, False),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d_fwd_bwd(cfg, dt):
+    N, H, W, Ci, Co, k, s, p, bias, relu = cfg
+    x = rng.t_normal(1, f"x{cfg}", (N, Ci, H, W))
+    w = rng.t_normal(1, f"w{cfg}", (Co, Ci, k, k), 0, (2.0 / (Ci * k * k)) ** 0.5)
+    b = rng.t_normal(1, f"b{cfg}", (Co,), 0, 0.1) if bias else None
+    xr, wr = rnd(x, dt).requires_grad_(True), rnd(w, dt).requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, s, p)
+    if relu:
+        yr = F.relu(yr)
+    gy = rng.t_normal(1, f"g{cfg}", tuple(yr.shape))
+    yr.backward(rnd(gy, dt))
+
+    xg = to_nhwc(x, dt).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    y = ops().conv2d(xg, wg, bg, s, p, relu)
+    assert y.shape[-1] == (Co + 15) // 16 * 16
+    close(to_nchw(y)[:, :Co], yr, dt, "conv fwd")
+    if y.shape[-1] != Co:
+        assert float(y[..., Co:].abs().max()) == 0.0, "channel padding must stay zero"
+    gyp = torch.zeros(y.shape, dtype=dt, device=DEV)
+    gyp[..., :Co] = to_nhwc(gy, dt)
+    y.backward(gyp)
+    close(to_nchw(xg.grad), xr.grad, dt, "conv dgrad")
+    close(wg.grad, wr.grad, dt, "conv wgrad")
+    if bias:
+        close(bg.grad, br.grad, dt, "conv bias grad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 32), (1, 5, 7, 512, 256), (2, 16, 16, 256, 256)])
+def test_conv_transpose_4x4_s2(cfg, dt):
+    N, H, W, Ci, Co = cfg
+    x = rng.t_normal(2, f"x{cfg}", (N, Ci, H, W))
+    w = rng.t_normal(2, f"w{cfg}", (Ci, Co, 4, 4), 0, (2.0 / (Ci * 4)) ** 0.5)
+    xr, wr = rnd(x, dt).requires_grad_(True), rnd(w, dt).requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, 2, 1)
+    gy = rng.t_normal(2, f"g{cfg}", tuple(yr.shape))
+    yr.backward(rnd(gy, dt))
+    xg, wg = to_nhwc(x, dt).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = ops().conv_transpose2d(xg, wg, 2, 1)
+    close(to_nchw(y), yr, dt, "convT fwd")
+    y.backward(to_nhwc(gy, dt))
+    close(to_nchw(xg.grad), xr.grad, dt, "convT dgrad")
+    close(wg.grad, wr.grad, dt, "convT wgrad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 16, 1), (2, 37, 41, 64, 2), (1, 64, 96, 16, 1)])
+def test_stem_conv(cfg, dt):
+    N, H, W, Co, s = cfg
+    x = rng.t_normal(3, f"x{cfg}", (N, 3, H, W))
+    w = rng.t_normal(3, f"w{cfg}", (Co, 3, 7, 7), 0, 0.1)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, s, 3)
+    gy = rng.t_normal(3, f"g{cfg}", tuple(yr.shape))
+    yr.backward(rnd(gy, dt))
+    wg = w.to(DEV).requires_grad_(True)
+    y = ops().StemConvFn.apply(x.to(DEV), wg, s, 3, dt)
+    close(to_nchw(y), yr, dt, "stem fwd")
+    y.backward(to_nhwc(gy, dt))
+    close(wg.grad, wr.grad, torch.float32 if dt == torch.float32 else dt, "stem wgrad")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 16, True, True), (2, 9, 11, 64, False, True), (3, 8, 8, 512, True, False),
+                                 (1, 5, 5, 2048, False, False)])
+def test_batchnorm_train(cfg, dt):
+    from centernet_amd import nn as hnn
+    N, H, W, C, use_res, relu = cfg
+    x = rng.t_normal(4, f"x{cfg}", (N, C, H, W), 0.3, 1.7)
+    res = rng.t_normal(4, f"r{cfg}", (N, C, H, W)) if use_res else None
+    bn_ref = torch.nn.BatchNorm2d(C, momentum=0.1)
+    bn = hnn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn_ref.weight.copy_(rng.t_uniform(4, "g", (C,), 0.5, 1.5)); bn_ref.bias.copy_(rng.t_normal(4, "b", (C,), 0, 0.2))
+        bn.weight.copy_(bn_ref.weight); bn.bias.copy_(bn_ref.bias)
+    xr = rnd(x, dt).requires_grad_(True)
+    rr = rnd(res, dt).requires_grad_(True) if use_res else None
+    yr = bn_ref(xr)
+    if use_res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    gy = rng.t_normal(4, f"gy{cfg}", tuple(yr.shape))
+    yr.backward(rnd(gy, dt))
+    xg = to_nhwc(x, dt).requires_grad_(True)
+    rg = to_nhwc(res, dt).requires_grad_(True) if use_res else None
+    bn.train()
+    y = bn(xg, rg, relu)
+    close(to_nchw(y), yr, dt, "bn fwd")
+    close(bn.running_mean, bn_ref.running_mean, torch.float32, "running_mean")
+    close(bn.running_var, bn_ref.running_var, torch.float32, "running_var")
+    y.backward(to_nhwc(gy, dt))
+    # the ReLU mask of the bf16 run is taken from the bf16-rounded output: exclude elements that round across zero
+    close(to_nchw(xg.grad), xr.grad, dt, "bn dx")
+    close(bn.weight.grad, bn_ref.weight.grad, dt, "bn dgamma")
+    close(bn.bias.grad, bn_ref.bias.grad, dt, "bn dbeta")
+    if use_res:
+        close(to_nchw(rg.grad), rr.grad, dt, "bn dres")
+    assert bn.state_dict()["num_batches_tracked"].item() == 1
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 32, 2, 2, 0), (2, 17, 15, 64, 3, 2, 1), (1, 8, 8, 16, 2, 2, 0)])
+def test_maxpool(cfg, dt):
+    N, H, W, C, k, s, p = cfg
+    x = F.relu(rng.t_normal(5, f"x{cfg}", (N, C, H, W)))          # many exact ties at 0, like post-ReLU maps
+    x = rnd(x, dt)
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, k, s, p)
+    gy = rnd(rng.t_normal(5, f"g{cfg}", tuple(yr.shape)), dt)
+    yr.backward(gy)
+    xg = to_nhwc(x, dt).requires_grad_(True)
+    y = ops().max_pool(xg, k, s, p)
+    assert torch.equal(to_nchw(y), yr.detach()), "maxpool fwd must be exact"
+    y.backward(to_nhwc(gy, dt))
+    close(to_nchw(xg.grad), xr.grad, dt, "maxpool bwd (first-max tie rule)")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 2), (1, 6, 5, 64, 4), (2, 4, 4, 256, 2)])
+def test_depthwise_up(cfg, dt):
+    N, H, W, C, f = cfg
+    k = 2 * f
+    x = rng.t_normal(6, f"x{cfg}", (N, C, H, W))
+    w = rng.t_uniform(6, f"w{cfg}", (C, 1, k, k), 0.0, 0.5)
+    xr, wr = rnd(x, dt).requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, f, f // 2, groups=C)
+    gy = rng.t_normal(6, f"g{cfg}", tuple(yr.shape))
+    yr.backward(rnd(gy, dt))
+    xg, wg = to_nhwc(x, dt).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = ops().DwDeconvFn.apply(xg, wg, f, f // 2)
+    close(to_nchw(y), yr, dt, "dwdeconv fwd")
+    y.backward(to_nhwc(gy, dt))
+    close(to_nchw(xg.grad), xr.grad, dt, "dwdeconv dx")
+    close(wg.grad, wr.grad, dt, "dwdeconv dw")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 12, 12, 64, 64), (1, 9, 7, 128, 64), (1, 6, 6, 512, 256), (2, 16, 16, 32, 16)])
+def test_dcnv2(cfg, dt):
+    """vs oracle/dcn_ref.py (pure torch); offsets are O(1) so every bilinear corner / border case is exercised."""
+    from centernet_amd import nn as hnn
+    from oracle.dcn_ref import DCN as RefDCN
+    N, H, W, Ci, Co = cfg
+    ref = RefDCN(Ci, Co)
+    with torch.no_grad():
+        ref.weight.copy_(rnd(rng.t_normal(7, f"w{cfg}", (Co, Ci, 3, 3), 0, (2.0 / (Ci * 9)) ** 0.5), dt))
+        ref.bias.copy_(rng.t_normal(7, "b", (Co,), 0, 0.1))
+        ref.conv_offset_mask.weight.copy_(rnd(rng.t_normal(7, f"ow{cfg}", (27, Ci, 3, 3), 0, 0.6 / (Ci * 9) ** 0.5), dt))
+        ref.conv_offset_mask.bias.copy_(rng.t_normal(7, "ob", (27,), 0, 0.3))
+    mod = hnn.DCN(Ci, Co).to(DEV)
+    mod.load_state_dict(ref.state_dict())
+    x = rng.t_normal(7, f"x{cfg}", (N, Ci, H, W))
+    xr = rnd(x, dt).requires_grad_(True)
+    yr = ref(xr)
+    gy = rng.t_normal(7, f"g{cfg}", tuple(yr.shape))
+    yr.backward(rnd(gy, dt))
+    xg = to_nhwc(x, dt).requires_grad_(True)
+    y = mod(xg)
+    # bf16: the offsets themselves are rounded to bf16 in HBM, which moves sampling points by up to 2^-8 px
+    tol_dt = dt
+    close(to_nchw(y), yr, tol_dt, "dcn fwd", scale=float(yr.abs().max()) * (1 if dt == torch.float32 else 3))
+    y.backward(to_nhwc(gy, dt))
+    sc = (1 if dt == torch.float32 else 4)
+    close(to_nchw(xg.grad), xr.grad, dt, "dcn dx", scale=float(xr.grad.abs().max()) * sc)
+    close(mod.weight.grad, ref.weight.grad, dt, "dcn dw", scale=float(ref.weight.grad.abs().max()) * sc)
+    close(mod.bias.grad, ref.bias.grad, dt, "dcn db", scale=float(ref.bias.grad.abs().max()) * sc)
+    close(mod.conv_offset_mask.weight.grad, ref.conv_offset_mask.weight.grad, dt, "dcn d(offset conv w)",
+          scale=float(ref.conv_offset_mask.weight.grad.abs().max()) * sc)
+    close(mod.conv_offset_mask.bias.grad, ref.conv_offset_mask.bias.grad, dt, "dcn d(offset conv b)",
+          scale=float(ref.conv_offset_mask.bias.grad.abs().max()) * sc)
+
+
+def test_dcn_zero_init_is_half_conv():
+    """Known-answer test 1 of SURVEY Appendix A on the HIP kernel (the state of every DCN at the start of training)."""
+    from centernet_amd import nn as hnn
+    mod = hnn.DCN(32, 48).to(DEV)
+    x = rng.t_normal(8, "x", (2, 32, 10, 10))
+    y = mod(to_nhwc(x, torch.float32))
+    ref = 0.5 * F.conv2d(x, mod.weight.detach().cpu(), None, 1, 1) + mod.bias.detach().cpu().view(1, -1, 1, 1)
+    close(to_nchw(y), ref, torch.float32, "dcn zero-init")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_glue_ops(dt):
+    o = ops()
+    a = rng.t_normal(9, "a", (2, 32, 7, 9)); b = rng.t_normal(9, "b", (2, 16, 7, 9)); c = rng.t_normal(9, "c", (2, 64, 7, 9))
+    ag, bg, cg = (to_nhwc(t, dt).requires_grad_(True) for t in (a, b, c))
+    cat = o.concat([ag, bg, cg])
+    assert torch.equal(to_nchw(cat), torch.cat([rnd(a, dt), rnd(b, dt), rnd(c, dt)], 1))
+    g = rng.t_normal(9, "g", (2, 112, 7, 9))
+    cat.backward(to_nhwc(g, dt))
+    assert torch.equal(to_nchw(bg.grad), rnd(g, dt)[:, 32:48])
+    s = o.add(ag.detach(), to_nhwc(rng.t_normal(9, "a2", (2, 32, 7, 9)), dt))
+    close(to_nchw(s), rnd(a, dt) + rnd(rng.t_normal(9, "a2", (2, 32, 7, 9)), dt), dt, "add")
+    y = o.ToNCHWFn.apply(cg, 50)
+    assert y.dtype == torch.float32 and torch.equal(y.cpu(), rnd(c, dt)[:, :50])
+    y.backward(g[:, :50].to(DEV).contiguous())
+    gg = to_nchw(cg.grad)
+    assert torch.equal(gg[:, :50], rnd(g[:, :50], dt)) and float(gg[:, 50:].abs().max()) == 0
+
+
+def test_adam_matches_torch():
+    from centernet_amd.engine import FlatAdam
+    ps = [torch.nn.Parameter(rng.t_normal(10, f"p{i}", s).to(DEV)) for i, s in enumerate([(33, 7), (5,), (64, 3, 3, 3)])]
+    qs = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt, ref = FlatAdam(ps, lr=1e-2), torch.optim.Adam(qs, lr=1e-2)
+    for it in range(3):
+        opt.zero_grad(); ref.zero_grad()
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            g = rng.t_normal(11 + it, f"g{i}", tuple(q.shape))
+            p.grad.add_(g.to(DEV)); q.grad = g.clone()
+        opt.step(); ref.step()
+    for p, q in zip(ps, qs):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), rtol=1e-5, atol=1e-6)
