@@ -34,6 +34,7 @@ struct ConvGeom {
     int ktot;   // weight row length = total taps * Ci
     int co_pad; // weight rows available
     int relu;
+    int y_f32;  // store the output as fp32 even in bf16 compute mode (DCN offsets / mask logits)
     int sm;     // input index = out_class_index * sm + d[tap]
     int so;     // output index = out_class_index * so + parity
     int ntaps[CN_MAX_CLS];
@@ -243,6 +244,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+                if (sizeof(T) == 2 && g.y_f32) {
+                    float* dstf = reinterpret_cast<float*>(g.y) + pix * g.y_ld + ch;
+                    if (full) {
+                        *reinterpret_cast<float4*>(dstf) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ch + e < g.Co) dstf[e] = v[e];
+                    }
+                    continue;
+                }
                 T* dst = Y + pix * g.y_ld + ch;
                 if (full) {
                     if constexpr (sizeof(T) == 2) {
@@ -313,20 +325,35 @@ static void launch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
     hipLaunchKernelGGL((conv_igemm_kernel<T, BN, BK>), grid, dim3(256), 0, st, g);
 }
 
-template <typename T>
-static int dispatch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
-    // BN: smallest padded waste, ties -> larger tile
-    int co32 = (g.Co + 31) / 32 * 32;
+// tile choice: BN = smallest padded waste over {32,64,128} (ties -> larger); BK by divisibility of Ci
+static void pick_tile(int Ci, int Co, int dtype, int* bn_out, int* bk_out) {
+    int co32 = (Co + 31) / 32 * 32;
     int best = 32, bestw = co32;
     for (int bn : {64, 128}) {
         int w = (co32 + bn - 1) / bn * bn;
         if (w <= bestw) { best = bn; bestw = w; }
     }
+    int bk = 16;
+    if (dtype == CN_BF16) {
+        bk = (Ci % 64 == 0) ? 64 : (Ci % 32 == 0 ? 32 : 16);
+        if (best == 128 && bk == 64) bk = 32;  // keep LDS <= 40 KB/block for 128x128 tiles
+    }
+    *bn_out = best;
+    *bk_out = bk;
+}
+
+extern "C" int cn_conv2d_variant(int Ci, int Co, int dtype) {
+    int bn, bk;
+    pick_tile(Ci, Co, dtype, &bn, &bk);
+    return bn * 1000 + bk;
+}
+
+template <typename T>
+static int dispatch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
+    int best, bk;
+    pick_tile(g.Ci, g.Co, sizeof(T) == 2 ? CN_BF16 : CN_F32, &best, &bk);
 #define CN_IG(BN_, BK_) launch_igemm<T, BN_, BK_>(g, ncls, st)
     if constexpr (sizeof(T) == 2) {
-        // BK: 64/32/16 by divisibility of Ci
-        int bk = (g.Ci % 64 == 0) ? 64 : (g.Ci % 32 == 0 ? 32 : 16);
-        if (best == 128 && bk == 64) bk = 32;  // keep LDS <= 40 KB/block for 128x128 tiles
         if (best == 128) { if (bk == 32) CN_IG(128, 32); else CN_IG(128, 16); }
         else if (best == 64) { if (bk == 64) CN_IG(64, 64); else if (bk == 32) CN_IG(64, 32); else CN_IG(64, 16); }
         else { if (bk == 64) CN_IG(32, 64); else if (bk == 32) CN_IG(32, 32); else CN_IG(32, 16); }
@@ -339,7 +366,8 @@ static int dispatch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
 
 extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                              int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
-                             int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, void* stream) {
+                             int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype,
+                             void* stream) {
     CN_CHECK_ARG(x && wp && y, "cn_conv2d_fwd: null pointer");
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0, "cn_conv2d_fwd: bad dims");
     if (Ci % 16 != 0 || Ci <= 0) CN_UNSUPPORTED("cn_conv2d_fwd: Ci=%d must be a positive multiple of 16", Ci);
@@ -354,6 +382,9 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     g.x = x; g.w = wp; g.bias = bias; g.res = residual; g.y = y;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = OH; g.OW = OW; g.Co = Co; g.y_ld = y_ld;
     g.res_ld = res_ld; g.ktot = KH * KW * Ci; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu;
+    g.y_f32 = (out_dtype == CN_F32);
+    CN_CHECK_ARG(out_dtype == dtype || out_dtype == CN_F32, "cn_conv2d_fwd: out_dtype must be the compute dtype or fp32");
+    CN_CHECK_ARG(!(residual && out_dtype != dtype), "cn_conv2d_fwd: residual needs out_dtype == dtype");
     int ncls = build_geom(g, KH, KW, stride, pad, transposed);
     if (ncls < 0) CN_UNSUPPORTED("cn_conv2d_fwd: kernel %dx%d stride %d not supported", KH, KW, stride);
     if (dtype == CN_F32) dispatch_igemm<float>(g, ncls, (hipStream_t)stream);

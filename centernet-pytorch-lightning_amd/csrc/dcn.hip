@@ -32,7 +32,7 @@ __device__ static inline Tap make_tap(float py, float px, int H, int W) {
 __device__ static inline float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dcn_im2col_kernel(const T* __restrict__ x, const T* __restrict__ om,
+__global__ __launch_bounds__(256) void dcn_im2col_kernel(const T* __restrict__ x, const float* __restrict__ om,
                                                          T* __restrict__ col, int N, int H, int W, int Ci, int x_ld,
                                                          int om_ld) {
     constexpr int V = Vec16<T>::N;
@@ -46,10 +46,10 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const T* __restrict__ x
         const int w = (int)(p % W);
         const int64_t q = p / W;
         const int h = (int)(q % H), n = (int)(q / H);
-        const T* o = om + p * om_ld;
-        const float py = (float)(h - 1 + k / 3) + Elem<T>::ld(o + 2 * k);
-        const float px = (float)(w - 1 + k % 3) + Elem<T>::ld(o + 2 * k + 1);
-        const float m = sigmoidf_(Elem<T>::ld(o + 18 + k));
+        const float* o = om + p * om_ld;
+        const float py = (float)(h - 1 + k / 3) + o[2 * k];
+        const float px = (float)(w - 1 + k % 3) + o[2 * k + 1];
+        const float m = sigmoidf_(o[18 + k]);
         const Tap t = make_tap(py, px, H, W);
         const T* xb = x + (int64_t)n * H * W * x_ld + cv * V;
         float acc[V], v[V];
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const T* __restrict__ x
 // One lane group (GS lanes, power of two <= 64) per (pixel, tap); lanes stride over the channel vectors.
 template <typename T>
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ dcol, const T* __restrict__ x,
-                                                         const T* __restrict__ om, float* __restrict__ dx,
-                                                         T* __restrict__ dom, int N, int H, int W, int Ci, int x_ld,
+                                                         const float* __restrict__ om, float* __restrict__ dx,
+                                                         float* __restrict__ dom, int N, int H, int W, int Ci, int x_ld,
                                                          int om_ld, int GS) {
     constexpr int V = Vec16<T>::N;
     const int CV = Ci / V;
@@ -90,10 +90,10 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ d
         const int w = (int)(p % W);
         const int64_t q = p / W;
         const int h = (int)(q % H), n = (int)(q / H);
-        const T* o = om + p * om_ld;
-        const float py = (float)(h - 1 + k / 3) + Elem<T>::ld(o + 2 * k);
-        const float px = (float)(w - 1 + k % 3) + Elem<T>::ld(o + 2 * k + 1);
-        const float m = sigmoidf_(Elem<T>::ld(o + 18 + k));
+        const float* o = om + p * om_ld;
+        const float py = (float)(h - 1 + k / 3) + o[2 * k];
+        const float px = (float)(w - 1 + k % 3) + o[2 * k + 1];
+        const float m = sigmoidf_(o[18 + k]);
         const Tap t = make_tap(py, px, H, W);
         const int64_t img = (int64_t)n * H * W;
         float s_m = 0.f, s_y = 0.f, s_x = 0.f;
@@ -128,15 +128,15 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const T* __restrict__ d
             s_x += __shfl_xor(s_x, ofs, 64);
         }
         if (lg == 0) {
-            T* d = dom + p * om_ld;
-            Elem<T>::st(d + 2 * k, s_y * m);
-            Elem<T>::st(d + 2 * k + 1, s_x * m);
-            Elem<T>::st(d + 18 + k, s_m * m * (1.f - m));
+            float* d = dom + p * om_ld;
+            d[2 * k] = s_y * m;
+            d[2 * k + 1] = s_x * m;
+            d[18 + k] = s_m * m * (1.f - m);
         }
     }
 }
 
-extern "C" int cn_dcn_im2col(const void* x, const void* om, void* col, int N, int H, int W, int Ci, int x_ld, int om_ld,
+extern "C" int cn_dcn_im2col(const void* x, const float* om, void* col, int N, int H, int W, int Ci, int x_ld, int om_ld,
                              int dtype, void* stream) {
     CN_CHECK_ARG(x && om && col && N > 0 && H > 0 && W > 0 && Ci > 0, "cn_dcn_im2col: bad args");
     const int V = dtype == CN_F32 ? 4 : 8;
@@ -145,12 +145,12 @@ extern "C" int cn_dcn_im2col(const void* x, const void* om, void* col, int N, in
     int64_t g = (total + 255) / 256;
     int grid = (int)(g > 65536 ? 65536 : g);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dcn_im2col_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)x, (const T*)om, (T*)col, N, H, W, Ci, x_ld, om_ld));
+                                                   (const T*)x, om, (T*)col, N, H, W, Ci, x_ld, om_ld));
     CN_LAUNCH_CHECK("cn_dcn_im2col");
     return CN_OK;
 }
 
-extern "C" int cn_dcn_col2im(const void* dcol, const void* x, const void* om, float* dx_f32, void* dom, int N, int H, int W,
+extern "C" int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_f32, float* dom, int N, int H, int W,
                              int Ci, int x_ld, int om_ld, int dtype, void* stream) {
     CN_CHECK_ARG(dcol && x && om && dx_f32 && dom && N > 0 && H > 0 && W > 0 && Ci > 0, "cn_dcn_col2im: bad args");
     const int V = dtype == CN_F32 ? 4 : 8;
@@ -162,7 +162,7 @@ extern "C" int cn_dcn_col2im(const void* dcol, const void* x, const void* om, fl
     int64_t g = (ngroups + gpb - 1) / gpb;
     int grid = (int)(g > 65536 ? 65536 : g);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dcn_col2im_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                                   (const T*)dcol, (const T*)x, (const T*)om, dx_f32, (T*)dom, N, H, W, Ci,
+                                                   (const T*)dcol, (const T*)x, om, dx_f32, dom, N, H, W, Ci,
                                                    x_ld, om_ld, GS));
     CN_LAUNCH_CHECK("cn_dcn_col2im");
     return CN_OK;

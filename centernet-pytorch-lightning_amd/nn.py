@@ -36,7 +36,7 @@ class Conv2d(nn.Module):
             return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu)
         return self.infer(x, None, None, None, relu)
 
-    def infer(self, x, scale, shift, residual, relu):
+    def infer(self, x, scale, shift, residual, relu, out_dtype=None):
         """No-grad path: y = act(conv(x)*scale + shift + residual); packed (folded) weights are cached."""
         key = (x.dtype, self.weight._version, None if scale is None else (scale.data_ptr(), scale._version))
         hit = self._cache.get("k")
@@ -50,7 +50,7 @@ class Conv2d(nn.Module):
         Co, _, KH, KW = self.weight.shape
         N, H, W, _ = x.shape
         OH, OW = ops.conv_out(H, KH, self.stride, self.padding), ops.conv_out(W, KW, self.stride, self.padding)
-        return ops._igemm(x, c["wp"], c["b"], residual, Co, KH, KW, self.stride, self.padding, False, relu, OH, OW)
+        return ops._igemm(x, c["wp"], c["b"], residual, Co, KH, KW, self.stride, self.padding, False, relu, OH, OW, out_dtype)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -162,7 +162,7 @@ class DCN(nn.Module):
             wp = ops.pack_weight(self.weight, 1, x.dtype, scale)
             self._cache = {"k": key, "wp": wp, "b": (self.bias.detach() * scale + shift).contiguous()}
         N, H, W, Ci = x.shape
-        om = self.conv_offset_mask.infer(x, None, None, None, False)
+        om = self.conv_offset_mask.infer(x, None, None, None, False, out_dtype=torch.float32)
         col = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
         ops.call("cn_dcn_im2col", x, om, col, N, H, W, Ci, Ci, om.shape[-1], ops.dtype_code(x.dtype))
         return ops._igemm(col, self._cache["wp"], self._cache["b"], None, self.weight.shape[0], 1, 1, 1, 0, False, relu, H, W)

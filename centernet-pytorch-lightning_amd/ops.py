@@ -55,14 +55,15 @@ def conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
-def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW):
+def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None):
     N, H, W, Ci = x.shape
     cp = rup(Co, 16)
+    out_dtype = out_dtype or x.dtype
     alloc = torch.empty if cp == Co else torch.zeros
-    y = alloc((N, OH, OW, cp), dtype=x.dtype, device=x.device)
+    y = alloc((N, OH, OW, cp), dtype=out_dtype, device=x.device)
     call("cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
          residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
-         dtype_code(x.dtype))
+         dtype_code(x.dtype), dtype_code(out_dtype))
     return y
 
 
@@ -378,7 +379,9 @@ class DCNv2Fn(Function):
         Co, Ci, _, _ = weight.shape
         N, H, W, _ = x.shape
         dt = dtype_code(x.dtype)
-        om = _igemm(x, pack_weight(om_weight, 1, x.dtype), om_bias.detach(), None, 27, 3, 3, 1, 1, False, False, H, W)
+        # offsets / mask logits stay fp32 in both compute modes: sampling coordinates must not be quantised to bf16
+        om = _igemm(x, pack_weight(om_weight, 1, x.dtype), om_bias.detach(), None, 27, 3, 3, 1, 1, False, False, H, W,
+                    out_dtype=torch.float32)
         col = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
         call("cn_dcn_im2col", x, om, col, N, H, W, Ci, Ci, om.shape[-1], dt)
         wp = pack_weight(weight, 1, x.dtype)                  # [Co_pad][9*Ci]: a 1x1 conv over the columns
@@ -400,9 +403,14 @@ class DCNv2Fn(Function):
         wpd = pack_weight(weight, 2, x.dtype)                 # [9*Ci][Co]
         dcol = _igemm(dy, wpd, None, None, 9 * Ci, 1, 1, 1, 0, False, False, H, W)
         dx32 = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
-        dom = torch.zeros_like(om)
-        call("cn_dcn_col2im", dcol, x, om, dx32, dom, N, H, W, Ci, Ci, om.shape[-1], dt)
+        dom32 = torch.zeros_like(om)
+        call("cn_dcn_col2im", dcol, x, om, dx32, dom32, N, H, W, Ci, Ci, om.shape[-1], dt)
         del dcol
+        if x.dtype == torch.float32:
+            dom = dom32
+        else:
+            dom = torch.empty(om.shape, dtype=x.dtype, device=x.device)
+            call("cn_cast", dom32, 0, dom, dt, dom32.numel())
         if x.dtype == torch.float32:
             dx_s = dx32
         else:
@@ -414,7 +422,7 @@ class DCNv2Fn(Function):
         wpo = pack_weight(om_weight, 0, x.dtype)              # rows = Ci, k = tap*32 + c
         dx = torch.empty_like(x)
         call("cn_conv2d_fwd", dom, wpo, None, dx_s, dx, N, H, W, om.shape[-1], om.shape[-1], H, W, Ci, Ci, Ci,
-             3, 3, 1, 1, 1, 0, dt)
+             3, 3, 1, 1, 1, 0, dt, dt)
         return dx, dw, db, dw_om, db_om
 
 

@@ -61,10 +61,13 @@ int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, i
  *   transposed == 1: xg = x[n, (oh + pad - kh)/stride, (ow + pad - kw)/stride, ci]   (nn.ConvTranspose2d /
  *                    data-gradient of a strided conv), taps that do not divide are skipped
  * x pitch = x_ld channels, y pitch = y_ld, residual pitch = res_ld (same dtype as y); bias fp32 nullable.
+ * out_dtype = dtype, or CN_F32 to keep a bf16-computed result in fp32 (DCN offsets / mask logits).
  * Requires Ci % 16 == 0. */
 int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                   int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
-                  int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, void* stream);
+                  int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype, void* stream);
+/* which tile instantiation cn_conv2d_fwd dispatches to: returns BN*1000 + BK (kernel `conv_igemm_kernel<T,BN,BK>`) */
+int cn_conv2d_variant(int Ci, int Co, int dtype);
 /* Weight gradient: dwp[co][t*Ci+ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*stride-pad+kh, ow*stride-pad+kw, ci]
  * dwp is fp32 [Co_pad32][KH*KW*Ci] and must be zeroed by the caller (split-K uses atomics).  db (nullable,
  * fp32[Co], zeroed) accumulates the bias gradient. */
@@ -112,12 +115,14 @@ int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp
                            int C, int k, int stride, int pad, int OH, int OW, int dtype, void* stream);
 
 /* ---- DCNv2 (DCN.dcn_v2.DCN, pose_dla_dcn.py:441-449) --------------------- */
-/* om = conv_offset_mask(x) as NHWC [P][om_ld] (channels 0..17 interleaved dy,dx per tap; 18..26 mask logits).
+/* om = conv_offset_mask(x) as NHWC FP32 [P][om_ld] in both compute modes — sampling coordinates stay exact —
+ * (channels 0..17 interleaved dy,dx per tap; 18..26 mask logits).
  * col[p][k*Ci + c] = sigmoid(om[p][18+k]) * bilinear(x[n,:,:,c], h-1+i+dy, w-1+j+dx), k = 3i+j. */
-int cn_dcn_im2col(const void* x, const void* om, void* col, int N, int H, int W, int Ci, int x_ld, int om_ld,
+int cn_dcn_im2col(const void* x, const float* om, void* col, int N, int H, int W, int Ci, int x_ld, int om_ld,
                   int dtype, void* stream);
-/* Given dcol (gradient of col), accumulate dx (fp32 [P][Ci], zeroed by caller, atomics) and write dom [P][om_ld]. */
-int cn_dcn_col2im(const void* dcol, const void* x, const void* om, float* dx_f32, void* dom,
+/* Given dcol (gradient of col), accumulate dx (fp32 [P][Ci], zeroed by caller, atomics) and write dom fp32 [P][om_ld]
+ * (zeroed by the caller: only channels 0..26 are written). */
+int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_f32, float* dom,
                   int N, int H, int W, int Ci, int x_ld, int om_ld, int dtype, void* stream);
 
 /* ---- losses (utils/losses.py) ---------------------------------------------------------------- */

@@ -20,7 +20,7 @@ def ops():
 
 
 def to_nhwc(x, dt):
-    return x.permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
+    return x.detach().permute(0, 2, 3, 1).contiguous().to(dt).to(DEV)
 
 
 def to_nchw(y):
@@ -29,7 +29,7 @@ def to_nchw(y):
 
 def rnd(x, dt):
     """operand as the kernel sees it"""
-    return x.to(dt).float()
+    return x.detach().to(dt).float().clone()
 
 
 def close(a, b, dt, what, scale=None):
@@ -256,6 +256,7 @@ def test_glue_ops(dt):
     assert torch.equal(to_nchw(bg.grad), rnd(g, dt)[:, 32:48])
     s = o.add(ag.detach(), to_nhwc(rng.t_normal(9, "a2", (2, 32, 7, 9)), dt))
     close(to_nchw(s), rnd(a, dt) + rnd(rng.t_normal(9, "a2", (2, 32, 7, 9)), dt), dt, "add")
+    cg = to_nhwc(c, dt).requires_grad_(True)
     y = o.ToNCHWFn.apply(cg, 50)
     assert y.dtype == torch.float32 and torch.equal(y.cpu(), rnd(c, dt)[:, :50])
     y.backward(g[:, :50].to(DEV).contiguous())
