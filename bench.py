@@ -1,0 +1,219 @@
+"""Headline benchmark: images/sec of (train step + decode), DLA-34 ctdet, 512x512, bs=64 per GPU, bf16 compute.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + focal/L1 losses + backward (+ RCCL gradient all-reduce overlapped with backward when N > 1) + Adam
++ ctdet_decode of that step's head maps, on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
+`roofline` is measured live with HIP events around every implicit-GEMM conv launch (on the launch stream) inside the
+timed region; `cpu_baseline` times the torch-CPU oracle (port of the reference path) on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+class ConvProbe:
+    """HIP-event timing of every cn_conv2d_fwd launch (the conv_igemm_kernel family), grouped by tile variant."""
+
+    def __init__(self, hip):
+        self.hip, self.records, self.orig = hip, [], hip.call
+
+    def __enter__(self):
+        hip = self.hip
+
+        def call(name, *args):
+            if name != "cn_conv2d_fwd":
+                return self.orig(name, *args)
+            (x, wp, bias, res, y, N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed, relu, dt, odt) = args
+            if transposed and stride > 1:   # only the taps of the output pixel's parity class are visited
+                macs = N * H * W * KH * KW * Ci * Co          # every (input pixel, tap) pair contributes once
+            else:
+                macs = N * OH * OW * KH * KW * Ci * Co
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(name, *args)
+            e1.record()
+            self.records.append((hip.lib().cn_conv2d_variant(Ci, Co, KH, KW, stride, pad, dt), 2.0 * macs, e0, e1))
+        hip.call = call
+        import centernet_amd.ops as ops
+        import centernet_amd.nn as hnn
+        self._mods = [(ops, ops.call)]
+        ops.call = call
+        return self
+
+    def __exit__(self, *a):
+        self.hip.call = self.orig
+        for m, f in self._mods:
+            m.call = f
+
+    def summary(self):
+        by = {}
+        for var, flops, e0, e1 in self.records:
+            t = e0.elapsed_time(e1) * 1e-3
+            d = by.setdefault(var, [0.0, 0.0, 0])
+            d[0] += flops; d[1] += t; d[2] += 1
+        return by
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (torch-CPU restatement of the reference path: same op sequence, pure-torch DCNv2) on the host cores:
+    DLA-34 ctdet train step + decode, fp32, batch 2, 512x512."""
+    from centernet_amd import rng, synth
+    from oracle import models_ref, ops_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = models_ref.CenterNetRef("dla_34")
+    rng.fill_state_dict(m, 1234)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    x, tgt = synth.ctdet_batch(1234, 2)
+    n, t0 = 0, time.time()
+    while True:
+        opt.zero_grad()
+        out = m(x)
+        loss, _ = m.loss(out, tgt)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            ops_ref.ctdet_decode(ops_ref.sigmoid_clamped(out[0]["heatmap"]), out[0]["width_height"], out[0]["regression"])
+        n += 1
+        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
+            break
+    dt = time.time() - t0
+    return {"value": round(2 * n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} step(s) of DLA-34 ctdet train step + decode, batch 2, 512x512, fp32, torch CPU oracle "
+                      f"(pure-torch DCNv2), no warm-up, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--arch", default="dla_34")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="skip the per-launch HIP-event pass that feeds `roofline`")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches + backward-overlapped RCCL buckets instead of hipGraph replay")
+    ap.add_argument("--probe-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    from centernet_amd import _hip, synth
+    from centernet_amd.centernet_detection import CenterNetDetection
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.engine import TrainStep, init_distributed
+
+    rank, local, world = init_distributed()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path for the product)"
+    dev = torch.device("cuda", local)
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234 + rank)
+
+    model = CenterNetDetection(args.arch, compute_dtype=dt).to(dev).train()
+    # one synthetic COCO-like batch per rank (different images per rank), resident in HBM before timing starts
+    nuniq = min(args.batch, 8)
+    x, tgt = synth.ctdet_batch(1234, nuniq, args.size, args.size, start=rank * nuniq)
+    rep = (args.batch + nuniq - 1) // nuniq
+    x = x.repeat(rep, 1, 1, 1)[:args.batch].to(dev)
+    tgt = {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:args.batch].to(dev) for k, v in tgt.items()}
+    batch = (x, tgt)
+    captured = {}
+    orig_loss = model.loss
+
+    def loss_and_keep(outputs, target):          # keep this step's head maps for the decode half of the metric
+        r = orig_loss(outputs, target)
+        captured["out"] = outputs[-1]
+        return r
+    model.loss = loss_and_keep
+
+    def decode():   # heat map is already sigmoid (+clamp) from the loss, like after sigmoid_() in test_step_end
+        out = captured["out"]
+        return ctdet_decode(out["heatmap"].detach(), out["width_height"].detach(), reg=out["regression"].detach())
+
+    step = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_step=decode)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(batch)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(batch)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    det = step.post_out
+    assert det.shape == (args.batch, 100, 6) and bool(torch.isfinite(det).all())
+
+    probe = None
+    if rank == 0 and world == 1 and not args.no_probe:
+        # same step, launched eagerly, with a HIP event pair around every implicit-GEMM launch on the launch stream
+        probe = ConvProbe(_hip)
+        with probe:
+            for _ in range(args.probe_steps):
+                step._eager(batch)
+            torch.cuda.synchronize()
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        roof = None
+        tn = "bf16" if dt == torch.bfloat16 else "f32"
+        kname = lambda v: (f"conv3x3s1_kernel<{tn},{(v - 3000000) // 1000},{v % 1000}>" if v >= 3000000
+                           else f"conv_igemm_kernel<{tn},{v // 1000},{v % 1000}>")
+        if probe:
+            by = probe.summary()
+            var, (fl, tt, n) = max(by.items(), key=lambda kv: kv[1][1])
+            peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+            ach = fl / tt / 1e12
+            allf = sum(v[0] for v in by.values()); allt = sum(v[1] for v in by.values())
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": None,
+                    "how": f"HIP events around each launch, {args.probe_steps} eagerly launched step(s) of the same workload right after the timed region",
+                    "kernel": kname(var),
+                    "launches": n, "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": round(fl / n, 1),
+                    "all_igemm": {"achieved": round(allf / allt / 1e12, 2), "ms_per_step": round(allt / args.probe_steps * 1e3, 3),
+                                  "variants": {kname(k): {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.probe_steps * 1e3, 3), "launches_per_step": v[2] // args.probe_steps}
+                                               for k, v in sorted(by.items())}}}
+        line = {"metric": "images/sec (train step + decode) DLA-34 512x512 bs=64 at 1/2/4/8 MI355X",
+                "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": f"{args.arch} ctdet (80 classes) train step (fwd+loss+bwd+Adam) + ctdet_decode, "
+                                       f"{args.size}x{args.size}, batch {args.batch}/GPU, {args.dtype} compute / fp32 master weights",
+                           "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                           "launch": "eager" if args.no_graph else "hipGraph replay (2 graphs/step)",
+                           "final_loss": round(float(loss.detach()), 4)},
+                "roofline": roof,
+                "cpu_baseline": None}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

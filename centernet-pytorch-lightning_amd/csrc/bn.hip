@@ -93,10 +93,13 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
                                                               float* __restrict__ rmean, float* __restrict__ rvar,
                                                               float* __restrict__ smean, float* __restrict__ sinvstd,
                                                               float* __restrict__ coef, float momentum, float eps) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    // one wave per channel: lanes stride over the per-workgroup partials, fp64 butterfly
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    for (int b = lane; b < nblk; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if (lane != 0) return;
     const double m = s / (double)npix;
     double var = q / (double)npix - m * m;
     if (var < 0.0) var = 0.0;
@@ -117,10 +120,12 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ sinvstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ coef) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    for (int b = lane; b < nblk; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if (lane != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
     coef[c] = gamma[c] * sinvstd[c];
@@ -212,7 +217,7 @@ extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, con
                                                    (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
                                                    (const float*)nullptr, part, npix, C, L, 0));
     CN_LAUNCH_CHECK("cn_bn_train_fwd(partial)");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, coef, momentum, eps);
     CN_LAUNCH_CHECK("cn_bn_train_fwd(finalize)");
     int64_t nvec = npix * (C / V);
@@ -252,7 +257,7 @@ extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, con
                                                    (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, part, npix,
                                                    C, L, relu));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(partial)");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, save_invstd,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, save_invstd,
                        dgamma, dbeta, coef);
     CN_LAUNCH_CHECK("cn_bn_train_bwd(finalize)");
     int64_t nvec = npix * (C / V);

@@ -1,0 +1,167 @@
+// 3x3 / stride 1 / pad 1 convolution (and its data gradient = the same conv with mirrored taps) — the shape that
+// carries most of DLA-34's FLOPs.  The generic implicit-GEMM kernel re-reads every input pixel once per tap and pays
+// one global->LDS round trip + barrier per tap slice, which left it latency-bound (7-15 % of the MFMA peak, ~13 % of the
+// HBM roofline on the 64-channel 128x128 layers).  Here a workgroup owns an 8x16 output-pixel tile:
+//   * the (8+2)x(16+2) input HALO tile of a 64-channel slice is loaded into LDS ONCE (1.4x over-read instead of 9x)
+//     and all 9 taps read their A fragments from it with ds_read_b128 at a per-lane shifted pixel address;
+//   * the per-tap weight slice [BN][64] is double-buffered through LDS with a register prefetch one tap ahead, so the
+//     only exposed global latency per workgroup is the halo load; 2-3 workgroups per CU overlap it with MFMA work.
+// bf16: v_mfma_f32_32x32x16_bf16; fp32 (parity mode): v_mfma_f32_32x32x2_f32.  Epilogue shared with the generic kernel.
+#include "conv_common.h"
+
+#define T3_TH 8
+#define T3_TW 16
+
+template <typename T, int BN, int CK>
+__global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
+    constexpr int BM = T3_TH * T3_TW;                  // 128 output pixels
+    constexpr int HW_ = T3_TW + 2, HH_ = T3_TH + 2;    // halo tile
+    constexpr int HP = HH_ * HW_;                      // 180 halo pixels
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int PITCH = CK + Mma<T>::PAD;
+    constexpr int VPR = CK / VEC;                      // 16-byte vectors per pixel / weight row
+    constexpr int A_VECS = HP * VPR;
+    constexpr int A_PASS = (A_VECS + 255) / 256;
+    constexpr int B_VECS = BN * VPR;
+    constexpr int B_PASS = (B_VECS + 255) / 256;
+    constexpr int WGN = (BN >= 64) ? 2 : 1;
+    constexpr int WGM = 4 / WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / 32, NJ = WN / 32;
+    constexpr int KSTEPS = CK / Mma<T>::KSTEP;
+
+    __shared__ __attribute__((aligned(16))) T lds[(HP + 2 * BN) * PITCH];
+    T* const As = lds;
+    T* const Bs = lds + HP * PITCH;                    // two buffers of BN rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_w = (g.OW + T3_TW - 1) / T3_TW;
+    const int th0 = (blockIdx.x / tiles_w) * T3_TH, tw0 = (blockIdx.x % tiles_w) * T3_TW;
+    const int n0 = blockIdx.y * BN;
+    const int n = blockIdx.z;
+    const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(g.x) + (int64_t)n * g.H * g.W * g.x_ld;
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(g.w);
+
+    // lane's pixels in the halo tile (centre position, i.e. tap shift (0,0))
+    int hbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = wm + i * 32 + (lane & 31);
+        hbase[i] = (m / T3_TW + 1) * HW_ + (m % T3_TW) + 1;
+    }
+
+    f32x16_t acc[NJ][MI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+    uint4 rb[B_PASS];
+    auto bload = [&](int tap, int c0) {
+        const int wofs = (int)g.wt[0][tap] * g.Ci + c0;
+#pragma unroll
+        for (int p = 0; p < B_PASS; ++p) {
+            const int v = tid + p * 256;
+            const int row = v / VPR, col = (v % VPR) * VEC;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (v < B_VECS && n0 + row < g.co_pad) val = *reinterpret_cast<const uint4*>(Wp + (int64_t)(n0 + row) * g.ktot + wofs + col);
+            rb[p] = val;
+        }
+    };
+    auto bstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < B_PASS; ++p) {
+            const int v = tid + p * 256;
+            if (v < B_VECS) lds_store_vec<T, PITCH>(Bs + buf * BN * PITCH, v / VPR, (v % VPR) * VEC, rb[p]);
+        }
+    };
+
+    for (int c0 = 0; c0 < g.Ci; c0 += CK) {
+        if (c0 > 0) __syncthreads();                   // everybody is done with the previous slice's halo tile
+        // ---- halo tile of this channel slice: one pass over HBM/L2 ----
+#pragma unroll
+        for (int p = 0; p < A_PASS; ++p) {
+            const int v = tid + p * 256;
+            if (v < A_VECS) {
+                const int hp = v / VPR, col = (v % VPR) * VEC;
+                const int ih = th0 - 1 + hp / HW_, iw = tw0 - 1 + hp % HW_;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
+                    val = *reinterpret_cast<const uint4*>(X + ((int64_t)ih * g.W + iw) * g.x_ld + c0 + col);
+                lds_store_vec<T, PITCH>(As, hp, col, val);
+            }
+        }
+        bload(0, c0);
+        bstore(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) bload(tap + 1, c0);
+            const int shift = (int)g.dh[0][tap] * HW_ + (int)g.dw[0][tap];
+            const T* bt = Bs + (tap & 1) * BN * PITCH;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                typename Mma<T>::Frag fa[MI], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if constexpr (sizeof(T) == 2) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(As + (hbase[i] + shift) * PITCH + kk * 16 + (lane >> 5) * 8);
+                        fa[i] = __builtin_bit_cast(bf16x8_t, v);
+                    } else {
+                        fa[i] = As[(hbase[i] + shift) * PITCH + kk * 2 + (lane >> 5)];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = Mma<T>::load(bt, PITCH, wn + j * 32, kk, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[j][i] = Mma<T>::mma(fb[j], fa[i], acc[j][i]);
+            }
+            if (tap < 8) bstore((tap + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    int64_t pix[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = wm + i * 32 + (lane & 31);
+        const int oh = th0 + m / T3_TW, ow = tw0 + m % T3_TW;
+        pix[i] = (oh < g.OH && ow < g.OW) ? ((int64_t)n * g.OH + oh) * g.OW + ow : -1;
+    }
+    conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
+}
+
+template <typename T, int BN, int CK>
+static void launch3(const ConvGeom& g, hipStream_t st) {
+    dim3 grid(((g.OH + T3_TH - 1) / T3_TH) * ((g.OW + T3_TW - 1) / T3_TW), (g.Co + BN - 1) / BN, g.N);
+    hipLaunchKernelGGL((conv3x3s1_kernel<T, BN, CK>), grid, dim3(256), 0, st, g);
+}
+
+bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
+    // caller guarantees: 3x3, stride 1, pad 1 geometry in class 0 of g (normal or mirrored taps), OH == H, OW == W
+    if (g.N > 65535) return false;
+    const int co32 = (g.Co + 31) / 32 * 32;
+    int bn = 32, bw = co32;
+    for (int c : {64, 128}) {
+        int w = (co32 + c - 1) / c * c;
+        if (w <= bw) { bn = c; bw = w; }
+    }
+    if (dtype == CN_BF16) {
+        if (g.Ci % 64 == 0) {
+            if (bn == 128) launch3<bf16_t, 128, 64>(g, st); else if (bn == 64) launch3<bf16_t, 64, 64>(g, st); else launch3<bf16_t, 32, 64>(g, st);
+        } else if (g.Ci % 32 == 0) {
+            if (bn == 128) launch3<bf16_t, 128, 32>(g, st); else if (bn == 64) launch3<bf16_t, 64, 32>(g, st); else launch3<bf16_t, 32, 32>(g, st);
+        } else {
+            if (bn == 128) launch3<bf16_t, 128, 16>(g, st); else if (bn == 64) launch3<bf16_t, 64, 16>(g, st); else launch3<bf16_t, 32, 16>(g, st);
+        }
+    } else {
+        if (bn == 128) launch3<float, 128, 16>(g, st); else if (bn == 64) launch3<float, 64, 16>(g, st); else launch3<float, 32, 16>(g, st);
+    }
+    return true;
+}

@@ -15,68 +15,8 @@
 // decomposed by output parity class (blockIdx.z): only the taps whose offset divides the stride
 // are visited, so no MACs are wasted.  Geometry per class comes as small tap tables in the
 // kernel arguments (built by the host below).
-#include "common.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-#define CN_MAX_TAPS 16
-#define CN_MAX_CLS 4
-
-struct ConvGeom {
-    const void* x;
-    const void* w;
-    const float* bias;
-    const void* res;
-    void* y;
-    int N, H, W, Ci, x_ld;
-    int OH, OW, Co, y_ld, res_ld;
-    int ktot;   // weight row length = total taps * Ci
-    int co_pad; // weight rows available
-    int relu;
-    int y_f32;  // store the output as fp32 even in bf16 compute mode (DCN offsets / mask logits)
-    int sm;     // input index = out_class_index * sm + d[tap]
-    int so;     // output index = out_class_index * so + parity
-    int ntaps[CN_MAX_CLS];
-    signed char dh[CN_MAX_CLS][CN_MAX_TAPS];
-    signed char dw[CN_MAX_CLS][CN_MAX_TAPS];
-    unsigned char wt[CN_MAX_CLS][CN_MAX_TAPS];
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    static constexpr int KSTEP = 16;  // k per MFMA
-    static constexpr int PAD = 8;     // elements of row padding (16 bytes)
-    typedef bf16x8_t Frag;
-    __device__ static inline Frag load(const bf16_t* tile, int pitch, int row, int kk, int lane) {
-        const uint4 v = *reinterpret_cast<const uint4*>(tile + (row + (lane & 31)) * pitch + kk * 16 + (lane >> 5) * 8);
-        return __builtin_bit_cast(bf16x8_t, v);
-    }
-    __device__ static inline f32x16_t mma(Frag a, Frag b, f32x16_t c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    static constexpr int KSTEP = 2;
-    static constexpr int PAD = 1;
-    typedef float Frag;
-    __device__ static inline Frag load(const float* tile, int pitch, int row, int kk, int lane) {
-        return tile[(row + (lane & 31)) * pitch + kk * 2 + (lane >> 5)];
-    }
-    __device__ static inline f32x16_t mma(Frag a, Frag b, f32x16_t c) {
-        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-    }
-};
-
-template <typename T, int PITCH>
-__device__ static inline void lds_store_vec(T* tile, int row, int col, uint4 v) {
-    if constexpr (sizeof(T) == 2) {
-        *reinterpret_cast<uint4*>(tile + row * PITCH + col) = v;  // PITCH*2 is a multiple of 16
-    } else {
-        float* p = reinterpret_cast<float*>(tile) + row * PITCH + col;  // odd pitch: scalar stores
-        p[0] = __uint_as_float(v.x); p[1] = __uint_as_float(v.y); p[2] = __uint_as_float(v.z); p[3] = __uint_as_float(v.w);
-    }
-}
+#include "conv_common.h"
+#include <stdlib.h>
 
 template <typename T, int BN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
@@ -204,75 +144,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane holds pixel (lane&31), channels (r&3) + 8*(r>>2) + 4*(lane>>5) of each 32x32 block ----
-    T* __restrict__ Y = reinterpret_cast<T*>(g.y);
-    const T* __restrict__ R = reinterpret_cast<const T*>(g.res);
+    // ---- epilogue ----
+    int64_t pix[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm + i * 32 + (lane & 31);
-        if (m >= Mc) continue;
-        int64_t pix;
+        if (m >= Mc) { pix[i] = -1; continue; }
         if (g.so == 1) {
-            pix = m;
+            pix[i] = m;
         } else {
             int n = m / (OHc * OWc);
             int r = m - n * (OHc * OWc);
             int oh = r / OWc, ow = r - oh * OWc;
-            pix = ((int64_t)n * g.OH + oh * g.so + ph) * g.OW + ow * g.so + pw;
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = n0 + wn + j * 32 + 8 * q + 4 * (lane >> 5);
-                if (ch >= g.Co) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[j][i][q * 4 + e];
-                const bool full = (ch + 4 <= g.Co) && ((g.y_ld & 3) == 0) && (g.res == nullptr || (g.res_ld & 3) == 0);
-                if (g.bias) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (ch + e < g.Co) v[e] += g.bias[ch + e];
-                }
-                if (R) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (ch + e < g.Co) v[e] += Elem<T>::ld(R + pix * g.res_ld + ch + e);
-                }
-                if (g.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (sizeof(T) == 2 && g.y_f32) {
-                    float* dstf = reinterpret_cast<float*>(g.y) + pix * g.y_ld + ch;
-                    if (full) {
-                        *reinterpret_cast<float4*>(dstf) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (ch + e < g.Co) dstf[e] = v[e];
-                    }
-                    continue;
-                }
-                T* dst = Y + pix * g.y_ld + ch;
-                if (full) {
-                    if constexpr (sizeof(T) == 2) {
-                        uint2 o;
-                        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(dst) = o;
-                    } else {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (ch + e < g.Co) Elem<T>::st(dst + e, v[e]);
-                }
-            }
+            pix[i] = ((int64_t)n * g.OH + oh * g.so + ph) * g.OW + ow * g.so + pw;
         }
     }
+    conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -342,10 +229,19 @@ static void pick_tile(int Ci, int Co, int dtype, int* bn_out, int* bk_out) {
     *bk_out = bk;
 }
 
-extern "C" int cn_conv2d_variant(int Ci, int Co, int dtype) {
+static bool use_conv3x3(int KH, int KW, int stride, int pad, int H, int W, int OH, int OW) {
+    static const bool disabled = getenv("CN_DISABLE_CONV3X3") != nullptr;   // A/B switch for profiling
+    return !disabled && KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W;
+}
+
+extern "C" int cn_conv2d_variant(int Ci, int Co, int KH, int KW, int stride, int pad, int dtype) {
     int bn, bk;
     pick_tile(Ci, Co, dtype, &bn, &bk);
-    return bn * 1000 + bk;
+    if (use_conv3x3(KH, KW, stride, pad, 1, 1, 1, 1)) {
+        int ck = dtype == CN_BF16 ? (Ci % 64 == 0 ? 64 : (Ci % 32 == 0 ? 32 : 16)) : 16;
+        return 3000000 + bn * 1000 + ck;        // conv3x3s1_kernel<T, BN, CK>
+    }
+    return bn * 1000 + bk;                      // conv_igemm_kernel<T, BN, BK>
 }
 
 template <typename T>
@@ -387,6 +283,11 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     CN_CHECK_ARG(!(residual && out_dtype != dtype), "cn_conv2d_fwd: residual needs out_dtype == dtype");
     int ncls = build_geom(g, KH, KW, stride, pad, transposed);
     if (ncls < 0) CN_UNSUPPORTED("cn_conv2d_fwd: kernel %dx%d stride %d not supported", KH, KW, stride);
+    if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);
+    if (use_conv3x3(KH, KW, stride, pad, H, W, OH, OW) && conv3x3s1_launch(g, dtype, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_conv2d_fwd(3x3)");
+        return CN_OK;
+    }
     if (dtype == CN_F32) dispatch_igemm<float>(g, ncls, (hipStream_t)stream);
     else if (dtype == CN_BF16) dispatch_igemm<bf16_t>(g, ncls, (hipStream_t)stream);
     else CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);

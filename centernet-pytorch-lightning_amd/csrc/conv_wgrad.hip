@@ -212,15 +212,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
         }
 }
 
+// bias gradient: db[c] += sum_p dy[p][c].  16-byte loads, lanes = (channel vector, pixel row), LDS fold over rows,
+// one atomic per channel per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t P, int C,
-                                                     int ld, int64_t chunk) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
-    int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = p0 + chunk < P ? p0 + chunk : P;
-    float s = 0.f;
-    for (int64_t p = p0; p < p1; ++p) s += Elem<T>::ld(dy + p * ld + c);
-    atomicAdd(db + c, s);
+                                                     int ld, int CVB, int64_t rows_per_blk) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float red[256][V + 1];
+    const int tid = threadIdx.x, cvl = tid % CVB, prow = tid / CVB, RPB = 256 / CVB;
+    const int cv = blockIdx.y * CVB + cvl;
+    float s[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = 0.f;
+    if (prow < RPB && cv * V < C) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk < P ? r0 + rows_per_blk : P;
+        for (int64_t r = r0 + prow; r < r1; r += RPB) {
+            float v[V];
+            Vec16<T>::load(dy + r * ld + cv * V, v);      // ld is padded to a vector multiple
+#pragma unroll
+            for (int j = 0; j < V; ++j) s[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[tid][j] = s[j];
+    __syncthreads();
+    if (prow == 0 && cv * V < C) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float a = 0.f;
+            for (int p = 0; p < RPB; ++p) a += red[p * CVB + cvl][j];
+            if (cv * V + j < C) atomicAdd(db + cv * V + j, a);
+        }
+    }
 }
 
 template <typename T, int BMW, int BNW>
@@ -269,10 +292,16 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float*
 #undef CN_WG
     CN_LAUNCH_CHECK("cn_conv2d_wgrad");
     if (db) {
-        int64_t chunk = 512;
-        dim3 grid(cdiv(g.P, chunk), cdiv(Co, 256));
+        const int CV = (Co + V - 1) / V;
+        const int CVB = CV < 256 ? CV : 256;
+        const int RPB = 256 / CVB;
+        int64_t nblk = (g.P + (int64_t)RPB * 16 - 1) / ((int64_t)RPB * 16);
+        if (nblk > 512) nblk = 512;
+        if (nblk < 1) nblk = 1;
+        const int64_t rows_per_blk = (g.P + nblk - 1) / nblk;
+        dim3 grid((int)nblk, (CV + CVB - 1) / CVB);
         CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, db, g.P, Co,
-                                                       dy_ld, chunk));
+                                                       dy_ld, CVB, rows_per_blk));
         CN_LAUNCH_CHECK("cn_conv2d_wgrad(bias)");
     }
     return CN_OK;

@@ -164,3 +164,30 @@ extern "C" int cn_cast(const void* src, int sd, void* dst, int dd, int64_t n, vo
     CN_LAUNCH_CHECK("cn_cast");
     return CN_OK;
 }
+
+template <typename D>
+__global__ __launch_bounds__(256) void add_f32_to_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         D* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+        const float r[4] = {u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w};
+        if constexpr (sizeof(D) == 4) {
+            reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+            uint2 o;
+            o.x = (uint32_t)f2bf(r[0]) | ((uint32_t)f2bf(r[1]) << 16);
+            o.y = (uint32_t)f2bf(r[2]) | ((uint32_t)f2bf(r[3]) << 16);
+            reinterpret_cast<uint2*>(out)[i] = o;
+        }
+    }
+}
+
+extern "C" int cn_add_f32_to(const float* a, const float* b, void* out, int64_t n, int dtype, void* stream) {
+    CN_CHECK_ARG(a && b && out && n > 0 && n % 4 == 0, "cn_add_f32_to: bad args (n must be a multiple of 4)");
+    int64_t g = (n / 4 + 255) / 256;
+    int grid = (int)(g > 16384 ? 16384 : g);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(add_f32_to_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b,
+                                                   (T*)out, n / 4));
+    CN_LAUNCH_CHECK("cn_add_f32_to");
+    return CN_OK;
+}

@@ -4,7 +4,8 @@
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2, float gscale) {
+                                                   float bc1, float bc2, float gscale, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }   // graph replays read the per-step values from HBM
     const float step = lr / bc1;
     const float rsb2 = 1.f / sqrtf(bc2);
     const int64_t nv = n / 4;
@@ -33,12 +34,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 extern "C" int cn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                            float bc1, float bc2, float grad_scale, void* stream) {
+                            float bc1, float bc2, float grad_scale, const float* hyper, void* stream) {
     CN_CHECK_ARG(p && g && m && v && n > 0, "cn_adam_step: bad args");
     CN_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "cn_adam_step: buffers must be 16-byte aligned");
     int64_t gr = (n / 4 + 255) / 256;
     int grid = (int)(gr > 8192 ? 8192 : (gr < 1 ? 1 : gr));
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, bc1, bc2, grad_scale, hyper);
     CN_LAUNCH_CHECK("cn_adam_step");
     return CN_OK;
 }

@@ -402,20 +402,19 @@ class DCNv2Fn(Function):
         # column gradient: dcol[p][t*Ci+ci] = sum_co dy[p][co] * W[co][ci][t]
         wpd = pack_weight(weight, 2, x.dtype)                 # [9*Ci][Co]
         dcol = _igemm(dy, wpd, None, None, 9 * Ci, 1, 1, 1, 0, False, False, H, W)
-        dx32 = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
+        dx_tile = torch.empty((N, H, W, Ci), dtype=torch.float32, device=x.device)
+        dx_far = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
         dom32 = torch.zeros_like(om)
-        call("cn_dcn_col2im", dcol, x, om, dx32, dom32, N, H, W, Ci, Ci, om.shape[-1], dt)
+        call("cn_dcn_col2im", dcol, x, om, dx_tile, dx_far, dom32, N, H, W, Ci, Ci, om.shape[-1], dt)
         del dcol
+        dx_s = torch.empty_like(x)
+        call("cn_add_f32_to", dx_tile, dx_far, dx_s, dx_tile.numel(), dt)
+        del dx_tile, dx_far
         if x.dtype == torch.float32:
             dom = dom32
         else:
             dom = torch.empty(om.shape, dtype=x.dtype, device=x.device)
             call("cn_cast", dom32, 0, dom, dt, dom32.numel())
-        if x.dtype == torch.float32:
-            dx_s = dx32
-        else:
-            dx_s = torch.empty_like(x)
-            call("cn_cast", dx32, 0, dx_s, dt, dx32.numel())
         # offset/mask conv backward (its data gradient is added to the sampling gradient through `residual`)
         dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)
         dw_om = unpack_wgrad(dwp_om, 27, Ci, 3, 3)

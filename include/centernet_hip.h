@@ -66,8 +66,9 @@ int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, i
 int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                   int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
                   int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype, void* stream);
-/* which tile instantiation cn_conv2d_fwd dispatches to: returns BN*1000 + BK (kernel `conv_igemm_kernel<T,BN,BK>`) */
-int cn_conv2d_variant(int Ci, int Co, int dtype);
+/* which kernel cn_conv2d_fwd dispatches to: BN*1000 + BK = `conv_igemm_kernel<T,BN,BK>`;
+ * 3000000 + BN*1000 + CK = the 3x3/s1/p1 halo-tile kernel `conv3x3s1_kernel<T,BN,CK>` */
+int cn_conv2d_variant(int Ci, int Co, int KH, int KW, int stride, int pad, int dtype);
 /* Weight gradient: dwp[co][t*Ci+ci] += sum_{n,oh,ow} dy[n,oh,ow,co] * x[n, oh*stride-pad+kh, ow*stride-pad+kw, ci]
  * dwp is fp32 [Co_pad32][KH*KW*Ci] and must be zeroed by the caller (split-K uses atomics).  db (nullable,
  * fp32[Co], zeroed) accumulates the bias gradient. */
@@ -120,10 +121,14 @@ int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp
  * col[p][k*Ci + c] = sigmoid(om[p][18+k]) * bilinear(x[n,:,:,c], h-1+i+dy, w-1+j+dx), k = 3i+j. */
 int cn_dcn_im2col(const void* x, const float* om, void* col, int N, int H, int W, int Ci, int x_ld, int om_ld,
                   int dtype, void* stream);
-/* Given dcol (gradient of col), accumulate dx (fp32 [P][Ci], zeroed by caller, atomics) and write dom fp32 [P][om_ld]
- * (zeroed by the caller: only channels 0..26 are written). */
-int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_f32, float* dom,
+/* Given dcol (gradient of col): dx = dx_tile + dx_far, both fp32 [P][Ci].  dx_tile is fully overwritten by an atomic-free
+ * gather (every destination pixel sums the samples within 3 pixels whose bilinear weight reaches it); dx_far (zeroed by
+ * the caller) only receives samples displaced by more than 3 pixels, through global atomics.  dom fp32 [P][om_ld]:
+ * channels 0..26 are overwritten. */
+int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_tile, float* dx_far, float* dom,
                   int N, int H, int W, int Ci, int x_ld, int om_ld, int dtype, void* stream);
+/* out[i] = a[i] + b[i] for fp32 a, b -> out in `dtype` (combines dx_tile + dx_far into the activation dtype) */
+int cn_add_f32_to(const float* a, const float* b, void* out, int64_t n, int dtype, void* stream);
 
 /* ---- losses (utils/losses.py) ---------------------------------------------------------------- */
 /* in-place sigmoid on x, y = clamp(x, lo, 1-lo)  (utils/decode.py:43-45) */
@@ -171,9 +176,10 @@ int cn_multi_pose_decode(const float* heat, const float* wh, const float* kps, c
                          int B, int J, int H, int W, int K, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- optimiser (torch.optim.Adam defaults, centernet.py:94-95) -------------------------------- */
-/* flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t are computed by the host */
+/* flat fp32 buffers; bias corrections bc1 = 1-b1^t, bc2 = 1-b2^t are computed by the host.  hyper (nullable, device
+ * fp32[3] = {lr, bc1, bc2}) overrides the scalar arguments so that a captured hipGraph sees fresh values per replay. */
 int cn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
-                 float eps, float bc1, float bc2, float grad_scale, void* stream);
+                 float eps, float bc1, float bc2, float grad_scale, const float* hyper, void* stream);
 
 #ifdef __cplusplus
 }

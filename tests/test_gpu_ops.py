@@ -199,18 +199,20 @@ def test_depthwise_up(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 12, 12, 64, 64), (1, 9, 7, 128, 64), (1, 6, 6, 512, 256), (2, 16, 16, 32, 16)])
+@pytest.mark.parametrize("cfg", [(2, 12, 12, 64, 64), (1, 9, 7, 128, 64), (1, 6, 6, 512, 256), (2, 16, 16, 32, 16),
+                                 (1, 40, 36, 64, 64, 6.0), (2, 19, 33, 128, 128, 4.0), (1, 20, 20, 256, 64)])
 def test_dcnv2(cfg, dt):
     """vs oracle/dcn_ref.py (pure torch); offsets are O(1) so every bilinear corner / border case is exercised."""
     from centernet_amd import nn as hnn
     from oracle.dcn_ref import DCN as RefDCN
-    N, H, W, Ci, Co = cfg
+    N, H, W, Ci, Co = cfg[:5]
+    off_scale = cfg[5] if len(cfg) > 5 else 0.3     # > 3 px displacements exercise the far (global-atomic) path of col2im
     ref = RefDCN(Ci, Co)
     with torch.no_grad():
         ref.weight.copy_(rnd(rng.t_normal(7, f"w{cfg}", (Co, Ci, 3, 3), 0, (2.0 / (Ci * 9)) ** 0.5), dt))
         ref.bias.copy_(rng.t_normal(7, "b", (Co,), 0, 0.1))
         ref.conv_offset_mask.weight.copy_(rnd(rng.t_normal(7, f"ow{cfg}", (27, Ci, 3, 3), 0, 0.6 / (Ci * 9) ** 0.5), dt))
-        ref.conv_offset_mask.bias.copy_(rng.t_normal(7, "ob", (27,), 0, 0.3))
+        ref.conv_offset_mask.bias.copy_(rng.t_normal(7, "ob", (27,), 0, off_scale))
     mod = hnn.DCN(Ci, Co).to(DEV)
     mod.load_state_dict(ref.state_dict())
     x = rng.t_normal(7, f"x{cfg}", (N, Ci, H, W))
