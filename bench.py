@@ -27,15 +27,23 @@ PEAK_F32_TFLOPS = 157.3
 class ConvProbe:
     """HIP-event timing of every cn_conv2d_fwd launch (the conv_igemm_kernel family), grouped by tile variant."""
 
-    def __init__(self, hip):
+    def __init__(self, hip, all_ops=False):
         self.hip, self.records, self.orig = hip, [], hip.call
+        self.all_ops = [] if all_ops else None
 
     def __enter__(self):
         hip = self.hip
 
         def call(name, *args):
             if name != "cn_conv2d_fwd":
-                return self.orig(name, *args)
+                if self.all_ops is None:
+                    return self.orig(name, *args)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = self.orig(name, *args)
+                e1.record()
+                self.all_ops.append((name, tuple(a for a in args if isinstance(a, (int, float)) and not isinstance(a, bool)), e0, e1))
+                return r
             (x, wp, bias, res, y, N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed, relu, dt, odt) = args
             if transposed and stride > 1:   # only the taps of the output pixel's parity class are visited
                 macs = N * H * W * KH * KW * Ci * Co          # every (input pixel, tap) pair contributes once
@@ -45,7 +53,8 @@ class ConvProbe:
             e0.record()
             self.orig(name, *args)
             e1.record()
-            self.records.append((hip.lib().cn_conv2d_variant(Ci, Co, KH, KW, stride, pad, dt), 2.0 * macs, e0, e1))
+            self.records.append((hip.lib().cn_conv2d_variant(Ci, Co, KH, KW, stride, pad, dt), 2.0 * macs, e0, e1,
+                                 (N, H, W, Ci, OH, OW, Co, KH, stride, int(transposed))))
         hip.call = call
         import centernet_amd.ops as ops
         import centernet_amd.nn as hnn
@@ -58,9 +67,35 @@ class ConvProbe:
         for m, f in self._mods:
             m.call = f
 
+    def detail(self, path, steps):
+        by = {}
+        for var, flops, e0, e1, shape in self.records:
+            d = by.setdefault((var,) + shape, [0.0, 0.0, 0])
+            d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        with open(path, "w") as f:
+            f.write("variant N H W Ci OH OW Co K stride transposed | calls/step ms/step us/call TFLOP/s GB/s(in+out bf16)\n")
+            for k, (fl, t, n) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                N, H, W, Ci, OH, OW, Co = k[1:8]
+                byts = 2.0 * N * (H * W * Ci + OH * OW * Co) * n
+                f.write(f"{k} | {n / steps:.0f} {t / steps * 1e3:.3f} {t / n * 1e6:.1f} {fl / t / 1e12:.1f} {byts / t / 1e9:.0f}\n")
+
+    def detail_all(self, path, steps):
+        by = {}
+        for name, sig, e0, e1 in self.all_ops:
+            d = by.setdefault((name,) + sig, [0.0, 0])
+            d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += 1
+        tot = {}
+        with open(path, "w") as f:
+            for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0]):
+                f.write(f"{t / steps * 1e3:9.3f} ms/step {n / steps:5.0f} calls {t / n * 1e6:9.1f} us  {k}\n")
+                tot[k[0]] = tot.get(k[0], 0.0) + t
+            f.write("---- per entry point ----\n")
+            for k, t in sorted(tot.items(), key=lambda kv: -kv[1]):
+                f.write(f"{t / steps * 1e3:9.3f} ms/step  {k}\n")
+
     def summary(self):
         by = {}
-        for var, flops, e0, e1 in self.records:
+        for var, flops, e0, e1, _ in self.records:
             t = e0.elapsed_time(e1) * 1e-3
             d = by.setdefault(var, [0.0, 0.0, 0])
             d[0] += flops; d[1] += t; d[2] += 1
@@ -110,6 +145,7 @@ def main():
     ap.add_argument("--no-probe", action="store_true", help="skip the per-launch HIP-event pass that feeds `roofline`")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + backward-overlapped RCCL buckets instead of hipGraph replay")
     ap.add_argument("--probe-steps", type=int, default=2)
+    ap.add_argument("--probe-detail", default=None, help="write a per-shape table of the implicit-GEMM launches to this file")
     args = ap.parse_args()
 
     from centernet_amd import _hip, synth
@@ -170,11 +206,14 @@ def main():
     probe = None
     if rank == 0 and world == 1 and not args.no_probe:
         # same step, launched eagerly, with a HIP event pair around every implicit-GEMM launch on the launch stream
-        probe = ConvProbe(_hip)
+        probe = ConvProbe(_hip, all_ops=bool(args.probe_detail))
         with probe:
             for _ in range(args.probe_steps):
                 step._eager(batch)
             torch.cuda.synchronize()
+        if args.probe_detail:
+            probe.detail(args.probe_detail, args.probe_steps)
+            probe.detail_all(args.probe_detail + ".ops", args.probe_steps)
 
     if rank == 0:
         total_images = args.batch * world * args.steps

@@ -2,10 +2,11 @@
 //
 // The contraction runs over PIXELS, which is the slow axis of both NHWC operands, so MFMA
 // fragments (k-contiguous per lane) need a transpose on the way in:
-//   * bf16: each thread loads 16 B (8 channels of one pixel) and scatters them as 8 ds_write_b16
-//     into a channel-major LDS image [channel][32 pixels]; the four 8-pixel chunks of a row are
-//     XOR-swizzled with (channel>>3)&3 so both the scattered writes and the ds_read_b128 fragment
-//     reads spread over the banks.  MFMA: v_mfma_f32_32x32x16_bf16.
+//   * bf16: tiles are staged in their natural [pixel][channel] order with plain 16-byte LDS stores and the
+//     fragments are fetched with gfx950's transposing LDS read ds_read_b64_tr_b16 (a 16-lane group reads a
+//     4-pixel x 16-channel block and each lane receives the 4 pixels of ITS channel; semantics probed in
+//     tools/probe/tr_read.hip).  Rows are padded by 64 B so the four pixel rows of a read hit disjoint banks.
+//     MFMA: v_mfma_f32_32x32x16_bf16.
 //   * fp32 (parity mode): v_mfma_f32_32x32x2_f32 takes ONE f32 per lane, so the natural
 //     [pixel][channel] image is already conflict-free — no transpose.
 // Split-K over pixel chunks (blockIdx.x) with fp32 atomics into the (pre-zeroed) packed gradient;
@@ -14,6 +15,26 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+// 32(channel) x 16(pixel) bf16 MFMA operand out of a [pixel][channel] LDS tile (pitch in elements).
+// lane l: channel r0 + (l&31), pixels k0 + 8*(l>>5) .. +7.
+__device__ static inline bf16x8_t tr_frag(const bf16_t* tile, int pitch, int r0, int k0, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    const bf16_t* p = tile + (k0 + 8 * (g >> 1) + (r >> 2)) * pitch + r0 + 16 * (g & 1) + 4 * (r & 3);
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * pitch));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
+                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st);   // stem.hip
+
+bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
+                       hipStream_t st);                                                                 // conv_wgrad3x3.hip
 
 struct WgradGeom {
     const void* x;
@@ -41,8 +62,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     constexpr int KSTEPS = BF ? 2 : 8;
     static_assert(YV >= 1 && XV >= 1, "tile too small");
 
-    __shared__ __attribute__((aligned(16))) T lds[2 * (BMW + BNW) * BKP];
-    constexpr int BUF = (BMW + BNW) * BKP;  // elements per pipeline stage: [dY tile | X tile]
+    constexpr int PADE = BF ? 32 : 0;               // bf16 rows padded by 64 B (bank spread for the transposing reads)
+    constexpr int YP = BMW + PADE, XP = BNW + PADE; // row pitches in elements
+    constexpr int BUF = (YP + XP) * BKP;            // elements per pipeline stage: [dY tile | X tile]
+    __shared__ __attribute__((aligned(16))) T lds[2 * BUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tap = blockIdx.z;
@@ -108,31 +131,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     };
     auto lstore = [&](int buf) {
         if constexpr (BF) {
-            unsigned short* ys = reinterpret_cast<unsigned short*>((lds + buf * BUF));
-            unsigned short* xs = reinterpret_cast<unsigned short*>((lds + buf * BUF + BMW * BKP));
+            bf16_t* ys = reinterpret_cast<bf16_t*>(lds + buf * BUF);
+            bf16_t* xs = reinterpret_cast<bf16_t*>(lds + buf * BUF + YP * BKP);
 #pragma unroll
-            for (int v = 0; v < YV; ++v) {
-                const uint32_t w[4] = {ry[v].x, ry[v].y, ry[v].z, ry[v].w};
-                const int col = (((y_px[v] >> 3) ^ (y_cg[v] & 3)) << 3) + (y_px[v] & 7);
+            for (int v = 0; v < YV; ++v) *reinterpret_cast<uint4*>(ys + y_px[v] * YP + y_cg[v] * 8) = ry[v];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    ys[(y_cg[v] * 8 + j) * BKP + col] = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
-            }
-#pragma unroll
-            for (int v = 0; v < XV; ++v) {
-                const uint32_t w[4] = {rx[v].x, rx[v].y, rx[v].z, rx[v].w};
-                const int col = (((x_px[v] >> 3) ^ (x_cg[v] & 3)) << 3) + (x_px[v] & 7);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    xs[(x_cg[v] * 8 + j) * BKP + col] = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
-            }
+            for (int v = 0; v < XV; ++v) *reinterpret_cast<uint4*>(xs + x_px[v] * XP + x_cg[v] * 8) = rx[v];
         } else {
 #pragma unroll
             for (int v = 0; v < YV; ++v)
                 *reinterpret_cast<uint4*>(reinterpret_cast<float*>((lds + buf * BUF)) + y_px[v] * BMW + y_cg[v] * 4) = ry[v];
 #pragma unroll
             for (int v = 0; v < XV; ++v)
-                *reinterpret_cast<uint4*>(reinterpret_cast<float*>((lds + buf * BUF + BMW * BKP)) + x_px[v] * BNW + x_cg[v] * 4) = rx[v];
+                *reinterpret_cast<uint4*>(reinterpret_cast<float*>((lds + buf * BUF + YP * BKP)) + x_px[v] * BNW + x_cg[v] * 4) = rx[v];
         }
     };
 
@@ -154,22 +165,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
         const bool more = tile + 1 < ntiles;
         if (more) gload(tile + 1);
         if constexpr (BF) {
-            const bf16_t* yt = reinterpret_cast<const bf16_t*>((lds + cur * BUF));
-            const bf16_t* xt = reinterpret_cast<const bf16_t*>((lds + cur * BUF + BMW * BKP));
+            const bf16_t* yt = reinterpret_cast<const bf16_t*>(lds + cur * BUF);
+            const bf16_t* xt = reinterpret_cast<const bf16_t*>(lds + cur * BUF + YP * BKP);
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 bf16x8_t fa[MI], fb[NJ];
-                const int chunk = kk * 2 + (lane >> 5);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    int row = wm + i * 32 + (lane & 31);
-                    fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(yt + row * BKP + ((chunk ^ ((row >> 3) & 3)) << 3)));
-                }
+                for (int i = 0; i < MI; ++i) fa[i] = tr_frag(yt, YP, wm + i * 32, kk * 16, lane);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    int row = wn + j * 32 + (lane & 31);
-                    fb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xt + row * BKP + ((chunk ^ ((row >> 3) & 3)) << 3)));
-                }
+                for (int j = 0; j < NJ; ++j) fb[j] = tr_frag(xt, XP, wn + j * 32, kk * 16, lane);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
             }
         } else {
             const float* yt = reinterpret_cast<const float*>((lds + cur * BUF));
-            const float* xt = reinterpret_cast<const float*>((lds + cur * BUF + BMW * BKP));
+            const float* xt = reinterpret_cast<const float*>(lds + cur * BUF + YP * BKP);
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 float fa[MI], fb[NJ];
@@ -280,13 +284,24 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float*
     g.KW = KW; g.stride = stride; g.pad = pad; g.ktot = KH * KW * Ci; g.co_pad = (Co + 31) / 32 * 32;
     g.P = (int64_t)N * OH * OW;
     hipStream_t st = (hipStream_t)stream;
+    bool done_small = false;
+    if (Ci <= 16 && small_wgrad_packed(x, dy, dwp, N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, st)) {
+        CN_LAUNCH_CHECK("cn_conv2d_wgrad(small)");
+        done_small = true;
+    }
+    if (!done_small && dtype == CN_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W &&
+        wgrad3x3s1_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, st)) {
+        CN_LAUNCH_CHECK("cn_conv2d_wgrad(3x3)");
+        done_small = true;
+    }
     const bool bigm = Co > 64, bign = Ci > 64;
 #define CN_WG(T) \
     do { if (bigm && bign) launch_wgrad<T, 128, 128>(g, KH * KW, st); \
          else if (bigm) launch_wgrad<T, 128, 64>(g, KH * KW, st); \
          else if (bign) launch_wgrad<T, 64, 128>(g, KH * KW, st); \
          else launch_wgrad<T, 64, 64>(g, KH * KW, st); } while (0)
-    if (dtype == CN_F32) CN_WG(float);
+    if (done_small) { /* handled by the small-channel VALU kernel */ }
+    else if (dtype == CN_F32) CN_WG(float);
     else if (dtype == CN_BF16) CN_WG(bf16_t);
     else CN_CHECK_ARG(false, "cn_conv2d_wgrad: bad dtype %d", dtype);
 #undef CN_WG

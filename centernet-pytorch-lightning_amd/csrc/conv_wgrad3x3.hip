@@ -1,0 +1,191 @@
+// Weight gradient of 3x3 / stride 1 / pad 1 convolutions (bf16), halo-tile form:
+//   dWp[co][tap*Ci + ci] += sum_{pixels p of a tile} dY[p][co] * X[p + shift(tap)][ci]
+// The generic split-K kernel walks 32-pixel K slices (4 MFMAs per wave per barrier) and re-reads X once per tap, which
+// left it bound by L2->LDS latency (~250 TFLOP/s).  Here a workgroup takes an 8x16 pixel tile: the dY tile [128][BMW]
+// and the X HALO tile [(8+2)x(16+2)][BNW] are staged ONCE in their natural [pixel][channel] order, and every tap of the
+// tap group reads its shifted X rows straight out of the halo with the transposing LDS read (ds_read_b64_tr_b16) —
+// 9x (or 3x) more MFMA work per byte staged.  The next tile is prefetched into registers while the current one is
+// being multiplied; workgroups walk several tiles and flush their fp32 accumulators with one round of atomics.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#define W3_TH 8
+#define W3_TW 16
+#define W3_HW (W3_TW + 2)
+#define W3_HP ((W3_TH + 2) * W3_HW)
+
+struct Wgrad3Geom {
+    const bf16_t* x;
+    const bf16_t* dy;
+    float* dwp;
+    int N, H, W, Ci, x_ld, Co, dy_ld, ktot;
+    int tiles_h, tiles_w, ci_tiles;
+    int tiles_per_block;
+};
+
+// 32(channel) x 16(pixel) operand from a [row][channel] LDS tile; the 16 pixels are rows row0 .. row0+15.
+__device__ static inline bf16x8_t tr_frag16(const bf16_t* tile, int pitch, int c0, int row0, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    const bf16_t* p = tile + (row0 + 8 * (g >> 1) + (r >> 2)) * pitch + c0 + 16 * (g & 1) + 4 * (r & 3);
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * pitch));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// TAPS = 9: one workgroup accumulates all taps;  TAPS = 3: blockIdx.z selects the tap row kh.
+template <int BMW, int BNW, int TAPS>
+__global__ __launch_bounds__(256) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
+    constexpr int YP = BMW + 32, XP = BNW + 32;               // +64 B: the 4 rows of a transposing read hit disjoint banks
+    constexpr int YCG = BMW / 8, XCG = BNW / 8;
+    constexpr int YV = (W3_TH * W3_TW * YCG + 255) / 256;     // 16-byte loads per thread
+    constexpr int XV = (W3_HP * XCG + 255) / 256;
+    constexpr int WM = BMW / 2, WN = BNW / 2;                 // 2 x 2 waves
+    constexpr int MI = WM / 32, NJ = WN / 32;
+    constexpr int HROWS = TAPS == 9 ? W3_TH + 2 : W3_TH;      // halo rows staged
+
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [128][YP] dY tile | [HROWS*18][XP] X halo
+    bf16_t* const yt = lds;
+    bf16_t* const xt = lds + W3_TH * W3_TW * YP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = (blockIdx.y / g.ci_tiles) * BMW, ci0 = (blockIdx.y % g.ci_tiles) * BNW;
+    const int kh0 = TAPS == 9 ? 0 : (int)blockIdx.z;          // first tap row handled here
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int64_t t_beg = (int64_t)blockIdx.x * g.tiles_per_block;
+    const int64_t t_end = t_beg + g.tiles_per_block < ntiles ? t_beg + g.tiles_per_block : ntiles;
+    if (t_beg >= ntiles) return;
+
+    f32x16_t acc[TAPS][MI][NJ];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+    uint4 ry[YV], rx[XV];
+    auto gload = [&](int64_t tile) {
+        const int n = (int)(tile / (g.tiles_h * g.tiles_w));
+        const int r = (int)(tile - (int64_t)n * g.tiles_h * g.tiles_w);
+        const int th0 = (r / g.tiles_w) * W3_TH, tw0 = (r % g.tiles_w) * W3_TW;
+        const int64_t img = (int64_t)n * g.H * g.W;
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            const int idx = tid + v * 256;
+            const int px = idx / YCG, c = co0 + (idx % YCG) * 8;
+            const int oh = th0 + px / W3_TW, ow = tw0 + px % W3_TW;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (idx < W3_TH * W3_TW * YCG && oh < g.H && ow < g.W && c < g.Co)
+                val = *reinterpret_cast<const uint4*>(g.dy + (img + (int64_t)oh * g.W + ow) * g.dy_ld + c);
+            ry[v] = val;
+        }
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            const int idx = tid + v * 256;
+            const int hp = idx / XCG, c = ci0 + (idx % XCG) * 8;
+            const int hr = hp / W3_HW;                         // staged halo row: image row th0 - 1 + kh0 + hr
+            const int ih = th0 - 1 + kh0 + hr, iw = tw0 - 1 + hp % W3_HW;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (idx < HROWS * W3_HW * XCG && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W && c < g.Ci)
+                val = *reinterpret_cast<const uint4*>(g.x + (img + (int64_t)ih * g.W + iw) * g.x_ld + c);
+            rx[v] = val;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            const int idx = tid + v * 256;
+            if (idx < W3_TH * W3_TW * YCG) *reinterpret_cast<uint4*>(yt + (idx / YCG) * YP + (idx % YCG) * 8) = ry[v];
+        }
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            const int idx = tid + v * 256;
+            if (idx < HROWS * W3_HW * XCG) *reinterpret_cast<uint4*>(xt + (idx / XCG) * XP + (idx % XCG) * 8) = rx[v];
+        }
+    };
+
+    gload(t_beg);
+    for (int64_t tile = t_beg; tile < t_end; ++tile) {
+        __syncthreads();                      // every wave is done reading the previous tile
+        lstore();
+        __syncthreads();
+        if (tile + 1 < t_end) gload(tile + 1);   // in flight while this tile is multiplied
+#pragma unroll
+        for (int kk = 0; kk < W3_TH; ++kk) {  // one k16 step = one 16-pixel tile row
+            bf16x8_t fa[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = tr_frag16(yt, YP, wm + i * 32, kk * W3_TW, lane);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int kh = t / 3, kw = t % 3;             // TAPS == 3: kh is relative to kh0 (the halo starts at that row)
+                bf16x8_t fb[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = tr_frag16(xt, XP, wn + j * 32, (kk + kh) * W3_HW + kw, lane);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // D rows = co: (r&3) + 8*(r>>2) + 4*(lane>>5); D col = ci: lane&31
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        const int tap = TAPS == 9 ? t : kh0 * 3 + t;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int ci = ci0 + wn + j * 32 + (lane & 31);
+                if (ci >= g.Ci) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < g.Co) atomicAdd(g.dwp + (int64_t)co * g.ktot + (int64_t)tap * g.Ci + ci, acc[t][i][j][r]);
+                }
+            }
+    }
+}
+
+template <int BMW, int BNW, int TAPS>
+static void launch_w3(Wgrad3Geom& g, hipStream_t st) {
+    const int co_tiles = cdiv(g.Co, BMW);
+    g.ci_tiles = cdiv(g.Ci, BNW);
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
+    int64_t want = (1536 + par - 1) / par;                 // ~6 workgroups per CU over the whole launch
+    if (want > ntiles) want = ntiles;
+    if (want < 1) want = 1;
+    g.tiles_per_block = (int)((ntiles + want - 1) / want);
+    const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    const int hrows = TAPS == 9 ? W3_TH + 2 : W3_TH;
+    const size_t smem = ((size_t)W3_TH * W3_TW * (BMW + 32) + (size_t)hrows * W3_HW * (BNW + 32)) * sizeof(bf16_t);
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)wgrad3x3s1_kernel<BMW, BNW, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((wgrad3x3s1_kernel<BMW, BNW, TAPS>), dim3(gx, co_tiles * g.ci_tiles, TAPS == 9 ? 1 : 3), dim3(256), smem, st, g);
+}
+
+// bf16, 3x3 / stride 1 / pad 1, Ci > 16.  Returns false if the shape is not handled here.
+bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
+                       hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_WGRAD3X3") != nullptr;
+    if (disabled || Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) return false;
+    Wgrad3Geom g;
+    g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.dwp = dwp;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.ktot = 9 * Ci;
+    g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
+    if (Co > 64) launch_w3<128, 64, 3>(g, st);      // 68.6 KB LDS, 96 accumulator registers
+    else launch_w3<64, 64, 9>(g, st);               // 59 KB LDS, 144 accumulator registers
+    return true;
+}

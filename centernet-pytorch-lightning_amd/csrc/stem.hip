@@ -69,38 +69,34 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
     }
 }
 
-// dW[co][ci][kh][kw] += sum_pix dy[pix][co] * x[ci][oh*s-p+kh][ow*s-p+kw]; every workgroup walks many pixel tiles,
-// keeps its (tap, co) partial sums in registers and flushes them with one round of atomics.
-#define ST_WG_ACC 10   // ceil(3*7*7*16 / 256)
-template <typename T>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
-                                                         float* __restrict__ dw, int N, int Ci, int H, int W, int Co,
-                                                         int KH, int KW, int stride, int pad, int OH, int OW,
-                                                         int tiles_h, int tiles_w) {
-    extern __shared__ float smem[];
+// Weight gradient for layers with <= 16 input channels (7x7 stem on the NCHW fp32 image; DLA level0/level1 3x3 convs on
+// 16-channel NHWC maps).  K = pixels is huge (16.7 M at 512x512, batch 64) while M x N = Co x (Ci*taps) is tiny, and a
+// 16-channel operand wastes 3/4 of a 64x64 MFMA tile plus its LDS transposes — so this is a VALU kernel that is
+// FMA-issue bound: thread = one (ci, kh, kw) position x 16 output channels held in registers; per pixel it does ONE
+// LDS read of the image tile and four wave-broadcast ds_read_b128 of the dy row for 16 FMAs.  Workgroups walk many
+// pixel tiles and flush with one round of atomics.
+#define SW_THREADS 320
+template <typename T, bool X_NCHW>
+__global__ __launch_bounds__(SW_THREADS) void small_wgrad_kernel(const void* __restrict__ xv, const T* __restrict__ dy,
+                                                                 float* __restrict__ dw, int N, int Ci, int x_ld, int H,
+                                                                 int W, int Co, int dy_ld, int KH, int KW, int stride,
+                                                                 int pad, int OH, int OW, int tiles_h, int tiles_w,
+                                                                 int os_co, int os_ci, int os_tap) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int IH = (ST_TH - 1) * stride + KH, IW = (ST_TW - 1) * stride + KW;
-    float* xt = smem;                          // [Ci][IH][IW]
-    float* dt = smem + Ci * IH * IW;           // [256 pixels][ST_COB]
+    float* dt = smem;                                   // [256 pixels][16 co]   (16-byte aligned rows)
+    float* xt = smem + ST_TH * ST_TW * ST_COB;          // [Ci][IH][IW]
     const int tid = threadIdx.x;
     const int co0 = blockIdx.y * ST_COB;
-    const int ntap = Ci * KH * KW;
-    const int nout = ntap * ST_COB;
-    float acc[ST_WG_ACC];
-    int o_xoff[ST_WG_ACC], o_co[ST_WG_ACC];
+    const int NT = Ci * KH * KW;
+    const int u = tid % NT, half = tid / NT;            // half 0: tile rows 0..3, half 1: rows 4..7
+    const bool active = tid < 2 * NT;
+    const int ci = u / (KH * KW), r0 = u - ci * KH * KW;
+    const int kh = r0 / KW, kw = r0 - kh * KW;
+    const int xoff = (ci * IH + kh + half * (ST_TH / 2) * stride) * IW + kw;
+    float acc[ST_COB];
 #pragma unroll
-    for (int i = 0; i < ST_WG_ACC; ++i) {
-        acc[i] = 0.f;
-        int o = tid + i * 256;
-        int t = o / ST_COB;
-        o_co[i] = o % ST_COB;
-        if (o < nout) {
-            int ci = t / (KH * KW), r = t - ci * KH * KW;
-            int kh = r / KW, kw = r - kh * KW;
-            o_xoff[i] = (ci * IH + kh) * IW + kw;
-        } else {
-            o_xoff[i] = -1;
-        }
-    }
+    for (int c = 0; c < ST_COB; ++c) acc[c] = 0.f;
     const int64_t ntiles = (int64_t)N * tiles_h * tiles_w;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = (int)(tile / (tiles_h * tiles_w));
@@ -108,42 +104,87 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
         const int th0 = (r / tiles_w) * ST_TH, tw0 = (r % tiles_w) * ST_TW;
         const int ih0 = th0 * stride - pad, iw0 = tw0 * stride - pad;
         __syncthreads();
-        for (int i = tid; i < Ci * IH * IW; i += 256) {
-            int c = i / (IH * IW), rr = i - c * IH * IW;
-            int hh = rr / IW, ww = rr - hh * IW;
-            int ih = ih0 + hh, iw = iw0 + ww;
+        for (int i = tid; i < Ci * IH * IW; i += SW_THREADS) {
             float v = 0.f;
-            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[(((int64_t)n * Ci + c) * H + ih) * W + iw];
-            xt[i] = v;
+            if (X_NCHW) {
+                const int c = i / (IH * IW), rr = i - c * IH * IW;
+                const int ih = ih0 + rr / IW, iw = iw0 + rr % IW;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                    v = reinterpret_cast<const float*>(xv)[(((int64_t)n * Ci + c) * H + ih) * W + iw];
+                xt[i] = v;
+            } else {                                     // NHWC: consecutive threads -> consecutive channels of one pixel
+                const int c = i % Ci, pp = i / Ci;
+                const int ih = ih0 + pp / IW, iw = iw0 + pp % IW;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                    v = Elem<T>::ld(reinterpret_cast<const T*>(xv) + (((int64_t)n * H + ih) * W + iw) * x_ld + c);
+                xt[(c * IH + pp / IW) * IW + pp % IW] = v;
+            }
         }
-        {
-            const int ty = tid / ST_TW, tx = tid % ST_TW;
-            const int oh = th0 + ty, ow = tw0 + tx;
-            const bool ok = oh < OH && ow < OW;
-            const T* src = dy + (((int64_t)n * OH + oh) * OW + ow) * Co + co0;
-            for (int c = 0; c < ST_COB; ++c) dt[tid * ST_COB + c] = (ok && co0 + c < Co) ? Elem<T>::ld(src + c) : 0.f;
+        for (int i = tid; i < ST_TH * ST_TW * ST_COB; i += SW_THREADS) {
+            const int px = i / ST_COB, c = i - px * ST_COB;
+            const int oh = th0 + px / ST_TW, ow = tw0 + px % ST_TW;
+            float v = 0.f;
+            if (oh < OH && ow < OW && co0 + c < Co) v = Elem<T>::ld(dy + (((int64_t)n * OH + oh) * OW + ow) * dy_ld + co0 + c);
+            dt[i] = v;
         }
         __syncthreads();
+        if (active) {
+            for (int py = 0; py < ST_TH / 2; ++py) {
+                const float* xr = xt + xoff + py * stride * IW;
+                const float4* dr = reinterpret_cast<const float4*>(dt + ((half * (ST_TH / 2) + py) * ST_TW) * ST_COB);
+#pragma unroll 4
+                for (int px = 0; px < ST_TW; ++px) {
+                    const float x = xr[px * stride];
 #pragma unroll
-        for (int i = 0; i < ST_WG_ACC; ++i) {
-            if (o_xoff[i] < 0) continue;
-            const float* xb = xt + o_xoff[i];
-            const float* db = dt + o_co[i];
-            float s = 0.f;
-            for (int py = 0; py < ST_TH; ++py) {
-                const float* xr = xb + py * stride * IW;
-                const float* dr = db + py * ST_TW * ST_COB;
-#pragma unroll 8
-                for (int px = 0; px < ST_TW; ++px) s = fmaf(dr[px * ST_COB], xr[px * stride], s);
+                    for (int q = 0; q < ST_COB / 4; ++q) {
+                        const float4 d = dr[px * (ST_COB / 4) + q];
+                        acc[4 * q + 0] = fmaf(d.x, x, acc[4 * q + 0]);
+                        acc[4 * q + 1] = fmaf(d.y, x, acc[4 * q + 1]);
+                        acc[4 * q + 2] = fmaf(d.z, x, acc[4 * q + 2]);
+                        acc[4 * q + 3] = fmaf(d.w, x, acc[4 * q + 3]);
+                    }
+                }
             }
-            acc[i] += s;
         }
     }
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < ST_WG_ACC; ++i) {
-        int o = tid + i * 256;
-        if (o_xoff[i] >= 0 && co0 + o_co[i] < Co) atomicAdd(dw + (int64_t)(co0 + o_co[i]) * ntap + o / ST_COB, acc[i]);
+        for (int c = 0; c < ST_COB; ++c)
+            if (co0 + c < Co) atomicAdd(dw + (int64_t)(co0 + c) * os_co + (int64_t)ci * os_ci + (int64_t)(kh * KW + kw) * os_tap, acc[c]);
     }
+}
+
+// shared launcher: returns false when the shape does not fit the small-channel kernel
+template <typename T>
+static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* dw, int N, int Ci, int x_ld, int H, int W, int Co,
+                               int dy_ld, int KH, int KW, int stride, int pad, int OH, int OW, int os_co, int os_ci, int os_tap,
+                               hipStream_t st) {
+    if (Ci * KH * KW * 2 > SW_THREADS || (stride != 1 && stride != 2) || KH > ST_MAXK || KW > ST_MAXK) return false;
+    const int tiles_h = cdiv(OH, ST_TH), tiles_w = cdiv(OW, ST_TW);
+    const int IH = (ST_TH - 1) * stride + KH, IW = (ST_TW - 1) * stride + KW;
+    const size_t smem = (size_t)(ST_TH * ST_TW * ST_COB + Ci * IH * IW) * sizeof(float);
+    if (smem > 64 * 1024) return false;
+    const int64_t ntiles = (int64_t)N * tiles_h * tiles_w;
+    const int gx = (int)(ntiles < 1024 ? ntiles : 1024);
+    dim3 grid(gx, cdiv(Co, ST_COB));
+    if (x_nchw)
+        hipLaunchKernelGGL((small_wgrad_kernel<T, true>), grid, dim3(SW_THREADS), smem, st, x, dy, dw, N, Ci, x_ld, H, W, Co, dy_ld,
+                           KH, KW, stride, pad, OH, OW, tiles_h, tiles_w, os_co, os_ci, os_tap);
+    else
+        hipLaunchKernelGGL((small_wgrad_kernel<T, false>), grid, dim3(SW_THREADS), smem, st, x, dy, dw, N, Ci, x_ld, H, W, Co, dy_ld,
+                           KH, KW, stride, pad, OH, OW, tiles_h, tiles_w, os_co, os_ci, os_tap);
+    return true;
+}
+
+// used by cn_conv2d_wgrad for Ci <= 16 (packed output layout dwp[co][tap*Ci + ci])
+bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
+                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st) {
+    if (Ci > 16) return false;
+    if (dtype == CN_F32)
+        return launch_small_wgrad<float>(x, false, (const float*)dy, dwp, N, Ci, x_ld, H, W, Co, dy_ld, KH, KW, stride, pad, OH, OW,
+                                         KH * KW * Ci, 1, Ci, st);
+    return launch_small_wgrad<bf16_t>(x, false, (const bf16_t*)dy, dwp, N, Ci, x_ld, H, W, Co, dy_ld, KH, KW, stride, pad, OH, OW,
+                                      KH * KW * Ci, 1, Ci, st);
 }
 
 static int stem_check(int Ci, int KH, int KW, int stride) {
@@ -175,16 +216,16 @@ extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int
     CN_CHECK_ARG(x && dy && dw && N > 0 && Co > 0, "cn_stem_conv_wgrad: bad args");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
-    if (Ci * KH * KW * ST_COB > ST_WG_ACC * 256) CN_UNSUPPORTED("cn_stem_conv_wgrad: too many taps");
-    int tiles_h = cdiv(OH, ST_TH), tiles_w = cdiv(OW, ST_TW);
-    int IH = (ST_TH - 1) * stride + KH, IW = (ST_TW - 1) * stride + KW;
-    size_t smem = (size_t)(Ci * IH * IW + 256 * ST_COB) * sizeof(float);
-    int64_t ntiles = (int64_t)N * tiles_h * tiles_w;
-    int gx = (int)(ntiles < 1024 ? ntiles : 1024);
-    dim3 grid(gx, cdiv(Co, ST_COB));
-    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(stem_wgrad_kernel<T>, grid, dim3(256), smem, (hipStream_t)stream, x,
-                                                   (const T*)dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, tiles_h,
-                                                   tiles_w));
+    bool ok;
+    if (dtype == CN_F32)
+        ok = launch_small_wgrad<float>(x, true, (const float*)dy, dw, N, Ci, 0, H, W, Co, Co, KH, KW, stride, pad, OH, OW,
+                                       Ci * KH * KW, KH * KW, 1, (hipStream_t)stream);
+    else if (dtype == CN_BF16)
+        ok = launch_small_wgrad<bf16_t>(x, true, (const bf16_t*)dy, dw, N, Ci, 0, H, W, Co, Co, KH, KW, stride, pad, OH, OW,
+                                        Ci * KH * KW, KH * KW, 1, (hipStream_t)stream);
+    else
+        CN_CHECK_ARG(false, "cn_stem_conv_wgrad: bad dtype %d", dtype);
+    if (!ok) CN_UNSUPPORTED("cn_stem_conv_wgrad: shape does not fit the small-channel kernel");
     CN_LAUNCH_CHECK("cn_stem_conv_wgrad");
     return CN_OK;
 }
