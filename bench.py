@@ -104,18 +104,23 @@ class ConvProbe:
 
 def cpu_baseline(seconds_budget=30.0):
     """The oracle (torch-CPU restatement of the reference path: same op sequence, pure-torch DCNv2) on the host cores:
-    DLA-34 ctdet train step + decode, fp32, batch 2, 512x512."""
+    DLA-34 ctdet train step + decode, fp32, batch 2, 512x512.  Threads are capped at 16: on the 256-thread GPU host
+    torch's intra-op pool gets SLOWER beyond that (measured: 16 threads 0.5 s, 128 threads 11.9 s for the same step)."""
     from centernet_amd import rng, synth
     from oracle import models_ref, ops_ref
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     m = models_ref.CenterNetRef("dla_34")
     rng.fill_state_dict(m, 1234)
     m.train()
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     x, tgt = synth.ctdet_batch(1234, 2)
-    n, t0 = 0, time.time()
-    while True:
+
+    def one():
         opt.zero_grad()
         out = m(x)
         loss, _ = m.loss(out, tgt)
@@ -123,13 +128,19 @@ def cpu_baseline(seconds_budget=30.0):
         opt.step()
         with torch.no_grad():
             ops_ref.ctdet_decode(ops_ref.sigmoid_clamped(out[0]["heatmap"]), out[0]["width_height"], out[0]["regression"])
+
+    t0 = time.time()
+    one()                                   # warm-up (also sizes the sample)
+    warm = time.time() - t0
+    n_max = max(1, min(5, int((seconds_budget - warm) / max(warm, 1e-3))))
+    n, t0 = 0, time.time()
+    while n < n_max and time.time() - t0 < seconds_budget:
+        one()
         n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 3:
-            break
     dt = time.time() - t0
     return {"value": round(2 * n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} step(s) of DLA-34 ctdet train step + decode, batch 2, 512x512, fp32, torch CPU oracle "
-                      f"(pure-torch DCNv2), no warm-up, {dt:.1f} s"}
+            "sample": f"{n} timed step(s) after 1 warm-up of DLA-34 ctdet train step (fwd+loss+bwd+Adam) + decode, batch 2, "
+                      f"512x512, fp32, torch-CPU oracle (pure-torch DCNv2), {cores} threads, {dt:.1f} s"}
 
 
 def main():
