@@ -1,6 +1,6 @@
 // Pieces shared by the convolution kernels: geometry block, MFMA traits, LDS vector store, fused epilogue.
 #pragma once
-#include "common.h"
+#include "dcn_common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -26,6 +26,14 @@ struct ConvGeom {
     signed char dh[CN_MAX_CLS][CN_MAX_TAPS];
     signed char dw[CN_MAX_CLS][CN_MAX_TAPS];
     unsigned char wt[CN_MAX_CLS][CN_MAX_TAPS];
+    // fused DCNv2 offset/mask-gradient epilogue (cn_dcn_bwd_dom): the GEMM result dcol[p][k*Ci+c] is never stored
+    const void* dcn_x;
+    const float* dcn_om;
+    float* dcn_dom;
+    float* dcn_far;
+    int dcn_Ci, dcn_H, dcn_W, dcn_xld, dcn_omld;
+    const float* res32;   // optional fp32 residual added in the epilogue (pitch res32_ld)
+    int res32_ld;
 };
 
 template <typename T> struct Mma;
@@ -95,6 +103,11 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                     for (int e = 0; e < 4; ++e)
                         if (ch + e < g.Co) v[e] += Elem<T>::ld(R + px * g.res_ld + ch + e);
                 }
+                if (g.res32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ch + e < g.Co) v[e] += g.res32[px * g.res32_ld + ch + e];
+                }
                 if (g.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -129,6 +142,91 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
         }
     }
 }
+
+// DCNv2 backward, source side, fused into the GEMM that produces dcol = dY x W^T (rows = tap*Ci + c):
+//   dom[p][2k]   = m * sum_c dcol[p,k,c] * d(bilinear)/d(py)      dom[p][2k+1] likewise for px
+//   dom[p][18+k] = m(1-m) * sum_c dcol[p,k,c] * bilinear_unmasked
+// plus the rare samples displaced by more than DCN_FAR_R pixels, scattered into dx_far with global atomics (everything
+// nearer is handled by the atomic-free adjoint-gather kernel).  Lane layout as in conv_epilogue: pixel = lane&31,
+// channels (r&3) + 8*(r>>2) + 4*(lane>>5).  `red` = LDS scratch [128 pixels][TPB taps][3], zeroed by the caller.
+#define DCN_FAR_R 3
+template <typename T, int MI, int NJ>
+__device__ static inline void dcn_dom_accumulate(const ConvGeom& g, f32x16_t (&acc)[NJ][MI], const int64_t (&pix)[MI],
+                                                 const int (&mloc)[MI], int n0, int ch0, int lane, float* red, int tpb) {
+    const T* __restrict__ X = reinterpret_cast<const T*>(g.dcn_x);
+    const int Ci = g.dcn_Ci, H = g.dcn_H, W = g.dcn_W;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (pix[i] < 0) continue;
+        const int64_t p = pix[i];
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const int64_t img = p - ((int64_t)h * W + w);
+        const float* o = g.dcn_om + p * g.dcn_omld;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int chb = ch0 + j * 32;
+            if (chb >= g.Co) continue;
+            const int k = chb / Ci, cb = chb - k * Ci;
+            const float py = (float)(h - 1 + k / 3) + o[2 * k];
+            const float px = (float)(w - 1 + k % 3) + o[2 * k + 1];
+            const float m = sigmoidf_(o[18 + k]);
+            const Tap t = make_tap(py, px, H, W);
+            const int64_t i00 = img + (int64_t)t.h0 * W + t.w0;
+            const int dh0 = t.h0 - h, dw0 = t.w0 - w;
+            const bool far_h0 = dh0 > DCN_FAR_R || dh0 < -DCN_FAR_R, far_h1 = dh0 + 1 > DCN_FAR_R || dh0 + 1 < -DCN_FAR_R;
+            const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
+            const bool any_far = far_h0 || far_h1 || far_w0 || far_w1;
+            float s_m = 0.f, s_y = 0.f, s_x = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = cb + 8 * q + 4 * (lane >> 5);
+                float x00[4] = {0.f, 0.f, 0.f, 0.f}, x01[4] = {0.f, 0.f, 0.f, 0.f}, x10[4] = {0.f, 0.f, 0.f, 0.f}, x11[4] = {0.f, 0.f, 0.f, 0.f};
+                auto ld4 = [&](int64_t pixel, float* out) {
+                    const T* src = X + pixel * g.dcn_xld + c;
+                    if constexpr (sizeof(T) == 2) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(src);
+                        out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+                        out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+                    } else {
+                        const float4 v = *reinterpret_cast<const float4*>(src);
+                        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+                    }
+                };
+                if (t.ok00) ld4(i00, x00);
+                if (t.ok01) ld4(i00 + 1, x01);
+                if (t.ok10) ld4(i00 + W, x10);
+                if (t.ok11) ld4(i00 + W + 1, x11);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gj = acc[j][i][q * 4 + e];
+                    const float val = x00[e] * t.w00 + x01[e] * t.w01 + x10[e] * t.w10 + x11[e] * t.w11;
+                    s_m = fmaf(gj, val, s_m);
+                    s_y = fmaf(gj, (1.f - t.lw) * (x10[e] - x00[e]) + t.lw * (x11[e] - x01[e]), s_y);
+                    s_x = fmaf(gj, (1.f - t.lh) * (x01[e] - x00[e]) + t.lh * (x11[e] - x10[e]), s_x);
+                    if (any_far) {
+                        const float gm = gj * m;
+                        float* far = g.dcn_far + c + e;
+                        if (t.w00 != 0.f && (far_h0 || far_w0)) atomicAdd(far + i00 * Ci, gm * t.w00);
+                        if (t.w01 != 0.f && (far_h0 || far_w1)) atomicAdd(far + (i00 + 1) * Ci, gm * t.w01);
+                        if (t.w10 != 0.f && (far_h1 || far_w0)) atomicAdd(far + (i00 + W) * Ci, gm * t.w10);
+                        if (t.w11 != 0.f && (far_h1 || far_w1)) atomicAdd(far + (i00 + W + 1) * Ci, gm * t.w11);
+                    }
+                }
+            }
+            s_m += __shfl_xor(s_m, 32, 64);
+            s_y += __shfl_xor(s_y, 32, 64);
+            s_x += __shfl_xor(s_x, 32, 64);
+            if (lane < 32) {
+                float* r = red + (mloc[i] * tpb + (chb - n0) / Ci) * 3;
+                atomicAdd(r + 0, s_y); atomicAdd(r + 1, s_x); atomicAdd(r + 2, s_m);
+            }
+        }
+    }
+}
+
+// fused DCNv2 data-gradient kernel (dcn_fused.hip)
+void dcn_bwd_dx_launch(const ConvGeom& g, int dtype, hipStream_t st);
 
 // 3x3 / stride 1 / pad 1 halo-tile kernel (conv3x3.hip); returns false when the shape is not handled there
 bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st);

@@ -18,7 +18,7 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
-template <typename T, int BN, int BK>
+template <typename T, int BN, int BK, bool DOM = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     constexpr int BM = 128;
     constexpr int VEC = 16 / sizeof(T);
@@ -159,7 +159,117 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
             pix[i] = ((int64_t)n * g.OH + oh * g.so + ph) * g.OW + ow * g.so + pw;
         }
     }
-    conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
+    if constexpr (!DOM) {
+        conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
+    } else {
+        // fused DCNv2 offset / mask gradient (the GEMM result dcol is never stored to HBM)
+        const int Ci = g.dcn_Ci;
+        if constexpr (sizeof(T) == 2) {
+            // bf16: park the dcol tile [128 pixels][BN channels] in LDS, then GS = BN/8 lanes per (pixel, tap) read 16-byte
+            // slices of it and of the four bilinear corners of x (coalesced 128/256-byte rows), reduce with shuffles.
+            constexpr int DP = BN + 8;
+            constexpr int GS = BN / 8;
+            static_assert(BM * DP <= 2 * BUF, "dcol tile must fit in the pipeline buffers");
+            bf16_t* dt = reinterpret_cast<bf16_t*>(lds);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint2 o;
+                        o.x = (uint32_t)f2bf(acc[j][i][q * 4 + 0]) | ((uint32_t)f2bf(acc[j][i][q * 4 + 1]) << 16);
+                        o.y = (uint32_t)f2bf(acc[j][i][q * 4 + 2]) | ((uint32_t)f2bf(acc[j][i][q * 4 + 3]) << 16);
+                        *reinterpret_cast<uint2*>(dt + (wm + i * 32 + (lane & 31)) * DP + wn + j * 32 + 8 * q + 4 * (lane >> 5)) = o;
+                    }
+            __syncthreads();
+            const int k = n0 / Ci, cb = n0 - k * Ci;              // BN <= Ci here: one tap, channel offset cb
+            const bool whole = BN >= Ci;
+            const int lg = threadIdx.x % GS, gl = threadIdx.x / GS;
+            const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(g.dcn_x);
+            const int H = g.dcn_H, W = g.dcn_W;
+            for (int ml = gl; ml < BM; ml += 256 / GS) {
+                const int m = m0 + ml;
+                if (m >= Mc) continue;                            // whole lane group leaves together
+                const int w = m % W, h = (m / W) % H;
+                const int64_t img = (int64_t)m - ((int64_t)h * W + w);
+                const float* o = g.dcn_om + (int64_t)m * g.dcn_omld;
+                const float py = (float)(h - 1 + k / 3) + o[2 * k];
+                const float px = (float)(w - 1 + k % 3) + o[2 * k + 1];
+                const float mk = sigmoidf_(o[18 + k]);
+                const Tap t = make_tap(py, px, H, W);
+                // unconditional loads from clamped addresses (4 independent gathers); out-of-image corners are zeroed
+                const int hc0 = min(max(t.h0, 0), H - 1), hc1 = min(max(t.h0 + 1, 0), H - 1);
+                const int wc0 = min(max(t.w0, 0), W - 1), wc1 = min(max(t.w0 + 1, 0), W - 1);
+                const bf16_t* xb = X + img * g.dcn_xld + cb + lg * 8;
+                float x00[8], x01[8], x10[8], x11[8], gc[8];
+                Vec16<bf16_t>::load(xb + ((int64_t)hc0 * W + wc0) * g.dcn_xld, x00);
+                Vec16<bf16_t>::load(xb + ((int64_t)hc0 * W + wc1) * g.dcn_xld, x01);
+                Vec16<bf16_t>::load(xb + ((int64_t)hc1 * W + wc0) * g.dcn_xld, x10);
+                Vec16<bf16_t>::load(xb + ((int64_t)hc1 * W + wc1) * g.dcn_xld, x11);
+                Vec16<bf16_t>::load(dt + ml * DP + lg * 8, gc);
+                const float k00 = t.ok00 ? 1.f : 0.f, k01 = t.ok01 ? 1.f : 0.f, k10 = t.ok10 ? 1.f : 0.f, k11 = t.ok11 ? 1.f : 0.f;
+                float s_m = 0.f, s_y = 0.f, s_x = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = x00[e] * k00, b = x01[e] * k01, c = x10[e] * k10, d = x11[e] * k11;
+                    s_m = fmaf(gc[e], a * t.w00 + b * t.w01 + c * t.w10 + d * t.w11, s_m);
+                    s_y = fmaf(gc[e], (1.f - t.lw) * (c - a) + t.lw * (d - b), s_y);
+                    s_x = fmaf(gc[e], (1.f - t.lh) * (b - a) + t.lh * (d - c), s_x);
+                }
+                const int dh0 = t.h0 - h, dw0 = t.w0 - w;
+                const bool far_h0 = dh0 > DCN_FAR_R || dh0 < -DCN_FAR_R, far_h1 = dh0 + 1 > DCN_FAR_R || dh0 + 1 < -DCN_FAR_R;
+                const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
+                if (far_h0 || far_h1 || far_w0 || far_w1) {       // samples the adjoint-gather window cannot see
+                    const int64_t i00 = img + (int64_t)t.h0 * W + t.w0;
+                    float* far = g.dcn_far + cb + lg * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gm = gc[e] * mk;
+                        if (t.w00 != 0.f && (far_h0 || far_w0)) atomicAdd(far + i00 * Ci + e, gm * t.w00);
+                        if (t.w01 != 0.f && (far_h0 || far_w1)) atomicAdd(far + (i00 + 1) * Ci + e, gm * t.w01);
+                        if (t.w10 != 0.f && (far_h1 || far_w0)) atomicAdd(far + (i00 + W) * Ci + e, gm * t.w10);
+                        if (t.w11 != 0.f && (far_h1 || far_w1)) atomicAdd(far + (i00 + W + 1) * Ci + e, gm * t.w11);
+                    }
+                }
+#pragma unroll
+                for (int ofs = GS >> 1; ofs > 0; ofs >>= 1) {
+                    s_m += __shfl_xor(s_m, ofs, 64);
+                    s_y += __shfl_xor(s_y, ofs, 64);
+                    s_x += __shfl_xor(s_x, ofs, 64);
+                }
+                if (lg == 0) {
+                    float* d = g.dcn_dom + (int64_t)m * g.dcn_omld;
+                    const float vy = s_y * mk, vx = s_x * mk, vm = s_m * mk * (1.f - mk);
+                    if (whole) { d[2 * k] = vy; d[2 * k + 1] = vx; d[18 + k] = vm; }
+                    else { atomicAdd(d + 2 * k, vy); atomicAdd(d + 2 * k + 1, vx); atomicAdd(d + 18 + k, vm); }
+                }
+            }
+        } else {
+            // fp32 (parity mode): per-lane accumulation straight from the MFMA registers, LDS fold across the channel waves
+            const int tpb = BN >= Ci ? BN / Ci : 1;                 // taps covered by this workgroup's BN channels
+            float* red = reinterpret_cast<float*>(lds);              // [128][tpb][3]   (the tiles are dead after the last barrier)
+            for (int i = threadIdx.x; i < BM * tpb * 3; i += 256) red[i] = 0.f;
+            __syncthreads();
+            int mloc[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) mloc[i] = wm + i * 32 + (lane & 31);
+            dcn_dom_accumulate<T, MI, NJ>(g, acc, pix, mloc, n0, n0 + wn, lane, red, tpb);
+            __syncthreads();
+            const bool whole = BN >= Ci;                             // this workgroup saw every channel of its taps
+            for (int i = threadIdx.x; i < BM * tpb; i += 256) {
+                const int ml = i / tpb, tl = i - ml * tpb;
+                const int m = m0 + ml;
+                const int k = n0 / Ci + tl;
+                if (m >= Mc || k >= 9) continue;
+                const float mk = sigmoidf_(g.dcn_om[(int64_t)m * g.dcn_omld + 18 + k]);
+                const float vy = red[i * 3 + 0] * mk, vx = red[i * 3 + 1] * mk, vm = red[i * 3 + 2] * mk * (1.f - mk);
+                float* d = g.dcn_dom + (int64_t)m * g.dcn_omld;
+                if (whole) { d[2 * k] = vy; d[2 * k + 1] = vx; d[18 + k] = vm; }
+                else { atomicAdd(d + 2 * k, vy); atomicAdd(d + 2 * k + 1, vx); atomicAdd(d + 18 + k, vm); }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -295,6 +405,61 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     return CN_OK;
 }
 
+// dom / dx_far of the DCNv2 backward, fused into the GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2: [9*Ci][Co_pad16])
+extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, float* dx_far,
+                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype, void* stream) {
+    CN_CHECK_ARG(dy && wpd2 && x && om && dom && dx_far && N > 0 && H > 0 && W > 0, "cn_dcn_bwd_dom: bad args");
+    if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dom: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
+    CN_CHECK_ARG(om_ld >= 27 && x_ld >= Ci, "cn_dcn_bwd_dom: bad pitches");
+    ConvGeom g;
+    memset(&g, 0, sizeof(g));
+    g.x = dy; g.w = wpd2; g.y = dom;
+    g.N = N; g.H = H; g.W = W; g.Ci = dy_ld; g.x_ld = dy_ld; g.OH = H; g.OW = W; g.Co = 9 * Ci; g.y_ld = 9 * Ci;
+    g.ktot = dy_ld; g.co_pad = (9 * Ci + 31) / 32 * 32;
+    (void)Co;
+    build_geom(g, 1, 1, 1, 0, 0);
+    g.dcn_x = x; g.dcn_om = om; g.dcn_dom = dom; g.dcn_far = dx_far;
+    g.dcn_Ci = Ci; g.dcn_H = H; g.dcn_W = W; g.dcn_xld = x_ld; g.dcn_omld = om_ld;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t M = (int64_t)N * H * W;
+    int bn = Ci % 128 == 0 ? 128 : (Ci % 64 == 0 ? 64 : 32);
+    if (bn == 128 && dtype == CN_BF16 && dy_ld % 32 != 0) bn = 64;   // the 128-wide tile needs the BK=32 pipeline buffers for its dcol tile
+    dim3 grid(cdiv(M, 128), cdiv(9 * Ci, bn), 1);
+#define CN_DOM(T, BN_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, BK_, true>), grid, dim3(256), 0, st, g)
+    if (dtype == CN_BF16) {
+        const int bk = dy_ld % 64 == 0 ? (bn == 128 ? 32 : 64) : (dy_ld % 32 == 0 ? 32 : 16);
+        if (bn == 128) { CN_DOM(bf16_t, 128, 32); }
+        else if (bn == 64) { if (bk == 64) CN_DOM(bf16_t, 64, 64); else if (bk == 32) CN_DOM(bf16_t, 64, 32); else CN_DOM(bf16_t, 64, 16); }
+        else { if (bk == 64) CN_DOM(bf16_t, 32, 64); else if (bk == 32) CN_DOM(bf16_t, 32, 32); else CN_DOM(bf16_t, 32, 16); }
+    } else if (dtype == CN_F32) {
+        if (bn == 128) CN_DOM(float, 128, 16); else if (bn == 64) CN_DOM(float, 64, 16); else CN_DOM(float, 32, 16);
+    } else {
+        CN_CHECK_ARG(false, "cn_dcn_bwd_dom: bad dtype %d", dtype);
+    }
+#undef CN_DOM
+    CN_LAUNCH_CHECK("cn_dcn_bwd_dom");
+    return CN_OK;
+}
+
+// dx of the DCNv2 backward (adjoint-gather + contraction, dcn_fused.hip).  wpd0 = cn_pack_weight mode 0 of the layer weight
+// ([Ci rows][tap*Co_pad16 + co]); dx_far = fp32 [P][Ci] from cn_dcn_bwd_dom (added in the epilogue); dx in `dtype`.
+extern "C" int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, const float* dx_far, void* dx,
+                             int N, int H, int W, int Ci, int dy_ld, int om_ld, int dtype, void* stream) {
+    CN_CHECK_ARG(dy && wpd0 && om && dx_far && dx && N > 0 && H > 0 && W > 0, "cn_dcn_bwd_dx: bad args");
+    if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dx: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
+    if (N > 65535) CN_UNSUPPORTED("cn_dcn_bwd_dx: batch %d", N);
+    if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_dcn_bwd_dx: bad dtype %d", dtype);
+    ConvGeom g;
+    memset(&g, 0, sizeof(g));
+    g.x = dy; g.w = wpd0; g.y = dx;
+    g.N = N; g.H = H; g.W = W; g.Ci = dy_ld; g.x_ld = dy_ld; g.OH = H; g.OW = W; g.Co = Ci; g.y_ld = Ci;
+    g.ktot = 9 * dy_ld; g.co_pad = (Ci + 31) / 32 * 32; g.so = 1; g.sm = 1;
+    g.dcn_om = om; g.dcn_omld = om_ld; g.res32 = dx_far; g.res32_ld = Ci;
+    dcn_bwd_dx_launch(g, dtype, (hipStream_t)stream);
+    CN_LAUNCH_CHECK("cn_dcn_bwd_dx");
+    return CN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ packing
 // mode 0: rows = B, k = t*inner_pad + a   (Wp[b][t*ip + a] = W[a][b][t])
 // mode 1: rows = A, k = t*inner_pad + b   (Wp[a][t*ip + b] = W[a][b][t])
@@ -345,22 +510,24 @@ extern "C" int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, in
 
 // dw[a][b][t] = dwp[a][t*inner_pad + b]   (inverse of mode 1)
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int A,
-                                                           int B, int taps, int inner_pad) {
+                                                           int B, int taps, int inner_pad, int accumulate) {
     const int64_t total = (int64_t)A * B * taps;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int t = (int)(i % taps);
         int64_t ab = i / taps;
         int b = (int)(ab % B), a = (int)(ab / B);
-        dw[i] = dwp[(int64_t)a * taps * inner_pad + (int64_t)t * inner_pad + b];
+        const float v = dwp[(int64_t)a * taps * inner_pad + (int64_t)t * inner_pad + b];
+        dw[i] = accumulate ? dw[i] + v : v;
     }
 }
 
-extern "C" int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, void* stream) {
+extern "C" int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, int accumulate,
+                               void* stream) {
     CN_CHECK_ARG(dwp && dw && A > 0 && B > 0 && inner_pad >= B, "cn_unpack_wgrad: bad args");
     int64_t total = (int64_t)A * B * KH * KW;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dwp, dw, A, B, KH * KW, inner_pad);
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dwp, dw, A, B, KH * KW, inner_pad, accumulate);
     CN_LAUNCH_CHECK("cn_unpack_wgrad");
     return CN_OK;
 }

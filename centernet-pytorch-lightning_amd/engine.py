@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
+from .ops import SideGrads
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -186,13 +187,17 @@ class TrainStep:
     `post_step` (optional callable, no grad) runs after the optimizer — the bench uses it for ctdet_decode.
     """
 
-    def __init__(self, model, lr=None, distributed=None, graph=False, post_step=None):
+    def __init__(self, model, lr=None, distributed=None, graph=False, post_step=None, side_grads=True):
         self.model = model
         lr = lr if lr is not None else getattr(model.hparams, "learning_rate", 1e-4)
         self.opt = FlatAdam(model.parameters(), lr=lr)
         self.graph, self.post_step, self.post_out = graph, post_step, None
         use_dist = dist.is_initialized() if distributed is None else distributed
         self.sync = GradSync(self.opt, hooks=not graph) if use_dist else None
+        # weight gradients on a second stream (deposited straight into the flat gradient buffer) unless grad-ready hooks
+        # need autograd to see every parameter gradient (eager multi-GPU mode)
+        hooks_on = self.sync is not None and self.sync.world > 1 and not graph
+        self.side = SideGrads.enable(side_grads and not hooks_on and self.opt.flat_p.is_cuda)
         if self.sync is not None:
             self.sync.broadcast_state(model)
         self._g1 = self._g2 = None
@@ -203,7 +208,9 @@ class TrainStep:
         loss = self.model.training_step(batch, batch_idx)
         if self.sync is not None and not self.graph:
             self.sync.begin()
+        SideGrads.active = self.side
         loss.backward()
+        SideGrads.join()
         if self.sync is not None:
             self.sync.allreduce_all() if self.graph else self.sync.finish()
         self.opt.step()
@@ -227,7 +234,9 @@ class TrainStep:
         with torch.cuda.graph(self._g1):
             self.opt.zero_grad()
             loss = self.model.training_step(static, 0)
+            SideGrads.active = self.side
             loss.backward()
+            SideGrads.join()
             self._loss = loss.detach()
         for m in self._bns:
             m._pending -= 1          # the capture pass ran host code only; nothing executed on the device

@@ -10,6 +10,9 @@ from torch.autograd import Function
 from . import _hip
 from ._hip import call, dtype_code
 
+import os as _os
+
+_DCN_UNFUSED = bool(_os.environ.get("CN_DCN_UNFUSED"))
 BN_MOMENTUM = 0.1  # msra_resnet.py:11, pose_dla_dcn.py:13
 BN_EPS = 1e-5
 
@@ -45,10 +48,48 @@ def pack_weight(w, mode, dtype, row_scale=None):
     return wp
 
 
-def unpack_wgrad(dwp, A, B, KH, KW):
-    dw = torch.empty((A, B, KH, KW), dtype=torch.float32, device=dwp.device)
-    call("cn_unpack_wgrad", dwp, dw, A, B, KH, KW, rup(B, 16))
+def unpack_wgrad(dwp, A, B, KH, KW, into=None):
+    """packed fp32 gradient -> parameter layout; `into` (a .grad view) is accumulated in place."""
+    dw = into if into is not None else torch.empty((A, B, KH, KW), dtype=torch.float32, device=dwp.device)
+    call("cn_unpack_wgrad", dwp, dw, A, B, KH, KW, rup(B, 16), int(into is not None))
     return dw
+
+
+class SideGrads:
+    """Weight gradients on a second HIP stream.
+
+    A layer's weight gradient only feeds the optimizer, while its data gradient is on the critical path of backward.
+    With this switch on, every op launches its weight-gradient kernels on a side stream (forked after dY is ready) and
+    deposits the result directly into `param.grad` (the flat gradient buffer) instead of returning it to autograd, so
+    the two chains overlap and fill each other's latency bubbles; `join()` merges the streams before the optimizer.
+    Under hipGraph capture this becomes a fork/join of graph branches.  Not used together with grad-ready hooks.
+    """
+    stream = None
+    active = False        # only true while a TrainStep (which joins afterwards) is running its backward
+
+    @classmethod
+    def enable(cls, on=True):
+        if on and cls.stream is None:
+            cls.stream = torch.cuda.Stream()
+        return on
+
+    @classmethod
+    def usable(cls, *params):
+        return cls.active and cls.stream is not None and all(p is None or p.grad is not None for p in params)
+
+    @classmethod
+    def fork(cls, *tensors):
+        cls.stream.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cls.stream)
+        return torch.cuda.stream(cls.stream)
+
+    @classmethod
+    def join(cls):
+        if cls.active and cls.stream is not None:
+            torch.cuda.current_stream().wait_stream(cls.stream)
+        cls.active = False
 
 
 def conv_out(h, k, s, p):
@@ -67,12 +108,13 @@ def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH,
     return y
 
 
-def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias):
-    """-> (dwp fp32 [rup32(Co)][KH*KW*Ci], db fp32[Co] | None); x [N,H,W,Ci], dy [N,OH,OW,>=Co]."""
+def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=None):
+    """-> (dwp fp32 [rup32(Co)][KH*KW*Ci], db fp32[Co] | None); x [N,H,W,Ci], dy [N,OH,OW,>=Co].
+    `db_into`: fp32[Co] buffer the bias gradient is ACCUMULATED into (e.g. bias.grad)."""
     N, H, W, Ci = x.shape
     _, OH, OW, ld = dy.shape
     dwp = torch.zeros((rup(Co, 32), KH * KW * Ci), dtype=torch.float32, device=x.device)
-    db = torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None
+    db = db_into if db_into is not None else (torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None)
     call("cn_conv2d_wgrad", x, dy, dwp, db, N, H, W, Ci, Ci, OH, OW, Co, ld, KH, KW, stride, pad, dtype_code(x.dtype))
     return dwp, db
 
@@ -91,6 +133,7 @@ class Conv2dFn(Function):
         y = _igemm(x, wp, bias, None, Co, KH, KW, stride, pad, False, relu, OH, OW)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (stride, pad, relu, bias is not None)
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -105,7 +148,11 @@ class Conv2dFn(Function):
             call("cn_relu_bwd", dy, y, g, dy.numel(), dtype_code(dy.dtype))
             dy = g
         dx = dw = db = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and Cx == Ci and SideGrads.usable(weight, ctx.bias_ref):
+            with SideGrads.fork(x, dy):
+                dwp, _ = _wgrad(x, dy, Co, KH, KW, stride, pad, False, db_into=ctx.bias_ref.grad if has_bias else None)
+                unpack_wgrad(dwp, Co, Ci, KH, KW, into=weight.grad)
+        elif ctx.needs_input_grad[1]:
             dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, has_bias and ctx.needs_input_grad[2])
             dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
         if ctx.needs_input_grad[0]:
@@ -138,7 +185,11 @@ class ConvTranspose2dFn(Function):
         N, H, W, _ = x.shape
         dy = dy.contiguous()
         dx = dw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and SideGrads.usable(weight):
+            with SideGrads.fork(x, dy):
+                dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
+                unpack_wgrad(dwp, Ci, Co, KH, KW, into=weight.grad)
+        elif ctx.needs_input_grad[1]:
             # dW[ci][co][t] = sum x[n,ih,iw,ci] * dy[n, ih*s-p+kh, iw*s-p+kw, co]: the wgrad kernel with roles swapped
             dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
             dw = unpack_wgrad(dwp, Ci, Co, KH, KW)
@@ -170,6 +221,11 @@ class StemConvFn(Function):
         Co, Ci, KH, KW = weight.shape
         N, _, H, W = img.shape
         dy = dy.contiguous()
+        if SideGrads.usable(weight):
+            with SideGrads.fork(img, dy):   # the kernel accumulates with atomics: deposit straight into weight.grad
+                call("cn_stem_conv_wgrad", img, dy, weight.grad, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2],
+                     dtype_code(dy.dtype))
+            return None, None, None, None, None
         dw = torch.zeros_like(weight, dtype=torch.float32)
         call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))
         return None, dw, None, None, None
@@ -291,7 +347,10 @@ class DwDeconvFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             call("cn_dwdeconv_bwd_input", dy, weight.detach().contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and SideGrads.usable(weight):
+            with SideGrads.fork(x, dy):
+                call("cn_dwdeconv_bwd_weight", x, dy, weight.grad, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        elif ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight, dtype=torch.float32)
             call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
         return dx, dw, None, None
@@ -387,6 +446,7 @@ class DCNv2Fn(Function):
         wp = pack_weight(weight, 1, x.dtype)                  # [Co_pad][9*Ci]: a 1x1 conv over the columns
         y = _igemm(col, wp, bias.detach(), None, Co, 1, 1, 1, 0, False, False, H, W)
         ctx.save_for_backward(x, om, col, weight, om_weight)
+        ctx.params = (bias, om_weight, om_bias)
         return y
 
     @staticmethod
@@ -397,27 +457,49 @@ class DCNv2Fn(Function):
         dt = dtype_code(x.dtype)
         dy = dy.contiguous()
         # main weight / bias: 1x1 wgrad over the sampled columns
-        dwp, db = _wgrad(col, dy, Co, 1, 1, 1, 0, True)
-        dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
-        # column gradient: dcol[p][t*Ci+ci] = sum_co dy[p][co] * W[co][ci][t]
-        wpd = pack_weight(weight, 2, x.dtype)                 # [9*Ci][Co]
-        dcol = _igemm(dy, wpd, None, None, 9 * Ci, 1, 1, 1, 0, False, False, H, W)
-        dx_tile = torch.empty((N, H, W, Ci), dtype=torch.float32, device=x.device)
+        side = SideGrads.usable(weight, ctx.params[0], ctx.params[1], ctx.params[2])
+        dw = db = dw_om = db_om = None
+        if side:
+            with SideGrads.fork(col, dy):
+                dwp, _ = _wgrad(col, dy, Co, 1, 1, 1, 0, False, db_into=ctx.params[0].grad)
+                unpack_wgrad(dwp, Co, Ci, 3, 3, into=weight.grad)
+        else:
+            dwp, db = _wgrad(col, dy, Co, 1, 1, 1, 0, True)
+            dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
         dx_far = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
         dom32 = torch.zeros_like(om)
-        call("cn_dcn_col2im", dcol, x, om, dx_tile, dx_far, dom32, N, H, W, Ci, Ci, om.shape[-1], dt)
-        del dcol
         dx_s = torch.empty_like(x)
-        call("cn_add_f32_to", dx_tile, dx_far, dx_s, dx_tile.numel(), dt)
-        del dx_tile, dx_far
+        if _DCN_UNFUSED:
+            # reference pipeline kept for A/B profiling: materialise dcol, then source + gather kernels
+            wpd = pack_weight(weight, 2, x.dtype)                 # [9*Ci][Co]
+            dcol = _igemm(dy, wpd, None, None, 9 * Ci, 1, 1, 1, 0, False, False, H, W)
+            dx_tile = torch.empty((N, H, W, Ci), dtype=torch.float32, device=x.device)
+            call("cn_dcn_col2im", dcol, x, om, dx_tile, dx_far, dom32, N, H, W, Ci, Ci, om.shape[-1], dt)
+            del dcol
+            call("cn_add_f32_to", dx_tile, dx_far, dx_s, dx_tile.numel(), dt)
+            del dx_tile
+        else:
+            # fused: the 9x-wide column gradient never reaches HBM
+            #   dom  <- epilogue of the GEMM dY x W^T (against the bilinear corner differences of x)
+            #   dx   <- adjoint bilinear gather of dY (LDS hit lists) contracted with W, + far samples
+            call("cn_dcn_bwd_dom", dy, pack_weight(weight, 2, x.dtype), x, om, dom32, dx_far, N, H, W, Ci, Co,
+                 dy.shape[-1], Ci, om.shape[-1], dt)
+            call("cn_dcn_bwd_dx", dy, pack_weight(weight, 0, x.dtype), om, dx_far, dx_s, N, H, W, Ci, dy.shape[-1],
+                 om.shape[-1], dt)
+        del dx_far
         if x.dtype == torch.float32:
             dom = dom32
         else:
             dom = torch.empty(om.shape, dtype=x.dtype, device=x.device)
             call("cn_cast", dom32, 0, dom, dt, dom32.numel())
         # offset/mask conv backward (its data gradient is added to the sampling gradient through `residual`)
-        dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)
-        dw_om = unpack_wgrad(dwp_om, 27, Ci, 3, 3)
+        if side:
+            with SideGrads.fork(x, dom):
+                dwp_om, _ = _wgrad(x, dom, 27, 3, 3, 1, 1, False, db_into=ctx.params[2].grad)
+                unpack_wgrad(dwp_om, 27, Ci, 3, 3, into=ctx.params[1].grad)
+        else:
+            dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)
+            dw_om = unpack_wgrad(dwp_om, 27, Ci, 3, 3)
         wpo = pack_weight(om_weight, 0, x.dtype)              # rows = Ci, k = tap*32 + c
         dx = torch.empty_like(x)
         call("cn_conv2d_fwd", dom, wpo, None, dx_s, dx, N, H, W, om.shape[-1], om.shape[-1], H, W, Ci, Ci, Ci,

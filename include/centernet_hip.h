@@ -53,8 +53,9 @@ int cn_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
  * of 16).  row_scale (nullable, fp32[rows]) multiplies each row (eval-mode BN folding). */
 int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, int KW, int mode, int rows_pad, int inner_pad,
                    const float* row_scale, int dtype, void* stream);
-/* inverse of mode 1 for gradients: dw[a][b][t] = dwp[a][t*inner_pad + b] (fp32 -> fp32) */
-int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, void* stream);
+/* inverse of mode 1 for gradients: dw[a][b][t] (+)= dwp[a][t*inner_pad + b] (fp32 -> fp32); accumulate != 0 adds into dw
+ * (used to deposit gradients straight into the flat gradient buffer from a side stream) */
+int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, int accumulate, void* stream);
 
 /* Implicit-GEMM convolution, NHWC.  y[n,oh,ow,co] = act(bias[co] + res[..] + sum_{t,ci} xg * Wp[co][t*Ci+ci])
  *   transposed == 0: xg = x[n, oh*stride - pad + kh, ow*stride - pad + kw, ci]       (nn.Conv2d)
@@ -127,6 +128,16 @@ int cn_dcn_im2col(const void* x, const float* om, void* col, int N, int H, int W
  * channels 0..26 are overwritten. */
 int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_tile, float* dx_far, float* dom,
                   int N, int H, int W, int Ci, int x_ld, int om_ld, int dtype, void* stream);
+/* Fused DCNv2 backward (no column gradient in HBM), used instead of cn_dcn_col2im:
+ *   cn_dcn_bwd_dom: GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2) whose epilogue reduces dcol against the bilinear
+ *     corner differences of x -> dom fp32 [P][om_ld] (channels 0..26; zeroed by the caller when Ci > 128), and scatters
+ *     samples displaced by more than 3 px into dx_far (fp32 [P][Ci], zeroed by the caller).
+ *   cn_dcn_bwd_dx: dx[q] = sum_k W_k^T G_k[q], G_k = adjoint bilinear sampling of dY (hit lists in LDS, atomic-free),
+ *     + dx_far in the epilogue.  wpd0 = cn_pack_weight mode 0.  dy_ld must equal the weights' inner_pad = rup16(Co). */
+int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, float* dx_far,
+                   int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype, void* stream);
+int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, const float* dx_far, void* dx,
+                  int N, int H, int W, int Ci, int dy_ld, int om_ld, int dtype, void* stream);
 /* out[i] = a[i] + b[i] for fp32 a, b -> out in `dtype` (combines dx_tile + dx_far into the activation dtype) */
 int cn_add_f32_to(const float* a, const float* b, void* out, int64_t n, int dtype, void* stream);
 
