@@ -188,31 +188,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
             const int lg = threadIdx.x % GS, gl = threadIdx.x / GS;
             const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(g.dcn_x);
             const int H = g.dcn_H, W = g.dcn_W;
-            for (int ml = gl; ml < BM; ml += 256 / GS) {
-                const int m = m0 + ml;
-                if (m >= Mc) continue;                            // whole lane group leaves together
-                const int w = m % W, h = (m / W) % H;
-                const int64_t img = (int64_t)m - ((int64_t)h * W + w);
-                const float* o = g.dcn_om + (int64_t)m * g.dcn_omld;
-                const float py = (float)(h - 1 + k / 3) + o[2 * k];
-                const float px = (float)(w - 1 + k % 3) + o[2 * k + 1];
-                const float mk = sigmoidf_(o[18 + k]);
-                const Tap t = make_tap(py, px, H, W);
-                // unconditional loads from clamped addresses (4 independent gathers); out-of-image corners are zeroed
-                const int hc0 = min(max(t.h0, 0), H - 1), hc1 = min(max(t.h0 + 1, 0), H - 1);
-                const int wc0 = min(max(t.w0, 0), W - 1), wc1 = min(max(t.w0 + 1, 0), W - 1);
+            // 128 pixels / (256/GS) pixels per pass = NP passes; all passes' dependent loads (offsets -> corners) are issued
+            // together so a workgroup pays two memory round trips instead of 2*NP.
+            constexpr int NPT = BM / (256 / GS);     // passes in total
+            constexpr int NP = NPT < 4 ? NPT : 4;     // passes batched together (register budget)
+#pragma unroll 1
+            for (int ub = 0; ub < NPT; ub += NP) {
+            const int glb = gl + ub * (256 / GS);
+            float py[NP], px[NP], mk[NP];
+            bool live[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int m = m0 + glb + u * (256 / GS);
+                live[u] = m < Mc;
+                const float* o = g.dcn_om + (int64_t)(live[u] ? m : m0) * g.dcn_omld;
+                py[u] = o[2 * k]; px[u] = o[2 * k + 1]; mk[u] = o[18 + k];
+            }
+            uint4 r00[NP], r01[NP], r10[NP], r11[NP];
+            Tap tp[NP];
+            int hh[NP], ww[NP];
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int m = live[u] ? m0 + glb + u * (256 / GS) : m0;
+                ww[u] = m % W; hh[u] = (m / W) % H;
+                const int64_t img = (int64_t)m - ((int64_t)hh[u] * W + ww[u]);
+                py[u] += (float)(hh[u] - 1 + k / 3);
+                px[u] += (float)(ww[u] - 1 + k % 3);
+                mk[u] = sigmoidf_(mk[u]);
+                tp[u] = make_tap(py[u], px[u], H, W);
+                // unconditional loads from clamped addresses; out-of-image corners are zeroed below
+                const int hc0 = min(max(tp[u].h0, 0), H - 1), hc1 = min(max(tp[u].h0 + 1, 0), H - 1);
+                const int wc0 = min(max(tp[u].w0, 0), W - 1), wc1 = min(max(tp[u].w0 + 1, 0), W - 1);
                 const bf16_t* xb = X + img * g.dcn_xld + cb + lg * 8;
-                float x00[8], x01[8], x10[8], x11[8], gc[8];
-                Vec16<bf16_t>::load(xb + ((int64_t)hc0 * W + wc0) * g.dcn_xld, x00);
-                Vec16<bf16_t>::load(xb + ((int64_t)hc0 * W + wc1) * g.dcn_xld, x01);
-                Vec16<bf16_t>::load(xb + ((int64_t)hc1 * W + wc0) * g.dcn_xld, x10);
-                Vec16<bf16_t>::load(xb + ((int64_t)hc1 * W + wc1) * g.dcn_xld, x11);
+                r00[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hc0 * W + wc0) * g.dcn_xld);
+                r01[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hc0 * W + wc1) * g.dcn_xld);
+                r10[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hc1 * W + wc0) * g.dcn_xld);
+                r11[u] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hc1 * W + wc1) * g.dcn_xld);
+            }
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int ml = glb + u * (256 / GS);
+                const int m = m0 + ml;
+                const Tap& t = tp[u];
+                const int h = hh[u], w = ww[u];
+                const int64_t img = (int64_t)m - ((int64_t)h * W + w);
+                float gc[8];
                 Vec16<bf16_t>::load(dt + ml * DP + lg * 8, gc);
                 const float k00 = t.ok00 ? 1.f : 0.f, k01 = t.ok01 ? 1.f : 0.f, k10 = t.ok10 ? 1.f : 0.f, k11 = t.ok11 ? 1.f : 0.f;
+                const uint32_t w00_[4] = {r00[u].x, r00[u].y, r00[u].z, r00[u].w}, w01_[4] = {r01[u].x, r01[u].y, r01[u].z, r01[u].w};
+                const uint32_t w10_[4] = {r10[u].x, r10[u].y, r10[u].z, r10[u].w}, w11_[4] = {r11[u].x, r11[u].y, r11[u].z, r11[u].w};
                 float s_m = 0.f, s_y = 0.f, s_x = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float a = x00[e] * k00, b = x01[e] * k01, c = x10[e] * k10, d = x11[e] * k11;
+                    const int sh = (e & 1) ? 0 : 16;
+                    const float a = __uint_as_float((e & 1) ? (w00_[e >> 1] & 0xffff0000u) : (w00_[e >> 1] << sh)) * k00;
+                    const float b = __uint_as_float((e & 1) ? (w01_[e >> 1] & 0xffff0000u) : (w01_[e >> 1] << sh)) * k01;
+                    const float c = __uint_as_float((e & 1) ? (w10_[e >> 1] & 0xffff0000u) : (w10_[e >> 1] << sh)) * k10;
+                    const float d = __uint_as_float((e & 1) ? (w11_[e >> 1] & 0xffff0000u) : (w11_[e >> 1] << sh)) * k11;
                     s_m = fmaf(gc[e], a * t.w00 + b * t.w01 + c * t.w10 + d * t.w11, s_m);
                     s_y = fmaf(gc[e], (1.f - t.lw) * (c - a) + t.lw * (d - b), s_y);
                     s_x = fmaf(gc[e], (1.f - t.lh) * (b - a) + t.lh * (d - c), s_x);
@@ -220,12 +252,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
                 const int dh0 = t.h0 - h, dw0 = t.w0 - w;
                 const bool far_h0 = dh0 > DCN_FAR_R || dh0 < -DCN_FAR_R, far_h1 = dh0 + 1 > DCN_FAR_R || dh0 + 1 < -DCN_FAR_R;
                 const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
-                if (far_h0 || far_h1 || far_w0 || far_w1) {       // samples the adjoint-gather window cannot see
+                if (live[u] && (far_h0 || far_h1 || far_w0 || far_w1)) {       // samples the adjoint-gather window cannot see
                     const int64_t i00 = img + (int64_t)t.h0 * W + t.w0;
                     float* far = g.dcn_far + cb + lg * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float gm = gc[e] * mk;
+                        const float gm = gc[e] * mk[u];
                         if (t.w00 != 0.f && (far_h0 || far_w0)) atomicAdd(far + i00 * Ci + e, gm * t.w00);
                         if (t.w01 != 0.f && (far_h0 || far_w1)) atomicAdd(far + (i00 + 1) * Ci + e, gm * t.w01);
                         if (t.w10 != 0.f && (far_h1 || far_w0)) atomicAdd(far + (i00 + W) * Ci + e, gm * t.w10);
@@ -238,12 +270,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
                     s_y += __shfl_xor(s_y, ofs, 64);
                     s_x += __shfl_xor(s_x, ofs, 64);
                 }
-                if (lg == 0) {
+                if (lg == 0 && live[u]) {
                     float* d = g.dcn_dom + (int64_t)m * g.dcn_omld;
-                    const float vy = s_y * mk, vx = s_x * mk, vm = s_m * mk * (1.f - mk);
+                    const float vy = s_y * mk[u], vx = s_x * mk[u], vm = s_m * mk[u] * (1.f - mk[u]);
                     if (whole) { d[2 * k] = vy; d[2 * k + 1] = vx; d[18 + k] = vm; }
                     else { atomicAdd(d + 2 * k, vy); atomicAdd(d + 2 * k + 1, vx); atomicAdd(d + 18 + k, vm); }
                 }
+            }
             }
         } else {
             // fp32 (parity mode): per-lane accumulation straight from the MFMA registers, LDS fold across the channel waves
@@ -427,7 +460,7 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
     dim3 grid(cdiv(M, 128), cdiv(9 * Ci, bn), 1);
 #define CN_DOM(T, BN_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<T, BN_, BK_, true>), grid, dim3(256), 0, st, g)
     if (dtype == CN_BF16) {
-        const int bk = dy_ld % 64 == 0 ? (bn == 128 ? 32 : 64) : (dy_ld % 32 == 0 ? 32 : 16);
+        const int bk = dy_ld % 32 == 0 ? 32 : 16;     // BK=32 keeps the LDS footprint at ~31-41 KB -> 4-5 workgroups per CU
         if (bn == 128) { CN_DOM(bf16_t, 128, 32); }
         else if (bn == 64) { if (bk == 64) CN_DOM(bf16_t, 64, 64); else if (bk == 32) CN_DOM(bf16_t, 64, 32); else CN_DOM(bf16_t, 64, 16); }
         else { if (bk == 64) CN_DOM(bf16_t, 32, 64); else if (bk == 32) CN_DOM(bf16_t, 32, 32); else CN_DOM(bf16_t, 32, 16); }
@@ -438,6 +471,26 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
     }
 #undef CN_DOM
     CN_LAUNCH_CHECK("cn_dcn_bwd_dom");
+    return CN_OK;
+}
+
+// Fused DCNv2 forward (sampling -> LDS -> MFMA, dcn_fused.hip): y = act(bias + sum_k W_k * mask_k * bilinear_k(x) [+ residual]).
+// wp = cn_pack_weight mode 1 of the layer weight ([Co_pad32][tap*Ci + ci]); om fp32 [P][om_ld]; bias fp32[Co] nullable.
+extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,
+                          int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(x && om && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "cn_dcn_fwd: bad args");
+    if (Ci % 16 != 0) CN_UNSUPPORTED("cn_dcn_fwd: Ci=%d must be a multiple of 16", Ci);
+    if (N > 65535) CN_UNSUPPORTED("cn_dcn_fwd: batch %d", N);
+    if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_dcn_fwd: bad dtype %d", dtype);
+    CN_CHECK_ARG(om_ld >= 27 && x_ld >= Ci && y_ld >= Co, "cn_dcn_fwd: bad pitches");
+    ConvGeom g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.w = wp; g.bias = bias; g.y = y;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld;
+    g.ktot = 9 * Ci; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu; g.so = 1; g.sm = 1;
+    g.dcn_om = om; g.dcn_omld = om_ld;
+    dcn_fwd_launch(g, dtype, (hipStream_t)stream);
+    CN_LAUNCH_CHECK("cn_dcn_fwd");
     return CN_OK;
 }
 

@@ -266,6 +266,30 @@ static void launch_wgrad(WgradGeom& g, int taps, hipStream_t st) {
     hipLaunchKernelGGL((conv_wgrad_kernel<T, BMW, BNW>), grid, dim3(256), 0, st, g);
 }
 
+static int launch_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype, hipStream_t st) {
+    const int V = dtype == CN_F32 ? 4 : 8;
+    const int CV = (Co + V - 1) / V;
+    const int CVB = CV < 256 ? CV : 256;
+    const int RPB = 256 / CVB;
+    int64_t nblk = (P + (int64_t)RPB * 16 - 1) / ((int64_t)RPB * 16);
+    if (nblk > 512) nblk = 512;
+    if (nblk < 1) nblk = 1;
+    const int64_t rows_per_blk = (P + nblk - 1) / nblk;
+    dim3 grid((int)nblk, (CV + CVB - 1) / CVB);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, db, P, Co, dy_ld, CVB,
+                                                   rows_per_blk));
+    CN_LAUNCH_CHECK("colsum");
+    return CN_OK;
+}
+
+// db[c] += sum_p dy[p][c]  (bias gradient on its own; db is accumulated into)
+extern "C" int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype, void* stream) {
+    CN_CHECK_ARG(dy && db && P > 0 && Co > 0, "cn_colsum: bad args");
+    const int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(dy_ld % V == 0 && dy_ld >= ((Co + V - 1) / V) * V, "cn_colsum: dy_ld must be a vector multiple covering Co");
+    return launch_colsum(dy, db, P, Co, dy_ld, dtype, (hipStream_t)stream);
+}
+
 extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
                                int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                                int KH, int KW, int stride, int pad, int dtype, void* stream) {
@@ -307,17 +331,8 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float*
 #undef CN_WG
     CN_LAUNCH_CHECK("cn_conv2d_wgrad");
     if (db) {
-        const int CV = (Co + V - 1) / V;
-        const int CVB = CV < 256 ? CV : 256;
-        const int RPB = 256 / CVB;
-        int64_t nblk = (g.P + (int64_t)RPB * 16 - 1) / ((int64_t)RPB * 16);
-        if (nblk > 512) nblk = 512;
-        if (nblk < 1) nblk = 1;
-        const int64_t rows_per_blk = (g.P + nblk - 1) / nblk;
-        dim3 grid((int)nblk, (CV + CVB - 1) / CVB);
-        CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(colsum_kernel<T>, grid, dim3(256), 0, st, (const T*)dy, db, g.P, Co,
-                                                       dy_ld, CVB, rows_per_blk));
-        CN_LAUNCH_CHECK("cn_conv2d_wgrad(bias)");
+        int rc = launch_colsum(dy, db, g.P, Co, dy_ld, dtype, st);
+        if (rc) return rc;
     }
     return CN_OK;
 }

@@ -6,7 +6,7 @@
 // tap group reads its shifted X rows straight out of the halo with the transposing LDS read (ds_read_b64_tr_b16) —
 // 9x (or 3x) more MFMA work per byte staged.  The next tile is prefetched into registers while the current one is
 // being multiplied; workgroups walk several tiles and flush their fp32 accumulators with one round of atomics.
-#include "common.h"
+#include "dcn_common.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -188,4 +188,194 @@ bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, 
     if (Co > 64) launch_w3<128, 64, 3>(g, st);      // 68.6 KB LDS, 96 accumulator registers
     else launch_w3<64, 64, 9>(g, st);               // 59 KB LDS, 144 accumulator registers
     return true;
+}
+
+
+// ================================================================================================ DCNv2 weight gradient
+// dWp[co][tap*Ci + ci] += sum_p dY[p][co] * (mask[p,tap] * bilinear(x[:, :, ci], pos(p,tap)))
+// Same halo-free tile scheme: the dY tile [128][BMW] is staged once per pixel tile; for every tap the sampled operand
+// [128][BNW] is rebuilt in LDS (geometry by 128 lanes, then four unconditional 16-byte corner loads per item) and
+// consumed with the transposing LDS read.  The 9x-wide column tensor is never materialised (nor kept from the forward).
+struct DcnWgradGeom {
+    const bf16_t* x;
+    const bf16_t* dy;
+    const float* om;
+    float* dwp;
+    int N, H, W, Ci, x_ld, Co, dy_ld, om_ld, ktot;
+    int tiles_h, tiles_w, ci_tiles;
+    int tiles_per_block;
+};
+
+template <int BMW, int BNW, int TAPS>
+__global__ __launch_bounds__(256) void dcn_wgrad_kernel(const DcnWgradGeom g) {
+    constexpr int YP = BMW + 32, XP = BNW + 32;
+    constexpr int YCG = BMW / 8, XCG = BNW / 8;
+    constexpr int BMP = W3_TH * W3_TW;                        // 128 pixels
+    constexpr int YV = (BMP * YCG + 255) / 256;
+    constexpr int XI = (BMP * XCG + 255) / 256;               // sampling items per thread
+    constexpr int WM = BMW / 2, WN = BNW / 2;
+    constexpr int MI = WM / 32, NJ = WN / 32;
+
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [128][YP] dY | [128][XP] sampled x
+    __shared__ int s_idx[4][BMP];
+    __shared__ float s_w[4][BMP];
+    bf16_t* const yt = lds;
+    bf16_t* const xt = lds + BMP * YP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co0 = (blockIdx.y / g.ci_tiles) * BMW, ci0 = (blockIdx.y % g.ci_tiles) * BNW;
+    const int tap0 = TAPS == 9 ? 0 : (int)blockIdx.z * 3;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int64_t t_beg = (int64_t)blockIdx.x * g.tiles_per_block;
+    const int64_t t_end = t_beg + g.tiles_per_block < ntiles ? t_beg + g.tiles_per_block : ntiles;
+    if (t_beg >= ntiles) return;
+
+    f32x16_t acc[TAPS][MI][NJ];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+    uint4 ry[YV];
+    auto yload = [&](int64_t tile) {
+        const int n = (int)(tile / (g.tiles_h * g.tiles_w));
+        const int r = (int)(tile - (int64_t)n * g.tiles_h * g.tiles_w);
+        const int th0 = (r / g.tiles_w) * W3_TH, tw0 = (r % g.tiles_w) * W3_TW;
+        const int64_t img = (int64_t)n * g.H * g.W;
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            const int idx = tid + v * 256;
+            const int px = idx / YCG, c = co0 + (idx % YCG) * 8;
+            const int oh = th0 + px / W3_TW, ow = tw0 + px % W3_TW;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (idx < BMP * YCG && oh < g.H && ow < g.W && c < g.Co)
+                val = *reinterpret_cast<const uint4*>(g.dy + (img + (int64_t)oh * g.W + ow) * g.dy_ld + c);
+            ry[v] = val;
+        }
+    };
+
+    yload(t_beg);
+    for (int64_t tile = t_beg; tile < t_end; ++tile) {
+        const int n = (int)(tile / (g.tiles_h * g.tiles_w));
+        const int rr = (int)(tile - (int64_t)n * g.tiles_h * g.tiles_w);
+        const int th0 = (rr / g.tiles_w) * W3_TH, tw0 = (rr % g.tiles_w) * W3_TW;
+        const int64_t img = (int64_t)n * g.H * g.W;
+        const bf16_t* __restrict__ X = g.x + img * g.x_ld + ci0;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            const int idx = tid + v * 256;
+            if (idx < BMP * YCG) *reinterpret_cast<uint4*>(yt + (idx / YCG) * YP + (idx % YCG) * 8) = ry[v];
+        }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int tap = tap0 + t;
+            if (tid < BMP) {
+                const int h = th0 + tid / W3_TW, w = tw0 + tid % W3_TW;
+                int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+                if (h < g.H && w < g.W) {
+                    const float* o = g.om + (img + (int64_t)h * g.W + w) * g.om_ld;
+                    const float py = (float)(h - 1 + tap / 3) + o[2 * tap];
+                    const float px = (float)(w - 1 + tap % 3) + o[2 * tap + 1];
+                    const float m = sigmoidf_(o[18 + tap]);
+                    const Tap tp = make_tap(py, px, g.H, g.W);
+                    const int hc0 = min(max(tp.h0, 0), g.H - 1), hc1 = min(max(tp.h0 + 1, 0), g.H - 1);
+                    const int wc0 = min(max(tp.w0, 0), g.W - 1), wc1 = min(max(tp.w0 + 1, 0), g.W - 1);
+                    i0 = hc0 * g.W + wc0; i1 = hc0 * g.W + wc1; i2 = hc1 * g.W + wc0; i3 = hc1 * g.W + wc1;
+                    w0 = tp.w00 * m; w1 = tp.w01 * m; w2 = tp.w10 * m; w3 = tp.w11 * m;
+                }
+                s_idx[0][tid] = i0; s_idx[1][tid] = i1; s_idx[2][tid] = i2; s_idx[3][tid] = i3;
+                s_w[0][tid] = w0; s_w[1][tid] = w1; s_w[2][tid] = w2; s_w[3][tid] = w3;
+            }
+            __syncthreads();                               // geometry (and, for t == 0, the dY tile) visible
+#pragma unroll
+            for (int ip = 0; ip < XI; ++ip) {
+                const int it = tid + ip * 256;
+                if (it < BMP * XCG) {
+                    const int pl = it / XCG, col = (it % XCG) * 8;
+                    float v0[8], v1[8], v2[8], v3[8], a[8];
+                    const bool cok = ci0 + col < g.Ci;
+                    const bf16_t* src = X + (cok ? col : 0);
+                    Vec16<bf16_t>::load(src + (int64_t)s_idx[0][pl] * g.x_ld, v0);
+                    Vec16<bf16_t>::load(src + (int64_t)s_idx[1][pl] * g.x_ld, v1);
+                    Vec16<bf16_t>::load(src + (int64_t)s_idx[2][pl] * g.x_ld, v2);
+                    Vec16<bf16_t>::load(src + (int64_t)s_idx[3][pl] * g.x_ld, v3);
+                    const float w0 = cok ? s_w[0][pl] : 0.f, w1 = cok ? s_w[1][pl] : 0.f, w2 = cok ? s_w[2][pl] : 0.f, w3 = cok ? s_w[3][pl] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] = v0[j] * w0 + v1[j] * w1 + v2[j] * w2 + v3[j] * w3;
+                    Vec16<bf16_t>::store(xt + pl * XP + col, a);
+                }
+            }
+            __syncthreads();
+            if (t == 0 && tile + 1 < t_end) yload(tile + 1);   // next dY tile in flight during this tile's MFMAs
+#pragma unroll
+            for (int kk = 0; kk < W3_TH; ++kk) {
+                bf16x8_t fa[MI], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = tr_frag16(yt, YP, wm + i * 32, kk * W3_TW, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = tr_frag16(xt, XP, wn + j * 32, kk * W3_TW, lane);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
+            }
+            __syncthreads();                               // xt / geometry may be overwritten by the next tap
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        const int tap = tap0 + t;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int ci = ci0 + wn + j * 32 + (lane & 31);
+                if (ci >= g.Ci) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (co < g.Co) atomicAdd(g.dwp + (int64_t)co * g.ktot + (int64_t)tap * g.Ci + ci, acc[t][i][j][r]);
+                }
+            }
+    }
+}
+
+template <int BMW, int BNW, int TAPS>
+static void launch_dw(DcnWgradGeom& g, hipStream_t st) {
+    const int co_tiles = cdiv(g.Co, BMW);
+    g.ci_tiles = cdiv(g.Ci, BNW);
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
+    int64_t want = (1536 + par - 1) / par;
+    if (want > ntiles) want = ntiles;
+    if (want < 1) want = 1;
+    g.tiles_per_block = (int)((ntiles + want - 1) / want);
+    const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    const size_t smem = ((size_t)W3_TH * W3_TW * (BMW + 32) + (size_t)W3_TH * W3_TW * (BNW + 32)) * sizeof(bf16_t);
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)dcn_wgrad_kernel<BMW, BNW, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((dcn_wgrad_kernel<BMW, BNW, TAPS>), dim3(gx, co_tiles * g.ci_tiles, TAPS == 9 ? 1 : 3), dim3(256), smem, st, g);
+}
+
+extern "C" int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
+                            int Co, int dy_ld, int om_ld, int dtype, void* stream) {
+    CN_CHECK_ARG(x && om && dy && dwp && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "cn_dcn_wgrad: bad args");
+    if (dtype != CN_BF16) CN_UNSUPPORTED("cn_dcn_wgrad: bf16 only (fp32 parity mode goes through cn_dcn_im2col + cn_conv2d_wgrad)");
+    if (Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) CN_UNSUPPORTED("cn_dcn_wgrad: channel counts must be multiples of 8");
+    DcnWgradGeom g;
+    g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.om = om; g.dwp = dwp;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.om_ld = om_ld; g.ktot = 9 * Ci;
+    g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
+    if (Co > 64) launch_dw<128, 64, 3>(g, (hipStream_t)stream);
+    else launch_dw<64, 64, 9>(g, (hipStream_t)stream);
+    CN_LAUNCH_CHECK("cn_dcn_wgrad");
+    return CN_OK;
 }

@@ -163,9 +163,12 @@ class DCN(nn.Module):
             self._cache = {"k": key, "wp": wp, "b": (self.bias.detach() * scale + shift).contiguous()}
         N, H, W, Ci = x.shape
         om = self.conv_offset_mask.infer(x, None, None, None, False, out_dtype=torch.float32)
-        col = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
-        ops.call("cn_dcn_im2col", x, om, col, N, H, W, Ci, Ci, om.shape[-1], ops.dtype_code(x.dtype))
-        return ops._igemm(col, self._cache["wp"], self._cache["b"], None, self.weight.shape[0], 1, 1, 1, 0, False, relu, H, W)
+        Co = self.weight.shape[0]
+        cp = ops.rup(Co, 16)
+        y = (torch.empty if cp == Co else torch.zeros)((N, H, W, cp), dtype=x.dtype, device=x.device)
+        ops.call("cn_dcn_fwd", x, om, self._cache["wp"], self._cache["b"], y, N, H, W, Ci, Ci, Co, cp, om.shape[-1], int(relu),
+                 ops.dtype_code(x.dtype))
+        return y
 
 
 class MaxPool2d(nn.Module):

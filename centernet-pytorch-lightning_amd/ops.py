@@ -441,10 +441,17 @@ class DCNv2Fn(Function):
         # offsets / mask logits stay fp32 in both compute modes: sampling coordinates must not be quantised to bf16
         om = _igemm(x, pack_weight(om_weight, 1, x.dtype), om_bias.detach(), None, 27, 3, 3, 1, 1, False, False, H, W,
                     out_dtype=torch.float32)
-        col = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
-        call("cn_dcn_im2col", x, om, col, N, H, W, Ci, Ci, om.shape[-1], dt)
-        wp = pack_weight(weight, 1, x.dtype)                  # [Co_pad][9*Ci]: a 1x1 conv over the columns
-        y = _igemm(col, wp, bias.detach(), None, Co, 1, 1, 1, 0, False, False, H, W)
+        wp = pack_weight(weight, 1, x.dtype)                  # [Co_pad][9*Ci]
+        if _DCN_UNFUSED:
+            col = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
+            call("cn_dcn_im2col", x, om, col, N, H, W, Ci, Ci, om.shape[-1], dt)
+            y = _igemm(col, wp, bias.detach(), None, Co, 1, 1, 1, 0, False, False, H, W)   # a 1x1 conv over the columns
+        else:
+            # fused: bilinear sampling writes the MFMA operand tile in LDS, no column tensor
+            cp = rup(Co, 16)
+            y = (torch.empty if cp == Co else torch.zeros)((N, H, W, cp), dtype=x.dtype, device=x.device)
+            call("cn_dcn_fwd", x, om, wp, bias.detach(), y, N, H, W, Ci, Ci, Co, cp, om.shape[-1], 0, dt)
+            col = None
         ctx.save_for_backward(x, om, col, weight, om_weight)
         ctx.params = (bias, om_weight, om_bias)
         return y
@@ -459,12 +466,27 @@ class DCNv2Fn(Function):
         # main weight / bias: 1x1 wgrad over the sampled columns
         side = SideGrads.usable(weight, ctx.params[0], ctx.params[1], ctx.params[2])
         dw = db = dw_om = db_om = None
+        def main_wgrad(db_into, want_bias):
+            """dW / db of the deformable conv: fused re-sampling kernel in bf16, im2col + GEMM in fp32 parity mode"""
+            if x.dtype == torch.bfloat16 and not _DCN_UNFUSED:
+                dwp_ = torch.zeros((rup(Co, 32), 9 * Ci), dtype=torch.float32, device=x.device)
+                call("cn_dcn_wgrad", x, om, dy, dwp_, N, H, W, Ci, Ci, Co, dy.shape[-1], om.shape[-1], dt)
+                db_ = db_into if db_into is not None else (torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None)
+                if db_ is not None:
+                    call("cn_colsum", dy, db_, N * H * W, Co, dy.shape[-1], dt)
+                return dwp_, db_
+            c = col
+            if c is None:
+                c = torch.empty((N, H, W, 9 * Ci), dtype=x.dtype, device=x.device)
+                call("cn_dcn_im2col", x, om, c, N, H, W, Ci, Ci, om.shape[-1], dt)
+            return _wgrad(c, dy, Co, 1, 1, 1, 0, want_bias, db_into=db_into)
+
         if side:
-            with SideGrads.fork(col, dy):
-                dwp, _ = _wgrad(col, dy, Co, 1, 1, 1, 0, False, db_into=ctx.params[0].grad)
+            with SideGrads.fork(x, om, dy, col):
+                dwp, _ = main_wgrad(ctx.params[0].grad, False)
                 unpack_wgrad(dwp, Co, Ci, 3, 3, into=weight.grad)
         else:
-            dwp, db = _wgrad(col, dy, Co, 1, 1, 1, 0, True)
+            dwp, db = main_wgrad(None, True)
             dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
         dx_far = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
         dom32 = torch.zeros_like(om)

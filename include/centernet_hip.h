@@ -77,6 +77,9 @@ int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
                     int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                     int KH, int KW, int stride, int pad, int dtype, void* stream);
 
+/* bias gradient alone: db[c] += sum_p dy[p][c] (db accumulated into; dy_ld a vector multiple) */
+int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype, void* stream);
+
 /* Stem convolution for tiny Ci (3 input channels, 7x7): direct kernel on the NCHW fp32 image
  * (msra_resnet.py:110, pose_dla_dcn.py:282).  w is the raw fp32 parameter [Co,Ci,KH,KW]. */
 int cn_stem_conv_fwd(const float* x_nchw, const float* w, void* y, int N, int Ci, int H, int W, int Co,
@@ -128,6 +131,14 @@ int cn_dcn_im2col(const void* x, const float* om, void* col, int N, int H, int W
  * channels 0..26 are overwritten. */
 int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_tile, float* dx_far, float* dom,
                   int N, int H, int W, int Ci, int x_ld, int om_ld, int dtype, void* stream);
+/* Fused DCNv2 forward: bilinear sampling straight into the MFMA operand tile in LDS — no column tensor in HBM.
+ * y = act(bias + sum_k W_k * sigmoid(om[18+k]) * bilinear_k(x)); wp = cn_pack_weight mode 1 ([Co_pad32][tap*Ci + ci]). */
+int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,
+               int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, void* stream);
+/* Fused DCNv2 weight gradient (bf16): dwp[co][tap*Ci+ci] += sum_p dy[p][co] * sampled_x[p,tap][ci], the sampled operand
+ * rebuilt per tap in LDS (no column tensor).  dwp fp32 [Co_pad32][9*Ci], zeroed by the caller.  fp32 -> CN_EUNSUPPORTED. */
+int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
+                 int Co, int dy_ld, int om_ld, int dtype, void* stream);
 /* Fused DCNv2 backward (no column gradient in HBM), used instead of cn_dcn_col2im:
  *   cn_dcn_bwd_dom: GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2) whose epilogue reduces dcol against the bilinear
  *     corner differences of x -> dom fp32 [P][om_ld] (channels 0..26; zeroed by the caller when Ci > 128), and scatters
