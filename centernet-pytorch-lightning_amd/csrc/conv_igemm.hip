@@ -444,6 +444,10 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
     CN_CHECK_ARG(dy && wpd2 && x && om && dom && dx_far && N > 0 && H > 0 && W > 0, "cn_dcn_bwd_dom: bad args");
     if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dom: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
     CN_CHECK_ARG(om_ld >= 27 && x_ld >= Ci, "cn_dcn_bwd_dom: bad pitches");
+    if (dtype == CN_BF16 && dcn_bwd_dom_tile_launch(dy, wpd2, x, om, dom, dx_far, N, H, W, Ci, Co, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_dcn_bwd_dom(tile)");
+        return CN_OK;
+    }
     ConvGeom g;
     memset(&g, 0, sizeof(g));
     g.x = dy; g.w = wpd2; g.y = dom;

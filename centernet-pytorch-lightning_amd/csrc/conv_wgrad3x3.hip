@@ -272,18 +272,23 @@ __global__ __launch_bounds__(256) void dcn_wgrad_kernel(const DcnWgradGeom g) {
             const int idx = tid + v * 256;
             if (idx < BMP * YCG) *reinterpret_cast<uint4*>(yt + (idx / YCG) * YP + (idx % YCG) * 8) = ry[v];
         }
+        // offsets / mask logit are fetched one tap ahead
+        const int gh_ = th0 + (tid & (BMP - 1)) / W3_TW, gw_ = tw0 + (tid & (BMP - 1)) % W3_TW;
+        const bool glive = tid < BMP && gh_ < g.H && gw_ < g.W;
+        const float* const orow = g.om + (img + (int64_t)(glive ? gh_ : 0) * g.W + (glive ? gw_ : 0)) * g.om_ld;
+        float ro[3] = {0.f, 0.f, 0.f};
+        if (glive) { ro[0] = orow[2 * tap0]; ro[1] = orow[2 * tap0 + 1]; ro[2] = orow[18 + tap0]; }
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int tap = tap0 + t;
             if (tid < BMP) {
-                const int h = th0 + tid / W3_TW, w = tw0 + tid % W3_TW;
+                const int h = gh_, w = gw_;
                 int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
                 float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-                if (h < g.H && w < g.W) {
-                    const float* o = g.om + (img + (int64_t)h * g.W + w) * g.om_ld;
-                    const float py = (float)(h - 1 + tap / 3) + o[2 * tap];
-                    const float px = (float)(w - 1 + tap % 3) + o[2 * tap + 1];
-                    const float m = sigmoidf_(o[18 + tap]);
+                if (glive) {
+                    const float py = (float)(h - 1 + tap / 3) + ro[0];
+                    const float px = (float)(w - 1 + tap % 3) + ro[1];
+                    const float m = sigmoidf_(ro[2]);
                     const Tap tp = make_tap(py, px, g.H, g.W);
                     const int hc0 = min(max(tp.h0, 0), g.H - 1), hc1 = min(max(tp.h0 + 1, 0), g.H - 1);
                     const int wc0 = min(max(tp.w0, 0), g.W - 1), wc1 = min(max(tp.w0 + 1, 0), g.W - 1);
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(256) void dcn_wgrad_kernel(const DcnWgradGeom g) {
                 s_w[0][tid] = w0; s_w[1][tid] = w1; s_w[2][tid] = w2; s_w[3][tid] = w3;
             }
             __syncthreads();                               // geometry (and, for t == 0, the dY tile) visible
+            if (glive && t + 1 < TAPS) { ro[0] = orow[2 * (tap + 1)]; ro[1] = orow[2 * (tap + 1) + 1]; ro[2] = orow[18 + tap + 1]; }
 #pragma unroll
             for (int ip = 0; ip < XI; ++ip) {
                 const int it = tid + ip * 256;

@@ -11,6 +11,7 @@
 // Samples displaced by more than R pixels are not seen here: cn_dcn_bwd_dom scatters those into dx_far, which this
 // kernel adds in its epilogue (fp32 residual).  No atomics on HBM, dcol is never written.
 #include "conv_common.h"
+#include <stdlib.h>
 
 #define DX_TH 8
 #define DX_TW 16
@@ -86,19 +87,38 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
 
     const int nchunks = g.Ci / CK;          // g.Ci = padded Co of the forward layer = contraction length per tap
     bload(0, 0);
+    // the offsets of the next tap's sources are fetched one tap ahead (no exposed latency in the list-building phase)
+    constexpr int NSRC = (SH * SW + 255) / 256;
+    float so[NSRC][3];
+    auto oload = [&](int tap) {
+#pragma unroll
+        for (int si = 0; si < NSRC; ++si) {
+            const int s = tid + si * 256;
+            const int sy = th0 - DX_R + s / SW, sx = tw0 - DX_R + s % SW;
+            so[si][0] = so[si][1] = so[si][2] = 0.f;
+            if (s < SH * SW && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W) {
+                const float* o = OM + ((int64_t)sy * g.W + sx) * g.dcn_omld;
+                so[si][0] = o[2 * tap]; so[si][1] = o[2 * tap + 1]; so[si][2] = o[18 + tap];
+            }
+        }
+    };
+    oload(0);
     int step = 0;                            // (tap, chunk) steps; weight slice `step` lives in buffer step & 1
     for (int tap = 0; tap < 9; ++tap) {
         // ---- 1. hit lists of this tap ----
         for (int i = tid; i < BM; i += 256) hit_n[i] = 0;
         if (tid == 0) ovf_n = 0;
         __syncthreads();
-        for (int s = tid; s < SH * SW; s += 256) {
+#pragma unroll
+        for (int si = 0; si < NSRC; ++si) {
+            const int s = tid + si * 256;
+            if (s >= SH * SW) continue;
             const int sy = th0 - DX_R + s / SW, sx = tw0 - DX_R + s % SW;
             if ((unsigned)sy >= (unsigned)g.H || (unsigned)sx >= (unsigned)g.W) continue;
             const int sp = sy * g.W + sx;
-            const float* o = OM + (int64_t)sp * g.dcn_omld;
-            const float py = (float)(sy - 1 + tap / 3) + o[2 * tap];
-            const float px = (float)(sx - 1 + tap % 3) + o[2 * tap + 1];
+            const float py = (float)(sy - 1 + tap / 3) + so[si][0];
+            const float px = (float)(sx - 1 + tap % 3) + so[si][1];
+            const float mlogit = so[si][2];
             const int y0 = (int)floorf(py), x0 = (int)floorf(px);
             const float ly = py - (float)y0, lx = px - (float)x0;
             float m = -1.f;
@@ -110,7 +130,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
                 if (qy - sy > DX_R || sy - qy > DX_R || qx - sx > DX_R || sx - qx > DX_R) continue;   // far: handled by dx_far
                 const float wgt = ((cnr >> 1) ? ly : 1.f - ly) * ((cnr & 1) ? lx : 1.f - lx);
                 if (!(wgt > 0.f)) continue;
-                if (m < 0.f) m = sigmoidf_(o[18 + tap]);
+                if (m < 0.f) m = sigmoidf_(mlogit);
                 const int ql = ty * DX_TW + tx;
                 const int slot = atomicAdd(&hit_n[ql], 1);
                 if (slot < DX_MAXH) { hit_p[ql][slot] = sp; hit_w[ql][slot] = wgt * m; }
@@ -121,6 +141,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
             }
         }
         __syncthreads();
+        if (tap < 8) oload(tap + 1);
         for (int ch = 0; ch < nchunks; ++ch, ++step) {
             const int c0 = ch * CK;
             // ---- 2. G tile of this (tap, channel slice) ----
@@ -288,16 +309,21 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(const ConvGeom g) {
 
     const int nchunks = g.Ci / CK;
     bload(0, 0);
+    // offsets / mask logit of the NEXT tap are fetched while the current tap is sampled and multiplied
+    const int gh_ = th0 + (tid & (BM - 1)) / DX_TW, gw_ = tw0 + (tid & (BM - 1)) % DX_TW;
+    const bool glive = tid < BM && gh_ < g.H && gw_ < g.W;
+    const float* const orow = OM + ((int64_t)(glive ? gh_ : 0) * g.W + (glive ? gw_ : 0)) * g.dcn_omld;
+    float ro[3] = {0.f, 0.f, 0.f};
+    if (glive) { ro[0] = orow[0]; ro[1] = orow[1]; ro[2] = orow[18]; }
     for (int tap = 0; tap < 9; ++tap) {
         if (tid < BM) {
-            const int h = th0 + tid / DX_TW, w = tw0 + tid % DX_TW;
+            const int h = gh_, w = gw_;
             int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
             float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-            if (h < g.H && w < g.W) {
-                const float* o = OM + ((int64_t)h * g.W + w) * g.dcn_omld;
-                const float py = (float)(h - 1 + tap / 3) + o[2 * tap];
-                const float px = (float)(w - 1 + tap % 3) + o[2 * tap + 1];
-                const float m = sigmoidf_(o[18 + tap]);
+            if (glive) {
+                const float py = (float)(h - 1 + tap / 3) + ro[0];
+                const float px = (float)(w - 1 + tap % 3) + ro[1];
+                const float m = sigmoidf_(ro[2]);
                 const Tap t = make_tap(py, px, g.H, g.W);
                 const int hc0 = min(max(t.h0, 0), g.H - 1), hc1 = min(max(t.h0 + 1, 0), g.H - 1);
                 const int wc0 = min(max(t.w0, 0), g.W - 1), wc1 = min(max(t.w0 + 1, 0), g.W - 1);
@@ -308,6 +334,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(const ConvGeom g) {
             s_w[0][tid] = w0; s_w[1][tid] = w1; s_w[2][tid] = w2; s_w[3][tid] = w3;
         }
         __syncthreads();
+        if (glive && tap < 8) { ro[0] = orow[2 * (tap + 1)]; ro[1] = orow[2 * (tap + 1) + 1]; ro[2] = orow[18 + tap + 1]; }
         for (int ch = 0; ch < nchunks; ++ch) {
             const int c0 = ch * CK;
 #pragma unroll
@@ -386,4 +413,208 @@ void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     } else {
         if (bn == 128) launch_fwd<float, 128, 16>(g, st); else if (bn == 64) launch_fwd<float, 64, 16>(g, st); else launch_fwd<float, 32, 16>(g, st);
     }
+}
+
+
+// ================================================================================================ offset / mask gradient
+// dom[p][2k], dom[p][2k+1], dom[p][18+k]  (see cn_dcn_bwd_dom) with every operand tile-resident:
+//   * the dY tile [128][Co] (A operand) and the x HALO tile [(8+7)x(16+7)][64] are loaded once per workgroup;
+//   * per tap: weight slice [64 ci][Co] -> LDS, MFMA (K = Co) gives dcol_k [128][64] in registers -> LDS (bf16);
+//     8 lanes per pixel then dot dcol against the bilinear corner combinations read from the halo tile in LDS
+//     (16-byte ds reads instead of 36 L2 gathers per pixel), shuffle-reduce, one store per (pixel, tap).
+// Corners that fall outside the halo (offsets beyond about +-2 px) are fetched from global memory; samples displaced by more
+// than DCN_FAR_R pixels are scattered into dx_far.  512 threads = 8 waves, one 32x32 MFMA block each.  bf16 only.
+#define DM_HR 3                       // halo reaches from -3 to +4 around the tile
+#define DM_HH (DX_TH + 7)
+#define DM_HW (DX_TW + 7)
+#define DM_HP (DM_HH * DM_HW)
+
+struct DomGeom {
+    const bf16_t* dy; const bf16_t* wd2; const bf16_t* x; const float* om; float* dom; float* far;
+    int N, H, W, Ci, Co, dy_ld, x_ld, om_ld;
+};
+
+template <int COP>   // padded Co (contraction length): 64 or 128
+__global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
+    constexpr int BM = DX_TH * DX_TW, BN = 64;
+    constexpr int AP = COP + 8;                 // dY tile / weight slice pitch
+    constexpr int DP = BN + 8;                  // dcol tile / halo pitch
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* const As = lds;                     // [128][AP]
+    bf16_t* const Bs = As + BM * AP;            // [64][AP]
+    bf16_t* const Ds = Bs + BN * AP;            // [128][DP]
+    bf16_t* const Xh = Ds + BM * DP;            // [DM_HP][DP]
+    __shared__ float s_lh[BM], s_lw[BM], s_m[BM];
+    __shared__ int s_h0[BM], s_w0[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_w = (g.W + DX_TW - 1) / DX_TW;
+    const int th0 = (blockIdx.x / tiles_w) * DX_TH, tw0 = (blockIdx.x % tiles_w) * DX_TW;
+    const int ci0 = blockIdx.y * BN;
+    const int n = blockIdx.z;
+    const int64_t img = (int64_t)n * g.H * g.W;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const bool whole = g.Ci == BN;
+
+    // ---- stage dY tile and x halo tile ----
+    for (int v = tid; v < BM * (COP / 8); v += 512) {
+        const int pl = v / (COP / 8), col = (v % (COP / 8)) * 8;
+        const int h = th0 + pl / DX_TW, w = tw0 + pl % DX_TW;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (h < g.H && w < g.W && col < g.dy_ld) val = *reinterpret_cast<const uint4*>(g.dy + (img + (int64_t)h * g.W + w) * g.dy_ld + col);
+        *reinterpret_cast<uint4*>(As + pl * AP + col) = val;
+    }
+    for (int v = tid; v < DM_HP * (BN / 8); v += 512) {
+        const int hp = v / (BN / 8), col = (v % (BN / 8)) * 8;
+        const int h = th0 - DM_HR + hp / DM_HW, w = tw0 - DM_HR + hp % DM_HW;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if ((unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W)
+            val = *reinterpret_cast<const uint4*>(g.x + (img + (int64_t)h * g.W + w) * g.x_ld + ci0 + col);
+        *reinterpret_cast<uint4*>(Xh + hp * DP + col) = val;
+    }
+
+    // Software pipeline: the next tap's weight slice (COP/64 x 16 B per thread) and offset triple are fetched into registers
+    // while the current tap is multiplied and reduced, so a tap exposes no global-memory latency.
+    constexpr int BV = BN * (COP / 8) / 512;         // 16-byte vectors of the weight slice per thread
+    uint4 rb[BV];
+    float ro[3] = {0.f, 0.f, 0.f};
+    const int gh = th0 + (tid & (BM - 1)) / DX_TW, gw = tw0 + (tid & (BM - 1)) % DX_TW;
+    const bool glive = tid < BM && gh < g.H && gw < g.W;
+    const float* const orow = g.om + (img + (int64_t)(glive ? gh : 0) * g.W + (glive ? gw : 0)) * g.om_ld;
+    auto prefetch = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            const int v = tid + i * 512;
+            const int row = v / (COP / 8), col = (v % (COP / 8)) * 8;
+            rb[i] = *reinterpret_cast<const uint4*>(g.wd2 + ((int64_t)tap * g.Ci + ci0 + row) * COP + col);
+        }
+        if (glive) { ro[0] = orow[2 * tap]; ro[1] = orow[2 * tap + 1]; ro[2] = orow[18 + tap]; }
+    };
+    prefetch(0);
+    for (int tap = 0; tap < 9; ++tap) {
+        // weight slice: rows tap*Ci + ci0 .. +63 of the mode-2 packed matrix [9*Ci][COP]
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            const int v = tid + i * 512;
+            *reinterpret_cast<uint4*>(Bs + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8) = rb[i];
+        }
+        if (tid < BM) {
+            float py = 0.f, px = 0.f, m = 0.f;
+            if (glive) {
+                py = (float)(gh - 1 + tap / 3) + ro[0];
+                px = (float)(gw - 1 + tap % 3) + ro[1];
+                m = sigmoidf_(ro[2]);
+            }
+            const float fh = floorf(py), fw = floorf(px);
+            s_h0[tid] = (int)fh; s_w0[tid] = (int)fw; s_lh[tid] = py - fh; s_lw[tid] = px - fw; s_m[tid] = m;
+        }
+        __syncthreads();
+        if (tap < 8) prefetch(tap + 1);
+        // ---- dcol_k tile = dY tile x W_k^T : one 32x32 block per wave ----
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < COP / 16; ++kk) {
+            const bf16x8_t fa = Mma<bf16_t>::load(As, AP, wm, kk, lane);     // pixels
+            const bf16x8_t fb = Mma<bf16_t>::load(Bs, AP, wn, kk, lane);     // channels (ci)
+            acc = Mma<bf16_t>::mma(fb, fa, acc);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint2 o;
+            o.x = (uint32_t)f2bf(acc[q * 4 + 0]) | ((uint32_t)f2bf(acc[q * 4 + 1]) << 16);
+            o.y = (uint32_t)f2bf(acc[q * 4 + 2]) | ((uint32_t)f2bf(acc[q * 4 + 3]) << 16);
+            *reinterpret_cast<uint2*>(Ds + (wm + (lane & 31)) * DP + wn + 8 * q + 4 * (lane >> 5)) = o;
+        }
+        __syncthreads();
+        // ---- per (pixel, 8-channel slice): corner combinations from the halo tile ----
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int it = tid + rep * 512;
+            const int pl = it >> 3, lg = it & 7;
+            const int h = th0 + pl / DX_TW, w = tw0 + pl % DX_TW;
+            const bool live = h < g.H && w < g.W;
+            const int h0 = s_h0[pl], w0 = s_w0[pl];
+            const float lh = s_lh[pl], lw = s_lw[pl], mk = s_m[pl];
+            const int hy = h0 - (th0 - DM_HR), hx = w0 - (tw0 - DM_HR);       // halo coordinates of corner 00
+            float x00[8], x01[8], x10[8], x11[8], gc[8];
+            if (hy >= 0 && hy + 1 < DM_HH && hx >= 0 && hx + 1 < DM_HW) {     // all four corners inside the LDS halo (zeros outside the image)
+                const bf16_t* b = Xh + (hy * DM_HW + hx) * DP + lg * 8;
+                Vec16<bf16_t>::load(b, x00);
+                Vec16<bf16_t>::load(b + DP, x01);
+                Vec16<bf16_t>::load(b + DM_HW * DP, x10);
+                Vec16<bf16_t>::load(b + DM_HW * DP + DP, x11);
+            } else {                                                          // rare: fetch from global, zero outside the image
+                auto gl = [&](int hh, int ww, float* out) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) out[e] = 0.f;
+                    if ((unsigned)hh < (unsigned)g.H && (unsigned)ww < (unsigned)g.W)
+                        Vec16<bf16_t>::load(g.x + (img + (int64_t)hh * g.W + ww) * g.x_ld + ci0 + lg * 8, out);
+                };
+                gl(h0, w0, x00); gl(h0, w0 + 1, x01); gl(h0 + 1, w0, x10); gl(h0 + 1, w0 + 1, x11);
+            }
+            Vec16<bf16_t>::load(Ds + pl * DP + lg * 8, gc);
+            const float a00 = (1.f - lh) * (1.f - lw), a01 = (1.f - lh) * lw, a10 = lh * (1.f - lw), a11 = lh * lw;
+            float sm = 0.f, sy = 0.f, sx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sm = fmaf(gc[e], x00[e] * a00 + x01[e] * a01 + x10[e] * a10 + x11[e] * a11, sm);
+                sy = fmaf(gc[e], (1.f - lw) * (x10[e] - x00[e]) + lw * (x11[e] - x01[e]), sy);
+                sx = fmaf(gc[e], (1.f - lh) * (x01[e] - x00[e]) + lh * (x11[e] - x10[e]), sx);
+            }
+            // far samples (the adjoint-gather window of cn_dcn_bwd_dx cannot see them)
+            const int dh0 = h0 - h, dw0 = w0 - w;
+            const bool far_h0 = dh0 > DCN_FAR_R || dh0 < -DCN_FAR_R, far_h1 = dh0 + 1 > DCN_FAR_R || dh0 + 1 < -DCN_FAR_R;
+            const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
+            if (live && (far_h0 || far_h1 || far_w0 || far_w1)) {
+                const bool in_h0 = (unsigned)h0 < (unsigned)g.H, in_h1 = (unsigned)(h0 + 1) < (unsigned)g.H;
+                const bool in_w0 = (unsigned)w0 < (unsigned)g.W, in_w1 = (unsigned)(w0 + 1) < (unsigned)g.W;
+                float* far = g.far + (img + (int64_t)h0 * g.W + w0) * g.Ci + ci0 + lg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gm = gc[e] * mk;
+                    if (in_h0 && in_w0 && a00 != 0.f && (far_h0 || far_w0)) atomicAdd(far + e, gm * a00);
+                    if (in_h0 && in_w1 && a01 != 0.f && (far_h0 || far_w1)) atomicAdd(far + g.Ci + e, gm * a01);
+                    if (in_h1 && in_w0 && a10 != 0.f && (far_h1 || far_w0)) atomicAdd(far + (int64_t)g.W * g.Ci + e, gm * a10);
+                    if (in_h1 && in_w1 && a11 != 0.f && (far_h1 || far_w1)) atomicAdd(far + (int64_t)(g.W + 1) * g.Ci + e, gm * a11);
+                }
+            }
+#pragma unroll
+            for (int ofs = 4; ofs > 0; ofs >>= 1) {
+                sm += __shfl_xor(sm, ofs, 64);
+                sy += __shfl_xor(sy, ofs, 64);
+                sx += __shfl_xor(sx, ofs, 64);
+            }
+            if (lg == 0 && live) {
+                float* d = g.dom + (img + (int64_t)h * g.W + w) * g.om_ld;
+                const float vy = sy * mk, vx = sx * mk, vm = sm * mk * (1.f - mk);
+                if (whole) { d[2 * tap] = vy; d[2 * tap + 1] = vx; d[18 + tap] = vm; }
+                else { atomicAdd(d + 2 * tap, vy); atomicAdd(d + 2 * tap + 1, vx); atomicAdd(d + 18 + tap, vm); }
+            }
+        }
+        __syncthreads();      // Bs / Ds / geometry are rewritten by the next tap
+    }
+}
+
+// returns false when the shape is not handled by the tile-resident kernel
+bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, float* far,
+                             int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_DOM_TILE") != nullptr;
+    if (disabled || Ci % 64 != 0 || (dy_ld != 64 && dy_ld != 128) || N > 65535) return false;
+    (void)Co;
+    DomGeom g;
+    g.dy = (const bf16_t*)dy; g.wd2 = (const bf16_t*)wd2; g.x = (const bf16_t*)x; g.om = om; g.dom = dom; g.far = far;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.dy_ld = dy_ld; g.x_ld = x_ld; g.om_ld = om_ld;
+    dim3 grid(((H + DX_TH - 1) / DX_TH) * ((W + DX_TW - 1) / DX_TW), Ci / 64, N);
+    const int cop = dy_ld;
+    const size_t smem = ((size_t)(128 + 64) * (cop + 8) + (size_t)(128 + DM_HP) * 72) * sizeof(bf16_t);
+    if (cop == 64) {
+        (void)hipFuncSetAttribute((const void*)dcn_bwd_dom_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_bwd_dom_kernel<64>, grid, dim3(512), smem, st, g);
+    } else {
+        (void)hipFuncSetAttribute((const void*)dcn_bwd_dom_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_bwd_dom_kernel<128>, grid, dim3(512), smem, st, g);
+    }
+    return true;
 }

@@ -197,7 +197,7 @@ class TrainStep:
         # weight gradients on a second stream (deposited straight into the flat gradient buffer) unless grad-ready hooks
         # need autograd to see every parameter gradient (eager multi-GPU mode)
         hooks_on = self.sync is not None and self.sync.world > 1 and not graph
-        self.side = SideGrads.enable(side_grads and not hooks_on and self.opt.flat_p.is_cuda)
+        self.side = SideGrads.enable(side_grads and not hooks_on and self.opt.flat_p.is_cuda and not os.environ.get("CN_NO_SIDE"))
         if self.sync is not None:
             self.sync.broadcast_state(model)
         self._g1 = self._g2 = None

@@ -1,0 +1,27 @@
+"""Run a few shapes of the conv / DCN kernels in isolation (for rocprofv3 --pmc passes)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from centernet_amd import ops, nn as hnn
+
+dev = "cuda"
+dt = torch.bfloat16
+N = 64
+def conv(ci, co, hw, reps=3):
+    x = torch.randn(N, hw, hw, ci, device=dev).to(dt)
+    w = torch.randn(co, ci, 3, 3, device=dev) * 0.05
+    wp = ops.pack_weight(w, 1, dt)
+    for _ in range(reps):
+        y = ops._igemm(x, wp, None, None, co, 3, 3, 1, 1, False, False, hw, hw)
+    torch.cuda.synchronize()
+    return y
+which = sys.argv[1] if len(sys.argv) > 1 else "conv"
+if which == "conv":
+    conv(64, 256, 128); conv(256, 64, 128); conv(64, 64, 128); conv(128, 128, 64); conv(256, 256, 32)
+elif which == "dcn":
+    m = hnn.DCN(64, 64).to(dev)
+    torch.nn.init.normal_(m.conv_offset_mask.weight, std=0.01)
+    x = torch.randn(N, 128, 128, 64, device=dev).to(dt).requires_grad_(True)
+    for _ in range(2):
+        y = m(x); y.backward(torch.randn_like(y))
+    torch.cuda.synchronize()
