@@ -105,6 +105,15 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
+// Branch-free guarded 16-byte global load.  A predicated load compiles to an exec-masked branch, after which the
+// compiler can no longer count the loads in flight and falls back to s_waitcnt vmcnt(0) — that serialises every software
+// prefetch behind it.  Here the caller passes an address that is readable either way and the value is masked instead.
+__device__ static inline uint4 ldg16_masked(const void* base, int64_t byte_ofs, bool ok) {
+    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (ok ? byte_ofs : (int64_t)0));
+    const uint32_t m = ok ? 0xffffffffu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+
 // ---- wave / block reductions (wave = 64 lanes) -----------------------------------------------------
 __device__ static inline float wave_sum(float v) {
 #pragma unroll

@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
     constexpr int MI = WM / 32, NJ = WN / 32;
     constexpr int KSTEPS = CK / Mma<T>::KSTEP;
 
-    __shared__ __attribute__((aligned(16))) T lds[(HP + 2 * BN) * PITCH];
+    constexpr int MAIN_ELEMS = (HP + 2 * BN) * PITCH;
+    constexpr int EPI_ELEMS = (sizeof(T) == 2) ? WGM * 32 * (BN + 4) * 2 : 0;   // fp32 slab of the LDS-staged epilogue
+    __shared__ __attribute__((aligned(16))) T lds[MAIN_ELEMS > EPI_ELEMS ? MAIN_ELEMS : EPI_ELEMS];
     T* const As = lds;
     T* const Bs = lds + HP * PITCH;                    // two buffers of BN rows
 
@@ -60,49 +62,74 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-    uint4 rb[B_PASS];
-    auto bload = [&](int tap, int c0) {
+    // Weight slices are prefetched PF taps ahead through a ring of register sets: one L2 round trip is ~1 us under
+    // load while a tap's MFMA work is 0.1-0.25 us, so a one-tap prefetch left every tap waiting on its weights.
+    constexpr int PF = 3;                              // 9 % PF == 0 keeps the ring index static per unrolled tap
+    uint4 rb[PF][B_PASS];
+    uint4 ra[A_PASS];
+    auto bload = [&](uint4 (&r)[B_PASS], int tap, int c0) {
         const int wofs = (int)g.wt[0][tap] * g.Ci + c0;
 #pragma unroll
         for (int p = 0; p < B_PASS; ++p) {
-            const int v = tid + p * 256;
-            const int row = v / VPR, col = (v % VPR) * VEC;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (v < B_VECS && n0 + row < g.co_pad) val = *reinterpret_cast<const uint4*>(Wp + (int64_t)(n0 + row) * g.ktot + wofs + col);
-            rb[p] = val;
+            // branch-free: rows past the packed matrix re-read its last row (those output channels are never stored)
+            const int v = (B_VECS % 256 == 0) ? tid + p * 256 : min(tid + p * 256, B_VECS - 1);
+            const int row = min(n0 + v / VPR, g.co_pad - 1), col = (v % VPR) * VEC;
+            r[p] = *reinterpret_cast<const uint4*>(Wp + (int64_t)row * g.ktot + wofs + col);
         }
     };
-    auto bstore = [&](int buf) {
+    auto bstore = [&](const uint4 (&r)[B_PASS], int buf) {
 #pragma unroll
         for (int p = 0; p < B_PASS; ++p) {
             const int v = tid + p * 256;
-            if (v < B_VECS) lds_store_vec<T, PITCH>(Bs + buf * BN * PITCH, v / VPR, (v % VPR) * VEC, rb[p]);
+            if (B_VECS % 256 == 0 || v < B_VECS) lds_store_vec<T, PITCH>(Bs + buf * BN * PITCH, v / VPR, (v % VPR) * VEC, r[p]);
         }
     };
-
-    for (int c0 = 0; c0 < g.Ci; c0 += CK) {
-        if (c0 > 0) __syncthreads();                   // everybody is done with the previous slice's halo tile
-        // ---- halo tile of this channel slice: one pass over HBM/L2 ----
+    auto aload = [&](int c0) {                         // halo tile of one channel slice: one pass over HBM/L2
 #pragma unroll
         for (int p = 0; p < A_PASS; ++p) {
             const int v = tid + p * 256;
-            if (v < A_VECS) {
-                const int hp = v / VPR, col = (v % VPR) * VEC;
-                const int ih = th0 - 1 + hp / HW_, iw = tw0 - 1 + hp % HW_;
-                uint4 val = make_uint4(0, 0, 0, 0);
-                if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-                    val = *reinterpret_cast<const uint4*>(X + ((int64_t)ih * g.W + iw) * g.x_ld + c0 + col);
-                lds_store_vec<T, PITCH>(As, hp, col, val);
-            }
+            const int hp = v / VPR, col = (v % VPR) * VEC;
+            const int ih = th0 - 1 + hp / HW_, iw = tw0 - 1 + hp % HW_;
+            const bool ok = v < A_VECS && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+            ra[p] = ldg16_masked(X, (((int64_t)ih * g.W + iw) * g.x_ld + c0 + col) * (int64_t)sizeof(T), ok);
         }
-        bload(0, c0);
-        bstore(0);
-        __syncthreads();
+    };
+    auto astore = [&]() {
+#pragma unroll
+        for (int p = 0; p < A_PASS; ++p) {
+            const int v = tid + p * 256;
+            if (v < A_VECS) lds_store_vec<T, PITCH>(As, v / VPR, (v % VPR) * VEC, ra[p]);
+        }
+    };
+
+    if (g.dbg >> 8) {                                  // experiment: de-phase the first wave of workgroups
+        const unsigned lb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (lb < 2048) {
+            const unsigned hsh = (lb * 2654435761u) >> 29;           // 0..7
+            const uint64_t t0 = wall_clock64(), dt = (uint64_t)(g.dbg >> 8) * 6 * hsh;   // 100 MHz ticks; unit 0.5 us / 8
+            while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    const int nchunks = g.Ci / CK;
+    aload(0);
+#pragma unroll
+    for (int d = 0; d < PF; ++d) bload(rb[d], d, 0);
+    astore();
+    bstore(rb[0], 0);
+    __syncthreads();
 #pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        const int c0 = c * CK;
+        const bool more = c + 1 < nchunks;
+        const int c1 = more ? c0 + CK : c0;            // the last slice prefetches itself again: no branches around loads
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) bload(tap + 1, c0);
+            // stage s = 9c + tap; its weights sit in LDS buffer (s & 1); stage s+PF goes into the ring slot just freed
+            if (tap + PF < 9) bload(rb[tap % PF], tap + PF, c0);
+            else bload(rb[tap % PF], tap + PF - 9, c1);
+            if (tap == 4) aload(c1);
             const int shift = (int)g.dh[0][tap] * HW_ + (int)g.dw[0][tap];
-            const T* bt = Bs + (tap & 1) * BN * PITCH;
+            const T* bt = Bs + ((c + tap) & 1) * BN * PITCH;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 typename Mma<T>::Frag fa[MI], fb[NJ];
@@ -122,8 +149,12 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i) acc[j][i] = Mma<T>::mma(fb[j], fa[i], acc[j][i]);
             }
-            if (tap < 8) bstore((tap + 1) & 1);
+            bstore(rb[(tap + 1) % PF], (c + tap + 1) & 1);
             __syncthreads();
+            if (tap == 8) {                            // everybody is done with this slice's halo tile
+                astore();
+                __syncthreads();
+            }
         }
     }
 
@@ -133,6 +164,16 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
         const int m = wm + i * 32 + (lane & 31);
         const int oh = th0 + m / T3_TW, ow = tw0 + m % T3_TW;
         pix[i] = (oh < g.OH && ow < g.OW) ? ((int64_t)n * g.OH + oh) * g.OW + ow : -1;
+    }
+    if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+    if constexpr (sizeof(T) == 2) {
+        if (g.epi_tile) {                              // main loop ended on a barrier: the LDS is free
+            conv_epilogue_tile<MI, NJ, WGM, WGN>(g, acc, reinterpret_cast<float*>(lds), n0, tid, [&](int m) -> int64_t {
+                const int oh = th0 + m / T3_TW, ow = tw0 + m % T3_TW;
+                return (oh < g.OH && ow < g.OW) ? ((int64_t)n * g.OH + oh) * g.OW + ow : -1;
+            });
+            return;
+        }
     }
     conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
 }
@@ -146,6 +187,8 @@ static void launch3(const ConvGeom& g, hipStream_t st) {
 bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     // caller guarantees: 3x3, stride 1, pad 1 geometry in class 0 of g (normal or mirrored taps), OH == H, OW == W
     if (g.N > 65535) return false;
+    { const char* e = getenv("CN_DBG"); const_cast<ConvGeom&>(g).dbg = e ? atoi(e) : 0; }
+    const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !(g.dbg & 32)) ? 1 : 0;
     const int co32 = (g.Co + 31) / 32 * 32;
     int bn = 32, bw = co32;
     for (int c : {64, 128}) {
@@ -153,7 +196,7 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
         if (w <= bw) { bn = c; bw = w; }
     }
     if (dtype == CN_BF16) {
-        if (g.Ci % 64 == 0) {
+        if (g.Ci % 64 == 0 && !(g.dbg & 64)) {
             if (bn == 128) launch3<bf16_t, 128, 64>(g, st); else if (bn == 64) launch3<bf16_t, 64, 64>(g, st); else launch3<bf16_t, 32, 64>(g, st);
         } else if (g.Ci % 32 == 0) {
             if (bn == 128) launch3<bf16_t, 128, 32>(g, st); else if (bn == 64) launch3<bf16_t, 64, 32>(g, st); else launch3<bf16_t, 32, 32>(g, st);

@@ -34,6 +34,8 @@ struct ConvGeom {
     int dcn_Ci, dcn_H, dcn_W, dcn_xld, dcn_omld;
     const float* res32;   // optional fp32 residual added in the epilogue (pitch res32_ld)
     int res32_ld;
+    int dbg;              // perf experiments only (CN_DBG env), 0 in production
+    int epi_tile;         // bf16 output rows are 16-byte aligned vectors: use the LDS-staged epilogue
 };
 
 template <typename T> struct Mma;
@@ -139,6 +141,65 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                         if (ch + e < g.Co) Elem<T>::st(dst + e, v[e]);
                 }
             }
+        }
+    }
+}
+
+// LDS-staged epilogue (bf16 outputs).  The direct epilogue above writes 8-byte pieces at a 32-pixel stride per store
+// instruction — on the 256-channel head convs that scatter cost 40 % of the kernel.  Here the accumulators pass through
+// an fp32 LDS slab (one 32-pixel row block per wave row at a time, pitch BN+4 floats = conflict-free for both sides)
+// and leave as 16-byte vectors along the channel axis: bias / residual / ReLU are applied in fp32 on the way out, so the
+// rounding is identical to the direct path.  Block tile = (WGM*MI*32) pixels x (WGN*NJ*32) channels, 256 threads.
+// `ot` needs WGM*32*(BN+4) floats and must not be read by anyone else (caller barriers before the call).
+static inline bool conv_epi_tile_ok(const ConvGeom& g, int dtype) {
+    return dtype == CN_BF16 && !g.y_f32 && g.res32 == nullptr && (g.Co & 7) == 0 && (g.y_ld & 7) == 0 &&
+           (g.res == nullptr || (g.res_ld & 7) == 0) && (((uintptr_t)g.y | (uintptr_t)g.res) & 15) == 0;
+}
+template <int MI, int NJ, int WGM, int WGN, typename PixFn>
+__device__ static inline void conv_epilogue_tile(const ConvGeom& g, f32x16_t (&acc)[NJ][MI], float* ot, int n0, int tid, PixFn pixel_of) {
+    constexpr int BN = WGN * NJ * 32, P = BN + 4, R = WGM * 32, WM = MI * 32;
+    constexpr int CPR = BN / 8, PASSES = (R * CPR + 255) / 256;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wgm = wave / WGN, wgn = wave % WGN;
+    bf16_t* __restrict__ Y = reinterpret_cast<bf16_t*>(g.y);
+    const bf16_t* __restrict__ Rr = reinterpret_cast<const bf16_t*>(g.res);
+#pragma unroll
+    for (int ii = 0; ii < MI; ++ii) {
+        if (ii > 0) __syncthreads();
+        float* dst = ot + (wgm * 32 + (lane & 31)) * P + wgn * NJ * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dst + j * 32 + 8 * q) = make_float4(acc[j][ii][q * 4], acc[j][ii][q * 4 + 1], acc[j][ii][q * 4 + 2], acc[j][ii][q * 4 + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int id = tid + p * 256;
+            const int rr = id / CPR, c8 = (id % CPR) * 8;
+            if (id >= R * CPR) continue;
+            const int ch = n0 + c8;
+            if (ch >= g.Co) continue;
+            const int64_t px = pixel_of((rr >> 5) * WM + ii * 32 + (rr & 31));
+            if (px < 0) continue;
+            float v[8];
+            const float4 a = *reinterpret_cast<const float4*>(ot + rr * P + c8), b = *reinterpret_cast<const float4*>(ot + rr * P + c8 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            if (g.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(g.bias + ch), b1 = *reinterpret_cast<const float4*>(g.bias + ch + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            if (Rr) {
+                float r[8];
+                Vec16<bf16_t>::load(Rr + px * g.res_ld + ch, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (g.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            Vec16<bf16_t>::store(Y + px * g.y_ld + ch, v);
         }
     }
 }
