@@ -52,12 +52,23 @@ __host__ __device__ static inline float bf2f(bf16_t b) {
     return v.f;
 }
 __host__ __device__ static inline bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bit_cast(bf16_t, (__bf16)f);      // v_cvt_pk_bf16_f32: round-to-nearest-even in hardware
+#endif
     union { uint32_t u; float f; } v;
     v.f = f;
     uint32_t u = v.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+}
+
+// two floats -> packed bf16 pair (low half = a) in one v_cvt_pk_bf16_f32
+__device__ static inline uint32_t pk_bf16(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 
 template <typename T> struct Elem;
@@ -100,7 +111,7 @@ template <> struct Vec16<bf16_t> {
     __device__ static inline void store(bf16_t* p, const float* in) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(in[2 * i]) | ((uint32_t)f2bf(in[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pk_bf16(in[2 * i], in[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -129,8 +129,8 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                 if (full) {
                     if constexpr (sizeof(T) == 2) {
                         uint2 o;
-                        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                        o.x = pk_bf16(v[0], v[1]);
+                        o.y = pk_bf16(v[2], v[3]);
                         *reinterpret_cast<uint2*>(dst) = o;
                     } else {
                         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);

@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         uint2 o;
-                        o.x = (uint32_t)f2bf(acc[j][i][q * 4 + 0]) | ((uint32_t)f2bf(acc[j][i][q * 4 + 1]) << 16);
-                        o.y = (uint32_t)f2bf(acc[j][i][q * 4 + 2]) | ((uint32_t)f2bf(acc[j][i][q * 4 + 3]) << 16);
+                        o.x = pk_bf16(acc[j][i][q * 4 + 0], acc[j][i][q * 4 + 1]);
+                        o.y = pk_bf16(acc[j][i][q * 4 + 2], acc[j][i][q * 4 + 3]);
                         *reinterpret_cast<uint2*>(dt + (wm + i * 32 + (lane & 31)) * DP + wn + j * 32 + 8 * q + 4 * (lane >> 5)) = o;
                     }
             __syncthreads();

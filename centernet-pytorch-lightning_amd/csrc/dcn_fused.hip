@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
                     }
                     if constexpr (sizeof(T) == 2) {
                         uint4 o;
-                        o.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16); o.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
-                        o.z = (uint32_t)f2bf(a[4]) | ((uint32_t)f2bf(a[5]) << 16); o.w = (uint32_t)f2bf(a[6]) | ((uint32_t)f2bf(a[7]) << 16);
+                        o.x = pk_bf16(a[0], a[1]); o.y = pk_bf16(a[2], a[3]);
+                        o.z = pk_bf16(a[4], a[5]); o.w = pk_bf16(a[6], a[7]);
                         lds_store_vec<T, PITCH>(Gs, ql, col, o);
                     } else {
                         lds_store_vec<T, PITCH>(Gs, ql, col, make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])));
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(const ConvGeom g) {
                     for (int j = 0; j < VEC; ++j) a[j] = v0[j] * w0 + v1[j] * w1 + v2[j] * w2 + v3[j] * w3;
                     if constexpr (sizeof(T) == 2) {
                         uint4 o;
-                        o.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16); o.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
-                        o.z = (uint32_t)f2bf(a[4]) | ((uint32_t)f2bf(a[5]) << 16); o.w = (uint32_t)f2bf(a[6]) | ((uint32_t)f2bf(a[7]) << 16);
+                        o.x = pk_bf16(a[0], a[1]); o.y = pk_bf16(a[2], a[3]);
+                        o.z = pk_bf16(a[4], a[5]); o.w = pk_bf16(a[6], a[7]);
                         lds_store_vec<T, PITCH>(As, pl, col, o);
                     } else {
                         lds_store_vec<T, PITCH>(As, pl, col, make_uint4(__float_as_uint(a[0]), __float_as_uint(a[1]), __float_as_uint(a[2]), __float_as_uint(a[3])));
@@ -434,166 +434,253 @@ struct DomGeom {
     int N, H, W, Ci, Co, dy_ld, x_ld, om_ld;
 };
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ static inline float dot8_bf16(const uint4& a, const uint4& b, float acc) {   // v_dot2c_f32_bf16 x 4
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.x), __builtin_bit_cast(bf16x2_t, b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.y), __builtin_bit_cast(bf16x2_t, b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.z), __builtin_bit_cast(bf16x2_t, b.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.w), __builtin_bit_cast(bf16x2_t, b.w), acc, false);
+    return acc;
+}
+
+__device__ static inline float quad_sum(float v) {        // sum over the 4 lanes of a quad, DPP only (no LDS traffic)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+    return v;
+}
+
+// Persistent workgroups (one per CU, 512 threads): each owns a contiguous run of 8x16-pixel tiles.  Per tile the dY
+// tile, the x halo tile and the 27 offset/mask values of every pixel are staged in LDS once; the NEXT tile's copies are
+// fetched into registers while the current one is processed, and the per-tap weight slices run through a 3-deep register
+// ring, so no global-memory latency is exposed inside the tap loop.  Per tap: dcol_k = dY x W_k^T on the matrix cores
+// (bf16 tile back through LDS), then per pixel the four corner dot products D_ab = sum_c dcol[c] * x_ab[c] with
+// v_dot2c_f32_bf16; the three gradients are linear in D_ab:
+//   d mask   = a00 D00 + a01 D01 + a10 D10 + a11 D11
+//   d off_y  = m ((1-lw)(D10-D00) + lw (D11-D01)),   d off_x = m ((1-lh)(D01-D00) + lh (D11-D10)).
 template <int COP>   // padded Co (contraction length): 64 or 128
 __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
     constexpr int BM = DX_TH * DX_TW, BN = 64;
     constexpr int AP = COP + 8;                 // dY tile / weight slice pitch
     constexpr int DP = BN + 8;                  // dcol tile / halo pitch
+    constexpr int OMP = 27;                     // odd pitch: conflict-free per-pixel reads
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     bf16_t* const As = lds;                     // [128][AP]
-    bf16_t* const Bs = As + BM * AP;            // [64][AP]
-    bf16_t* const Ds = Bs + BN * AP;            // [128][DP]
+    bf16_t* const Bs = As + BM * AP;            // 2 x [64][AP]
+    bf16_t* const Ds = Bs + 2 * BN * AP;        // [128][DP]
     bf16_t* const Xh = Ds + BM * DP;            // [DM_HP][DP]
-    __shared__ float s_lh[BM], s_lw[BM], s_m[BM];
-    __shared__ int s_h0[BM], s_w0[BM];
+    float* const Om = reinterpret_cast<float*>(Xh + DM_HP * DP);   // [128][27]
+    float* const Geo = Om + BM * OMP;           // 2 x [5][128]: h0, w0 (as int bits), lh, lw, m
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_w = (g.W + DX_TW - 1) / DX_TW;
-    const int th0 = (blockIdx.x / tiles_w) * DX_TH, tw0 = (blockIdx.x % tiles_w) * DX_TW;
+    const int tiles_w = (g.W + DX_TW - 1) / DX_TW, tiles_h = (g.H + DX_TH - 1) / DX_TH;
+    const int tiles_img = tiles_w * tiles_h, ntiles = tiles_img * g.N;
     const int ci0 = blockIdx.y * BN;
-    const int n = blockIdx.z;
-    const int64_t img = (int64_t)n * g.H * g.W;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const bool whole = g.Ci == BN;
+    // contiguous tile run per workgroup; consecutive runs stay on one XCD (workgroups are dealt round-robin to the 8 XCDs)
+    const int G = gridDim.x;
+    const int lb = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int tpb = (ntiles + G - 1) / G;
+    const int t_begin = lb * tpb, t_end = min(ntiles, t_begin + tpb);
+    if (t_begin >= t_end) return;
 
-    // ---- stage dY tile and x halo tile ----
-    for (int v = tid; v < BM * (COP / 8); v += 512) {
-        const int pl = v / (COP / 8), col = (v % (COP / 8)) * 8;
-        const int h = th0 + pl / DX_TW, w = tw0 + pl % DX_TW;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (h < g.H && w < g.W && col < g.dy_ld) val = *reinterpret_cast<const uint4*>(g.dy + (img + (int64_t)h * g.W + w) * g.dy_ld + col);
-        *reinterpret_cast<uint4*>(As + pl * AP + col) = val;
-    }
-    for (int v = tid; v < DM_HP * (BN / 8); v += 512) {
-        const int hp = v / (BN / 8), col = (v % (BN / 8)) * 8;
-        const int h = th0 - DM_HR + hp / DM_HW, w = tw0 - DM_HR + hp % DM_HW;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if ((unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W)
-            val = *reinterpret_cast<const uint4*>(g.x + (img + (int64_t)h * g.W + w) * g.x_ld + ci0 + col);
-        *reinterpret_cast<uint4*>(Xh + hp * DP + col) = val;
-    }
+    constexpr int DYV = BM * (COP / 8) / 512;
+    constexpr int XV = (DM_HP * (BN / 8) + 511) / 512;
+    constexpr int OV = (BM * 27 + 511) / 512;
+    constexpr int BV = BN * (COP / 8) / 512;
+    uint4 rdy[DYV], rx[XV], rb[3][BV];
+    float rom[OV];
 
-    // Software pipeline: the next tap's weight slice (COP/64 x 16 B per thread) and offset triple are fetched into registers
-    // while the current tap is multiplied and reduced, so a tap exposes no global-memory latency.
-    constexpr int BV = BN * (COP / 8) / 512;         // 16-byte vectors of the weight slice per thread
-    uint4 rb[BV];
-    float ro[3] = {0.f, 0.f, 0.f};
-    const int gh = th0 + (tid & (BM - 1)) / DX_TW, gw = tw0 + (tid & (BM - 1)) % DX_TW;
-    const bool glive = tid < BM && gh < g.H && gw < g.W;
-    const float* const orow = g.om + (img + (int64_t)(glive ? gh : 0) * g.W + (glive ? gw : 0)) * g.om_ld;
-    auto prefetch = [&](int tap) {
+    auto tile_load = [&](int t) {               // branch-free: out-of-image pieces are masked, not skipped
+        const int n = t / tiles_img, r = t % tiles_img;
+        const int th0 = (r / tiles_w) * DX_TH, tw0 = (r % tiles_w) * DX_TW;
+        const int64_t img = (int64_t)n * g.H * g.W;
 #pragma unroll
-        for (int i = 0; i < BV; ++i) {
+        for (int i = 0; i < DYV; ++i) {
             const int v = tid + i * 512;
-            const int row = v / (COP / 8), col = (v % (COP / 8)) * 8;
-            rb[i] = *reinterpret_cast<const uint4*>(g.wd2 + ((int64_t)tap * g.Ci + ci0 + row) * COP + col);
+            const int pl = v / (COP / 8), col = (v % (COP / 8)) * 8;
+            const int h = th0 + pl / DX_TW, w = tw0 + pl % DX_TW;
+            rdy[i] = ldg16_masked(g.dy, ((img + (int64_t)h * g.W + w) * g.dy_ld + col) * 2, h < g.H && w < g.W && col < g.dy_ld);
         }
-        if (glive) { ro[0] = orow[2 * tap]; ro[1] = orow[2 * tap + 1]; ro[2] = orow[18 + tap]; }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * 512;
+            const int hp = v / (BN / 8), col = (v % (BN / 8)) * 8;
+            const int h = th0 - DM_HR + hp / DM_HW, w = tw0 - DM_HR + hp % DM_HW;
+            rx[i] = ldg16_masked(g.x, ((img + (int64_t)h * g.W + w) * g.x_ld + ci0 + col) * 2,
+                                 hp < DM_HP && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W);
+        }
+#pragma unroll
+        for (int i = 0; i < OV; ++i) {
+            const int e = tid + i * 512;
+            const int pl = e / 27, k = e % 27;
+            const int h = th0 + pl / DX_TW, w = tw0 + pl % DX_TW;
+            const bool ok = pl < BM && h < g.H && w < g.W;
+            const float v = g.om[ok ? (img + (int64_t)h * g.W + w) * g.om_ld + k : 0];
+            rom[i] = ok ? v : 0.f;
+        }
     };
-    prefetch(0);
-    for (int tap = 0; tap < 9; ++tap) {
-        // weight slice: rows tap*Ci + ci0 .. +63 of the mode-2 packed matrix [9*Ci][COP]
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < DYV; ++i) {
+            const int v = tid + i * 512;
+            *reinterpret_cast<uint4*>(As + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8) = rdy[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * 512;
+            if (v < DM_HP * (BN / 8)) *reinterpret_cast<uint4*>(Xh + (v / (BN / 8)) * DP + (v % (BN / 8)) * 8) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < OV; ++i) {
+            const int e = tid + i * 512;
+            if (e < BM * 27) Om[e] = rom[i];    // pitch 27: the flat element index is the LDS index
+        }
+    };
+    auto bload = [&](uint4 (&r)[BV], int tap) { // rows tap*Ci + ci0 .. +63 of the mode-2 packed matrix [9*Ci][COP]
 #pragma unroll
         for (int i = 0; i < BV; ++i) {
             const int v = tid + i * 512;
-            *reinterpret_cast<uint4*>(Bs + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8) = rb[i];
+            r[i] = *reinterpret_cast<const uint4*>(g.wd2 + ((int64_t)tap * g.Ci + ci0 + v / (COP / 8)) * COP + (v % (COP / 8)) * 8);
+        }
+    };
+    auto stage_tap = [&](const uint4 (&r)[BV], int tap, int buf, int th0, int tw0) {   // weight slice + sample geometry -> LDS
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            const int v = tid + i * 512;
+            *reinterpret_cast<uint4*>(Bs + buf * BN * AP + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8) = r[i];
         }
         if (tid < BM) {
-            float py = 0.f, px = 0.f, m = 0.f;
-            if (glive) {
-                py = (float)(gh - 1 + tap / 3) + ro[0];
-                px = (float)(gw - 1 + tap % 3) + ro[1];
-                m = sigmoidf_(ro[2]);
-            }
+            const int gh = th0 + tid / DX_TW, gw = tw0 + tid % DX_TW;
+            const float* o = Om + tid * OMP;
+            const float py = (float)(gh - 1 + tap / 3) + o[2 * tap], px = (float)(gw - 1 + tap % 3) + o[2 * tap + 1];
             const float fh = floorf(py), fw = floorf(px);
-            s_h0[tid] = (int)fh; s_w0[tid] = (int)fw; s_lh[tid] = py - fh; s_lw[tid] = px - fw; s_m[tid] = m;
+            float* gq = Geo + buf * 5 * BM + tid;
+            gq[0] = __int_as_float((int)fh); gq[BM] = __int_as_float((int)fw);
+            gq[2 * BM] = py - fh; gq[3 * BM] = px - fw;
+            gq[4 * BM] = (gh < g.H && gw < g.W) ? sigmoidf_(o[18 + tap]) : 0.f;
         }
-        __syncthreads();
-        if (tap < 8) prefetch(tap + 1);
-        // ---- dcol_k tile = dY tile x W_k^T : one 32x32 block per wave ----
-        f32x16_t acc;
+    };
+
+    tile_load(t_begin);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int d = 0; d < 3; ++d) bload(rb[d], d);
+    tile_store();
+    __syncthreads();
+    {
+        const int r0 = t_begin % tiles_img;
+        stage_tap(rb[0], 0, 0, (r0 / tiles_w) * DX_TH, (r0 % tiles_w) * DX_TW);
+    }
+    bload(rb[0], 3);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; ++t) {
+        const int n = t / tiles_img, r = t % tiles_img;
+        const int th0 = (r / tiles_w) * DX_TH, tw0 = (r % tiles_w) * DX_TW;
+        const int64_t img = (int64_t)n * g.H * g.W;
+        const int tn = (t + 1 < t_end) ? t + 1 : t;            // the last tile prefetches itself again: no branches around loads
+        const int rn = tn % tiles_img;
+        const int nth0 = (rn / tiles_w) * DX_TH, ntw0 = (rn % tiles_w) * DX_TW;
 #pragma unroll
-        for (int kk = 0; kk < COP / 16; ++kk) {
-            const bf16x8_t fa = Mma<bf16_t>::load(As, AP, wm, kk, lane);     // pixels
-            const bf16x8_t fb = Mma<bf16_t>::load(Bs, AP, wn, kk, lane);     // channels (ci)
-            acc = Mma<bf16_t>::mma(fb, fa, acc);
-        }
+        for (int tap = 0; tap < 9; ++tap) {
+            // invariant: Bs[tap&1], Geo[tap&1] hold this tap; ring slot (tap+1)%3 holds tap+1, (tap+2)%3 holds tap+2,
+            // slot tap%3 is loading tap+3
+            const int buf = tap & 1;
+            if (tap == 1) tile_load(tn);
+            // ---- dcol_k tile = dY tile x W_k^T : one 32x32 block per wave ----
+            f32x16_t acc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint2 o;
-            o.x = (uint32_t)f2bf(acc[q * 4 + 0]) | ((uint32_t)f2bf(acc[q * 4 + 1]) << 16);
-            o.y = (uint32_t)f2bf(acc[q * 4 + 2]) | ((uint32_t)f2bf(acc[q * 4 + 3]) << 16);
-            *reinterpret_cast<uint2*>(Ds + (wm + (lane & 31)) * DP + wn + 8 * q + 4 * (lane >> 5)) = o;
-        }
-        __syncthreads();
-        // ---- per (pixel, 8-channel slice): corner combinations from the halo tile ----
+            for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.f;
 #pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-            const int it = tid + rep * 512;
-            const int pl = it >> 3, lg = it & 7;
-            const int h = th0 + pl / DX_TW, w = tw0 + pl % DX_TW;
-            const bool live = h < g.H && w < g.W;
-            const int h0 = s_h0[pl], w0 = s_w0[pl];
-            const float lh = s_lh[pl], lw = s_lw[pl], mk = s_m[pl];
-            const int hy = h0 - (th0 - DM_HR), hx = w0 - (tw0 - DM_HR);       // halo coordinates of corner 00
-            float x00[8], x01[8], x10[8], x11[8], gc[8];
-            if (hy >= 0 && hy + 1 < DM_HH && hx >= 0 && hx + 1 < DM_HW) {     // all four corners inside the LDS halo (zeros outside the image)
-                const bf16_t* b = Xh + (hy * DM_HW + hx) * DP + lg * 8;
-                Vec16<bf16_t>::load(b, x00);
-                Vec16<bf16_t>::load(b + DP, x01);
-                Vec16<bf16_t>::load(b + DM_HW * DP, x10);
-                Vec16<bf16_t>::load(b + DM_HW * DP + DP, x11);
-            } else {                                                          // rare: fetch from global, zero outside the image
-                auto gl = [&](int hh, int ww, float* out) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) out[e] = 0.f;
-                    if ((unsigned)hh < (unsigned)g.H && (unsigned)ww < (unsigned)g.W)
-                        Vec16<bf16_t>::load(g.x + (img + (int64_t)hh * g.W + ww) * g.x_ld + ci0 + lg * 8, out);
-                };
-                gl(h0, w0, x00); gl(h0, w0 + 1, x01); gl(h0 + 1, w0, x10); gl(h0 + 1, w0 + 1, x11);
+            for (int kk = 0; kk < COP / 16; ++kk) {
+                const bf16x8_t fa = Mma<bf16_t>::load(As, AP, wm, kk, lane);                       // pixels
+                const bf16x8_t fb = Mma<bf16_t>::load(Bs + buf * BN * AP, AP, wn, kk, lane);       // channels (ci)
+                acc = Mma<bf16_t>::mma(fb, fa, acc);
             }
-            Vec16<bf16_t>::load(Ds + pl * DP + lg * 8, gc);
-            const float a00 = (1.f - lh) * (1.f - lw), a01 = (1.f - lh) * lw, a10 = lh * (1.f - lw), a11 = lh * lw;
-            float sm = 0.f, sy = 0.f, sx = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sm = fmaf(gc[e], x00[e] * a00 + x01[e] * a01 + x10[e] * a10 + x11[e] * a11, sm);
-                sy = fmaf(gc[e], (1.f - lw) * (x10[e] - x00[e]) + lw * (x11[e] - x01[e]), sy);
-                sx = fmaf(gc[e], (1.f - lh) * (x01[e] - x00[e]) + lh * (x11[e] - x10[e]), sx);
+            for (int q = 0; q < 4; ++q) {
+                uint2 o;
+                o.x = pk_bf16(acc[q * 4 + 0], acc[q * 4 + 1]);
+                o.y = pk_bf16(acc[q * 4 + 2], acc[q * 4 + 3]);
+                *reinterpret_cast<uint2*>(Ds + (wm + (lane & 31)) * DP + wn + 8 * q + 4 * (lane >> 5)) = o;
             }
-            // far samples (the adjoint-gather window of cn_dcn_bwd_dx cannot see them)
-            const int dh0 = h0 - h, dw0 = w0 - w;
-            const bool far_h0 = dh0 > DCN_FAR_R || dh0 < -DCN_FAR_R, far_h1 = dh0 + 1 > DCN_FAR_R || dh0 + 1 < -DCN_FAR_R;
-            const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
-            if (live && (far_h0 || far_h1 || far_w0 || far_w1)) {
-                const bool in_h0 = (unsigned)h0 < (unsigned)g.H, in_h1 = (unsigned)(h0 + 1) < (unsigned)g.H;
-                const bool in_w0 = (unsigned)w0 < (unsigned)g.W, in_w1 = (unsigned)(w0 + 1) < (unsigned)g.W;
-                float* far = g.far + (img + (int64_t)h0 * g.W + w0) * g.Ci + ci0 + lg * 8;
+            // stage the next tap while this one is reduced (tap 8 stages tap 0 of the next tile after the tile swap below)
+            if (tap < 8) {
+                stage_tap(rb[(tap + 1) % 3], tap + 1, buf ^ 1, th0, tw0);
+                bload(rb[(tap + 1) % 3], (tap + 4) % 9);
+            }
+            __syncthreads();
+            // ---- per (pixel, 16-channel slice): corner dot products from the halo tile; 4 lanes share a pixel ----
+            const float* gq = Geo + buf * 5 * BM;
+            {
+                const int pl = tid >> 2, lq = tid & 3;
+                const int h = th0 + pl / DX_TW, w = tw0 + pl % DX_TW;
+                const bool live = h < g.H && w < g.W;
+                const int h0 = __float_as_int(gq[pl]), w0 = __float_as_int(gq[BM + pl]);
+                const float lh = gq[2 * BM + pl], lw = gq[3 * BM + pl], mk = gq[4 * BM + pl];
+                const int hy = h0 - (th0 - DM_HR), hx = w0 - (tw0 - DM_HR);       // halo coordinates of corner 00
+                uint4 x00[2], x01[2], x10[2], x11[2];
+                if (hy >= 0 && hy + 1 < DM_HH && hx >= 0 && hx + 1 < DM_HW) {     // all four corners inside the LDS halo (zeros outside the image)
+                    const bf16_t* b = Xh + (hy * DM_HW + hx) * DP + lq * 16;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float gm = gc[e] * mk;
-                    if (in_h0 && in_w0 && a00 != 0.f && (far_h0 || far_w0)) atomicAdd(far + e, gm * a00);
-                    if (in_h0 && in_w1 && a01 != 0.f && (far_h0 || far_w1)) atomicAdd(far + g.Ci + e, gm * a01);
-                    if (in_h1 && in_w0 && a10 != 0.f && (far_h1 || far_w0)) atomicAdd(far + (int64_t)g.W * g.Ci + e, gm * a10);
-                    if (in_h1 && in_w1 && a11 != 0.f && (far_h1 || far_w1)) atomicAdd(far + (int64_t)(g.W + 1) * g.Ci + e, gm * a11);
+                    for (int u = 0; u < 2; ++u) {
+                        x00[u] = *reinterpret_cast<const uint4*>(b + u * 8);
+                        x01[u] = *reinterpret_cast<const uint4*>(b + DP + u * 8);
+                        x10[u] = *reinterpret_cast<const uint4*>(b + DM_HW * DP + u * 8);
+                        x11[u] = *reinterpret_cast<const uint4*>(b + DM_HW * DP + DP + u * 8);
+                    }
+                } else {                                                          // rare: fetch from global, zero outside the image
+                    auto gl = [&](int hh, int ww, int u) {
+                        return ldg16_masked(g.x, ((img + (int64_t)hh * g.W + ww) * g.x_ld + ci0 + lq * 16 + u * 8) * 2,
+                                            (unsigned)hh < (unsigned)g.H && (unsigned)ww < (unsigned)g.W);
+                    };
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { x00[u] = gl(h0, w0, u); x01[u] = gl(h0, w0 + 1, u); x10[u] = gl(h0 + 1, w0, u); x11[u] = gl(h0 + 1, w0 + 1, u); }
+                }
+                const uint4 gc0 = *reinterpret_cast<const uint4*>(Ds + pl * DP + lq * 16), gc1 = *reinterpret_cast<const uint4*>(Ds + pl * DP + lq * 16 + 8);
+                const float d00 = dot8_bf16(gc1, x00[1], dot8_bf16(gc0, x00[0], 0.f)), d01 = dot8_bf16(gc1, x01[1], dot8_bf16(gc0, x01[0], 0.f));
+                const float d10 = dot8_bf16(gc1, x10[1], dot8_bf16(gc0, x10[0], 0.f)), d11 = dot8_bf16(gc1, x11[1], dot8_bf16(gc0, x11[0], 0.f));
+                const float a00 = (1.f - lh) * (1.f - lw), a01 = (1.f - lh) * lw, a10 = lh * (1.f - lw), a11 = lh * lw;
+                float sm = a00 * d00 + a01 * d01 + a10 * d10 + a11 * d11;
+                float sy = (1.f - lw) * (d10 - d00) + lw * (d11 - d01);
+                float sx = (1.f - lh) * (d01 - d00) + lh * (d11 - d10);
+                // far samples (the adjoint-gather window of cn_dcn_bwd_dx cannot see them)
+                const int dh0 = h0 - h, dw0 = w0 - w;
+                const bool far_h0 = dh0 > DCN_FAR_R || dh0 < -DCN_FAR_R, far_h1 = dh0 + 1 > DCN_FAR_R || dh0 + 1 < -DCN_FAR_R;
+                const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
+                if (live && (far_h0 || far_h1 || far_w0 || far_w1)) {
+                    const bool in_h0 = (unsigned)h0 < (unsigned)g.H, in_h1 = (unsigned)(h0 + 1) < (unsigned)g.H;
+                    const bool in_w0 = (unsigned)w0 < (unsigned)g.W, in_w1 = (unsigned)(w0 + 1) < (unsigned)g.W;
+                    float* far = g.far + (img + (int64_t)h0 * g.W + w0) * g.Ci + ci0 + lq * 16;
+                    float gc[16];
+                    Vec16<bf16_t>::load(Ds + pl * DP + lq * 16, gc);
+                    Vec16<bf16_t>::load(Ds + pl * DP + lq * 16 + 8, gc + 8);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float gm = gc[e] * mk;
+                        if (in_h0 && in_w0 && a00 != 0.f && (far_h0 || far_w0)) atomicAdd(far + e, gm * a00);
+                        if (in_h0 && in_w1 && a01 != 0.f && (far_h0 || far_w1)) atomicAdd(far + g.Ci + e, gm * a01);
+                        if (in_h1 && in_w0 && a10 != 0.f && (far_h1 || far_w0)) atomicAdd(far + (int64_t)g.W * g.Ci + e, gm * a10);
+                        if (in_h1 && in_w1 && a11 != 0.f && (far_h1 || far_w1)) atomicAdd(far + (int64_t)(g.W + 1) * g.Ci + e, gm * a11);
+                    }
+                }
+                sm = quad_sum(sm); sy = quad_sum(sy); sx = quad_sum(sx);
+                if (lq == 0 && live) {
+                    float* d = g.dom + (img + (int64_t)h * g.W + w) * g.om_ld;
+                    const float vy = sy * mk, vx = sx * mk, vm = sm * mk * (1.f - mk);
+                    if (whole) { d[2 * tap] = vy; d[2 * tap + 1] = vx; d[18 + tap] = vm; }
+                    else { atomicAdd(d + 2 * tap, vy); atomicAdd(d + 2 * tap + 1, vx); atomicAdd(d + 18 + tap, vm); }
                 }
             }
-#pragma unroll
-            for (int ofs = 4; ofs > 0; ofs >>= 1) {
-                sm += __shfl_xor(sm, ofs, 64);
-                sy += __shfl_xor(sy, ofs, 64);
-                sx += __shfl_xor(sx, ofs, 64);
-            }
-            if (lg == 0 && live) {
-                float* d = g.dom + (img + (int64_t)h * g.W + w) * g.om_ld;
-                const float vy = sy * mk, vx = sx * mk, vm = sm * mk * (1.f - mk);
-                if (whole) { d[2 * tap] = vy; d[2 * tap + 1] = vx; d[18 + tap] = vm; }
-                else { atomicAdd(d + 2 * tap, vy); atomicAdd(d + 2 * tap + 1, vx); atomicAdd(d + 18 + tap, vm); }
-            }
+            __syncthreads();      // Ds and this tap's Bs / geometry may be rewritten
         }
-        __syncthreads();      // Bs / Ds / geometry are rewritten by the next tap
+        // ---- tile swap: everyone is done with As / Xh / Om ----
+        tile_store();
+        __syncthreads();
+        stage_tap(rb[0], 0, 0, nth0, ntw0);     // ring slot 0 holds tap 0 again (loaded at tap 5)
+        bload(rb[0], 3);
+        __syncthreads();
     }
 }
 
@@ -601,14 +688,18 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
 bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, float* far,
                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_DOM_TILE") != nullptr;
-    if (disabled || Ci % 64 != 0 || (dy_ld != 64 && dy_ld != 128) || N > 65535) return false;
+    if (disabled || Ci % 64 != 0 || (dy_ld != 64 && dy_ld != 128)) return false;
     (void)Co;
     DomGeom g;
     g.dy = (const bf16_t*)dy; g.wd2 = (const bf16_t*)wd2; g.x = (const bf16_t*)x; g.om = om; g.dom = dom; g.far = far;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.dy_ld = dy_ld; g.x_ld = x_ld; g.om_ld = om_ld;
-    dim3 grid(((H + DX_TH - 1) / DX_TH) * ((W + DX_TW - 1) / DX_TW), Ci / 64, N);
+    const int ntiles = ((H + DX_TH - 1) / DX_TH) * ((W + DX_TW - 1) / DX_TW) * N;
+    int gx = 256 / (Ci / 64);                   // one persistent workgroup per CU
+    if (gx < 8) gx = 8;
+    if (gx > ntiles) gx = ntiles;
+    dim3 grid(gx, Ci / 64, 1);
     const int cop = dy_ld;
-    const size_t smem = ((size_t)(128 + 64) * (cop + 8) + (size_t)(128 + DM_HP) * 72) * sizeof(bf16_t);
+    const size_t smem = ((size_t)(128 + 2 * 64) * (cop + 8) + (size_t)(128 + DM_HP) * 72) * sizeof(bf16_t) + (size_t)(128 * 27 + 2 * 5 * 128) * sizeof(float);
     if (cop == 64) {
         (void)hipFuncSetAttribute((const void*)dcn_bwd_dom_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(dcn_bwd_dom_kernel<64>, grid, dim3(512), smem, st, g);

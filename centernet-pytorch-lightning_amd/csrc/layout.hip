@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void add_f32_to_kernel(const float* __restrict
             reinterpret_cast<float4*>(out)[i] = make_float4(r[0], r[1], r[2], r[3]);
         } else {
             uint2 o;
-            o.x = (uint32_t)f2bf(r[0]) | ((uint32_t)f2bf(r[1]) << 16);
-            o.y = (uint32_t)f2bf(r[2]) | ((uint32_t)f2bf(r[3]) << 16);
+            o.x = pk_bf16(r[0], r[1]);
+            o.y = pk_bf16(r[2], r[3]);
             reinterpret_cast<uint2*>(out)[i] = o;
         }
     }
