@@ -191,7 +191,7 @@ def main():
         out = captured["out"]
         return ctdet_decode(out["heatmap"].detach(), out["width_height"].detach(), reg=out["regression"].detach())
 
-    step = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_step=decode)
+    step = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_forward=decode)   # decode overlaps backward
 
     def fence():
         torch.cuda.synchronize()

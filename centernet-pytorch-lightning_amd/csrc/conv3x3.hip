@@ -178,6 +178,90 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
     conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
 }
 
+// ---- 16 -> 16 channel special case (DLA level0 and its data gradient at 512x512) -----------------------------------
+// These layers are pure HBM streams (1 GB in+out, 2.5 GFLOP/MB); the tile kernel above wastes 3/4 of every MFMA and
+// all of its LDS staging on them.  Here a wave owns one 64-pixel row strip and feeds v_mfma_f32_16x16x32_bf16 straight
+// from global memory: M = 16 output channels, N = 16 pixels, K = 32 = two taps x 16 input channels, so five MFMAs cover
+// the 9 taps (the tenth half is masked).  Operand lanes: weights A[co = lane&15][k = 8*(lane>>4)..+7] (held in registers
+// for the whole launch), pixels B[k][px = lane&15] = 16 contiguous bytes of pixel (w+px+dw, h+dh) — a 16-pixel group is
+// one 512-byte run, so every load is fully coalesced and the 9x tap re-reads are L1/L2 hits.  D[co = 4*(lane>>4)+r][px]:
+// each lane stores 4 consecutive channels of one pixel (8 bytes), a group again being one contiguous 512-byte run.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+#define C16_GROUPS 4
+__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvGeom g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = lane & 15, kc = lane >> 4;
+    const int half = kc & 1, tsel = kc >> 1;
+    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(g.x);
+    const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(g.w);
+    bf16_t* __restrict__ Y = reinterpret_cast<bf16_t*>(g.y);
+
+    bf16x8_t wa[5];
+    int dh[5], dw[5];
+    bool tv[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int t1 = 2 * m + 1 < 9 ? 2 * m + 1 : 8;
+        const int wt = tsel ? (int)g.wt[0][t1] : (int)g.wt[0][2 * m];
+        dh[m] = tsel ? (int)g.dh[0][t1] : (int)g.dh[0][2 * m];
+        dw[m] = tsel ? (int)g.dw[0][t1] : (int)g.dw[0][2 * m];
+        tv[m] = 2 * m + tsel < 9;
+        wa[m] = __builtin_bit_cast(bf16x8_t, ldg16_masked(Wp, ((int64_t)px * g.ktot + wt * 16 + half * 8) * 2, tv[m]));
+    }
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * kc + r < g.Co) bias4[r] = g.bias[4 * kc + r];
+    }
+
+    const int segs = (g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS);
+    const int64_t strips = (int64_t)g.N * g.H * segs;
+#pragma unroll 1
+    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < strips; s += (int64_t)gridDim.x * 4) {
+        const int seg = (int)(s % segs);
+        const int64_t row = s / segs;                   // n * H + h
+        const int h = (int)(row % g.H);
+        const int64_t img_row0 = row - h;               // n * H
+        uint4 xb[C16_GROUPS][5];
+#pragma unroll
+        for (int gq = 0; gq < C16_GROUPS; ++gq) {
+            const int wq = seg * 16 * C16_GROUPS + gq * 16 + px;
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                const int ih = h + dh[m], iw = wq + dw[m];
+                const bool ok = tv[m] && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+                xb[gq][m] = ldg16_masked(X, (((img_row0 + ih) * g.W + iw) * g.x_ld + half * 8) * 2, ok);
+            }
+        }
+#pragma unroll
+        for (int gq = 0; gq < C16_GROUPS; ++gq) {
+            f32x4_t acc = {bias4[0], bias4[1], bias4[2], bias4[3]};
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[m], __builtin_bit_cast(bf16x8_t, xb[gq][m]), acc, 0, 0, 0);
+            const int wq = seg * 16 * C16_GROUPS + gq * 16 + px;
+            if (wq < g.W && 4 * kc < g.Co) {
+                float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+                if (g.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                bf16_t* dst = Y + ((row * g.W) + wq) * g.y_ld + 4 * kc;
+                if (4 * kc + 4 <= g.Co) {
+                    uint2 o;
+                    o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * kc + r < g.Co) dst[r] = f2bf(v[r]);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BN, int CK>
 static void launch3(const ConvGeom& g, hipStream_t st) {
     dim3 grid(((g.OH + T3_TH - 1) / T3_TH) * ((g.OW + T3_TW - 1) / T3_TW), (g.Co + BN - 1) / BN, g.N);
@@ -189,6 +273,14 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     if (g.N > 65535) return false;
     { const char* e = getenv("CN_DBG"); const_cast<ConvGeom&>(g).dbg = e ? atoi(e) : 0; }
     const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !(g.dbg & 32)) ? 1 : 0;
+    if (dtype == CN_BF16 && g.Ci == 16 && g.Co <= 16 && g.co_pad >= 16 && !g.res && !g.res32 && !g.y_f32 &&
+        (g.y_ld & 3) == 0 && (g.x_ld & 7) == 0 && !(g.dbg & 128)) {
+        const int64_t strips = (int64_t)g.N * g.H * ((g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS));
+        int64_t blocks = (strips + 3) / 4;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+        return true;
+    }
     const int co32 = (g.Co + 31) / 32 * 32;
     int bn = 32, bw = co32;
     for (int c : {64, 128}) {

@@ -565,6 +565,49 @@ extern "C" int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, in
     return CN_OK;
 }
 
+#define PACK_CHUNK 2048
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const int64_t* __restrict__ tab, int n) {
+    int lo = 0, hi = n - 1;                                 // last record whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid * 10 + 8] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = tab + lo * 10;
+    const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
+    T* __restrict__ wp = reinterpret_cast<T*>(e[1]);
+    const int A = (int)e[2], B = (int)e[3], taps = (int)e[4], mode = (int)e[5], rows_pad = (int)e[6], inner_pad = (int)e[7];
+    const int ktot = mode == 2 ? inner_pad : taps * inner_pad;
+    const int64_t total = (int64_t)rows_pad * ktot;
+    const int64_t base = ((int64_t)blockIdx.x - e[8]) * PACK_CHUNK;
+#pragma unroll
+    for (int j = 0; j < PACK_CHUNK / 256; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int r = (int)(i / ktot), k = (int)(i - (int64_t)r * ktot);
+        int a = -1, b = -1, t = 0;
+        if (mode == 2) {
+            t = r / B; b = r - t * B; a = k;
+            if (t >= taps) b = -1;
+        } else {
+            t = k / inner_pad;
+            const int c = k - t * inner_pad;
+            if (mode == 1) { a = r; b = c; } else { a = c; b = r; }
+        }
+        float v = 0.f;
+        if (a >= 0 && a < A && b >= 0 && b < B) v = w[((int64_t)a * B + b) * taps + t];
+        Elem<T>::st(wp + i, v);
+    }
+}
+
+extern "C" int cn_pack_weight_batch(const void* table, int n_entries, int n_blocks, int dtype, void* stream) {
+    CN_CHECK_ARG(table && n_entries > 0 && n_blocks > 0, "cn_pack_weight_batch: bad args");
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(pack_weight_batch_kernel<T>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream,
+                                                   (const int64_t*)table, n_entries));
+    CN_LAUNCH_CHECK("cn_pack_weight_batch");
+    return CN_OK;
+}
+
 // dw[a][b][t] = dwp[a][t*inner_pad + b]   (inverse of mode 1)
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int A,
                                                            int B, int taps, int inner_pad, int accumulate) {

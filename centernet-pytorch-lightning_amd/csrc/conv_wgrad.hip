@@ -230,9 +230,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
     for (int j = 0; j < V; ++j) s[j] = 0.f;
     if (prow < RPB && cv * V < C) {
         const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk < P ? r0 + rows_per_blk : P;
-        for (int64_t r = r0 + prow; r < r1; r += RPB) {
+        int64_t r = r0 + prow;
+        for (; r + 7 * RPB < r1; r += 8 * RPB) {          // 8 independent 16-byte loads in flight per thread
+            float v[8][V];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) Vec16<T>::load(dy + (r + u * RPB) * ld + cv * V, v[u]);   // ld is padded to a vector multiple
+#pragma unroll
+            for (int j = 0; j < V; ++j) s[j] += ((v[0][j] + v[1][j]) + (v[2][j] + v[3][j])) + ((v[4][j] + v[5][j]) + (v[6][j] + v[7][j]));
+        }
+        for (; r < r1; r += RPB) {
             float v[V];
-            Vec16<T>::load(dy + r * ld + cv * V, v);      // ld is padded to a vector multiple
+            Vec16<T>::load(dy + r * ld + cv * V, v);
 #pragma unroll
             for (int j = 0; j < V; ++j) s[j] += v[j];
         }
@@ -272,7 +280,7 @@ static int launch_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld
     const int CVB = CV < 256 ? CV : 256;
     const int RPB = 256 / CVB;
     int64_t nblk = (P + (int64_t)RPB * 16 - 1) / ((int64_t)RPB * 16);
-    if (nblk > 512) nblk = 512;
+    if (nblk > 256) nblk = 256;                       // same-address atomics serialise: few workgroups, deep loads
     if (nblk < 1) nblk = 1;
     const int64_t rows_per_blk = (P + nblk - 1) / nblk;
     dim3 grid((int)nblk, (CV + CVB - 1) / CVB);

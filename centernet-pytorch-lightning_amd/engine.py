@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
-from .ops import SideGrads
+from .ops import SideGrads, PackArena
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -184,11 +184,15 @@ class TrainStep:
     graph=True : the ~1600 launches of a step are captured once into two hipGraphs (zero_grad+forward+loss+backward |
                  Adam+post_step) and replayed, which removes the launch-bound gaps; the all-reduce runs between the two
                  graphs (79 MB over xGMI is < 1 ms, so losing the overlap costs less than the launch gaps did).
-    `post_step` (optional callable, no grad) runs after the optimizer — the bench uses it for ctdet_decode.
+    `post_step` (optional callable, no grad) runs after the optimizer.  `post_forward` (optional callable, no grad) is
+    forked onto its own stream right after the forward pass and joined at the end of the step, so work that only needs
+    the forward outputs (the bench's ctdet_decode of the head maps) overlaps backward instead of trailing it.
     """
 
-    def __init__(self, model, lr=None, distributed=None, graph=False, post_step=None, side_grads=True):
+    def __init__(self, model, lr=None, distributed=None, graph=False, post_step=None, side_grads=True, post_forward=None):
         self.model = model
+        self.post_forward, self._pf_stream = post_forward, None
+        PackArena.reset()
         lr = lr if lr is not None else getattr(model.hparams, "learning_rate", 1e-4)
         self.opt = FlatAdam(model.parameters(), lr=lr)
         self.graph, self.post_step, self.post_out = graph, post_step, None
@@ -203,14 +207,46 @@ class TrainStep:
         self._g1 = self._g2 = None
         self._bns = [m for m in model.modules() if hasattr(m, "_pending")]
 
+    def _fork_post_forward(self):
+        if self.post_forward is None:
+            return
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream()
+        self._pf_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._pf_stream), torch.no_grad():
+            self.post_out = self.post_forward()
+
+    def _join_post_forward(self):
+        if self.post_forward is not None:
+            torch.cuda.current_stream().wait_stream(self._pf_stream)
+
+    def _begin_packs(self):
+        """one launch packs every weight operand of the step (recorded during the first step)"""
+        if not self.opt.flat_p.is_cuda:
+            return
+        PackArena.active = True
+        if PackArena.table is not None:
+            PackArena.repack()
+        elif not PackArena.slots:
+            PackArena.recording = True
+
+    def _end_packs(self):
+        if PackArena.recording:
+            PackArena.build()
+        PackArena.active = False
+
     def _eager(self, batch, batch_idx=0):
         self.opt.zero_grad()
+        self._begin_packs()
         loss = self.model.training_step(batch, batch_idx)
+        self._fork_post_forward()
         if self.sync is not None and not self.graph:
             self.sync.begin()
         SideGrads.active = self.side
         loss.backward()
         SideGrads.join()
+        self._end_packs()
+        self._join_post_forward()
         if self.sync is not None:
             self.sync.allreduce_all() if self.graph else self.sync.finish()
         self.opt.step()
@@ -233,10 +269,14 @@ class TrainStep:
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g1):
             self.opt.zero_grad()
+            self._begin_packs()
             loss = self.model.training_step(static, 0)
+            self._fork_post_forward()
             SideGrads.active = self.side
             loss.backward()
             SideGrads.join()
+            self._end_packs()
+            self._join_post_forward()
             self._loss = loss.detach()
         for m in self._bns:
             m._pending -= 1          # the capture pass ran host code only; nothing executed on the device

@@ -31,9 +31,8 @@ def _bn_ws(npix, C, device):
 
 
 # ------------------------------------------------------------------------------------------------ packing
-def pack_weight(w, mode, dtype, row_scale=None):
-    """w: fp32 [A,B,KH,KW] parameter -> packed GEMM operand (see cn_pack_weight)."""
-    A, B, KH, KW = w.shape
+def _pack_dims(shape, mode):
+    A, B, KH, KW = shape
     taps = KH * KW
     if mode == 0:
         rows, inner = B, A
@@ -42,7 +41,74 @@ def pack_weight(w, mode, dtype, row_scale=None):
     else:
         rows, inner = taps * B, A
     rows_pad, inner_pad = rup(rows, 32), rup(inner, 16)
-    cols = inner_pad if mode == 2 else taps * inner_pad
+    return rows_pad, inner_pad, (inner_pad if mode == 2 else taps * inner_pad)
+
+
+class PackArena:
+    """Every weight packing a training step needs, produced by ONE launch at the start of the step.
+
+    A step packs each convolution weight once per use (forward operand, data-gradient operand, the DCN variants): ~160
+    launches of a few microseconds each.  The weights only change in the optimizer, so `TrainStep` records the requests
+    of its first step (`recording`), `build()`s persistent destinations plus the device table, and from then on calls
+    `repack()` once per step; `pack_weight` then returns the resident copy.  Only live inside a TrainStep
+    (`active`), keyed by (storage pointer, shape, mode, dtype); anything else falls back to a direct pack."""
+    active = False
+    recording = False
+    requests = {}
+    slots = {}
+    table = None
+    n_blocks = 0
+    dtype = None
+
+    @classmethod
+    def key(cls, w, mode, dtype):
+        return (w.data_ptr(), tuple(w.shape), mode, dtype)
+
+    @classmethod
+    def reset(cls):
+        cls.active = cls.recording = False
+        cls.requests, cls.slots, cls.table, cls.n_blocks, cls.dtype = {}, {}, None, 0, None
+
+    @classmethod
+    def build(cls):
+        cls.recording = False
+        reqs = list(cls.requests.items())
+        cls.requests = {}
+        if not reqs:
+            return
+        dts = {k[3] for k, _ in reqs}
+        if len(dts) != 1:                     # mixed compute dtypes: keep the per-layer packs
+            return
+        cls.dtype = dts.pop()
+        rows, blk = [], 0
+        for k, w in reqs:
+            mode = k[2]
+            A, B, KH, KW = w.shape
+            rows_pad, inner_pad, cols = _pack_dims(w.shape, mode)
+            wp = torch.empty((rows_pad, cols), dtype=cls.dtype, device=w.device)
+            cls.slots[k] = wp
+            rows.append([w.data_ptr(), wp.data_ptr(), A, B, KH * KW, mode, rows_pad, inner_pad, blk, 0])
+            blk += (rows_pad * cols + 2047) // 2048
+        cls.table = torch.tensor(rows, dtype=torch.int64).to(reqs[0][1].device)
+        cls.n_blocks = blk
+
+    @classmethod
+    def repack(cls):
+        if cls.table is not None:
+            call("cn_pack_weight_batch", cls.table, cls.table.shape[0], cls.n_blocks, dtype_code(cls.dtype))
+
+
+def pack_weight(w, mode, dtype, row_scale=None):
+    """w: fp32 [A,B,KH,KW] parameter -> packed GEMM operand (see cn_pack_weight)."""
+    if PackArena.active and row_scale is None:
+        k = PackArena.key(w, mode, dtype)
+        hit = PackArena.slots.get(k)
+        if hit is not None:
+            return hit
+        if PackArena.recording:
+            PackArena.requests[k] = w.detach()
+    A, B, KH, KW = w.shape
+    rows_pad, inner_pad, cols = _pack_dims(w.shape, mode)
     wp = torch.empty((rows_pad, cols), dtype=dtype, device=w.device)
     call("cn_pack_weight", w.detach().contiguous(), wp, A, B, KH, KW, mode, rows_pad, inner_pad, row_scale, dtype_code(dtype))
     return wp

@@ -53,6 +53,11 @@ int cn_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n,
  * of 16).  row_scale (nullable, fp32[rows]) multiplies each row (eval-mode BN folding). */
 int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, int KW, int mode, int rows_pad, int inner_pad,
                    const float* row_scale, int dtype, void* stream);
+/* All weight packings of a training step in ONE launch (the per-layer calls were ~160 tiny launches per step).
+ * table: device array of n_entries records of 10 int64:
+ *   { w (fp32 device pointer), wp (device pointer), A, B, KH*KW, mode, rows_pad, inner_pad, first_block, 0 }
+ * with first_block the running sum of ceil(rows_pad*row_len / 2048) over the preceding records and n_blocks its total. */
+int cn_pack_weight_batch(const void* table, int n_entries, int n_blocks, int dtype, void* stream);
 /* inverse of mode 1 for gradients: dw[a][b][t] (+)= dwp[a][t*inner_pad + b] (fp32 -> fp32); accumulate != 0 adds into dw
  * (used to deposit gradients straight into the flat gradient buffer from a side stream) */
 int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, int accumulate, void* stream);

@@ -44,6 +44,8 @@ def close(a, b, dt, what, scale=None):
 
 CONVS = [  # N,H,W,Ci,Co,k,s,p,bias,relu
     (2, 16, 16, 16, 16, 3, 1, 1, False, False),
+    (2, 9, 70, 16, 16, 3, 1, 1, True, True),       # direct 16-channel kernel, ragged row strips
+    (1, 33, 129, 16, 16, 3, 1, 1, False, False),
     (2, 17, 19, 32, 48, 3, 1, 1, True, True),
     (1, 16, 16, 64, 128, 3, 2, 1, False, False),
     (1, 15, 13, 64, 64, 3, 2, 1, False, False),
