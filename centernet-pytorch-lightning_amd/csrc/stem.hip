@@ -177,9 +177,16 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 }
 
 // used by cn_conv2d_wgrad for Ci <= 16 (packed output layout dwp[co][tap*Ci + ci])
+bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
+                           hipStream_t st);
+bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, hipStream_t st);
+
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
                         int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st) {
     if (Ci > 16) return false;
+    if (dtype == CN_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W &&
+        wgrad_c16_nhwc_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, st))
+        return true;
     if (dtype == CN_F32)
         return launch_small_wgrad<float>(x, false, (const float*)dy, dwp, N, Ci, x_ld, H, W, Co, dy_ld, KH, KW, stride, pad, OH, OW,
                                          KH * KW * Ci, 1, Ci, st);
@@ -217,7 +224,10 @@ extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
     bool ok;
-    if (dtype == CN_F32)
+    if (dtype == CN_BF16 && KH == 7 && KW == 7 && stride == 1 && pad == 3 && OH == H && OW == W &&
+        wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, (hipStream_t)stream))
+        ok = true;
+    else if (dtype == CN_F32)
         ok = launch_small_wgrad<float>(x, true, (const float*)dy, dw, N, Ci, 0, H, W, Co, Co, KH, KW, stride, pad, OH, OW,
                                        Ci * KH * KW, KH * KW, 1, (hipStream_t)stream);
     else if (dtype == CN_BF16)

@@ -1,0 +1,204 @@
+// Weight gradients of the two 512x512 layers with <= 16 channels on both sides (bf16 compute mode):
+//   * DLA level0   conv3x3 16 -> 16   (x: NHWC bf16)                dW[co][kh,kw][ci] += sum_p dY[p][co] x[p+(kh,kw)][ci]
+//   * the 7x7 stem conv 3 -> 16       (x: the fp32 NCHW input image)
+// Both are HBM streams (0.6-1 GB, ~80 GFLOP); the VALU kernel they used to share spent 2-3.5 ms on LDS reads.  Here one
+// WAVE owns an 8x16 pixel tile: dY tile [128 px][16 co] and the x halo tile [px][XPIX] sit in the wave's own LDS slab in
+// their natural pixel-major order and both MFMA operands come out of them with the transposing LDS read
+// (ds_read_b64_tr_b16), feeding v_mfma_f32_16x16x32_bf16 with M = co, K = 32 pixels, N = 16 columns:
+//   XPIX = 16 (NHWC x):   N = ci, one MFMA per (tap, 32-pixel chunk);
+//   XPIX = 4  (stem):     the halo is stored as {c0, c1, c2, 0} per pixel, so 16 consecutive bf16 starting at pixel q are
+//                         the 4 pixels q..q+3 x 4 channels = the columns n = (kw & 3, ci) of FOUR taps at once; two MFMAs
+//                         cover the 7 (+1 masked) kw of a kernel row.
+// The next tile is fetched into registers while the current one is multiplied; a workgroup's four waves fold their
+// accumulators through LDS and flush with one round of fp32 atomics.
+#include "dcn_common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define C16_TH 8
+#define C16_TW 16
+
+struct WgC16Geom {
+    const void* x;
+    const bf16_t* dy;
+    float* dw;
+    int N, H, W, Ci, x_ld, Co, dy_ld;
+    int os_co, os_ci, os_tap;          // dw[co*os_co + ci*os_ci + (kh*KW+kw)*os_tap]
+    int tiles_h, tiles_w, iters;
+};
+
+// 8 consecutive K (pixel) values of 16 columns out of a pixel-major LDS tile: rows are LDS element offsets row_of(k)
+template <typename RowFn>
+__device__ static inline bf16x8_t tr_frag_k32(const bf16_t* tile, int lane, RowFn row_of) {
+    const int r = lane & 15, g4 = lane >> 4;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + row_of(8 * g4 + (r >> 2)) + 4 * (r & 3)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + row_of(8 * g4 + 4 + (r >> 2)) + 4 * (r & 3)));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int XPIX, int KH, int KW>
+__global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
+    constexpr int PAD = KH / 2;
+    constexpr int HH = C16_TH + KH - 1;
+    constexpr int KWG = XPIX == 16 ? KW : (KW + 3) / 4;                       // MFMA column groups per kernel row
+    constexpr int HWD = XPIX == 16 ? C16_TW + KW - 1 : C16_TW + 4 * KWG - 1;  // halo row length (the last 4-pixel window starts at tx + 4*(KWG-1))
+    constexpr int HP = HH * HWD;
+    constexpr int DY_ELEMS = C16_TH * C16_TW * 16;
+    constexpr int X_ELEMS = HP * XPIX;
+    constexpr int SLAB = DY_ELEMS + X_ELEMS;
+    constexpr int NACC = KH * KWG;
+    constexpr int RED_ELEMS = NACC * 4 * 64 * 4 * 2;                          // fp32 [wave][NACC*4][64] of the final fold, in bf16 units
+    static_assert(SLAB % 8 == 0, "wave slabs must stay 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * SLAB > RED_ELEMS ? 4 * SLAB : RED_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16_t* const dyt = lds + wave * SLAB;
+    bf16_t* const xh = dyt + DY_ELEMS;
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+
+    f32x4_t acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int DYV = DY_ELEMS / 8 / 64;                                    // 16-byte vectors per lane (4)
+    constexpr int XV = XPIX == 16 ? (HP * 2 + 63) / 64 : (HP + 63) / 64;      // XPIX 16: 16-byte vectors;  XPIX 4: pixels (3 floats each)
+    uint4 rdy[DYV];
+    uint4 rx16[XPIX == 16 ? XV : 1];
+    float rx4[XPIX == 4 ? XV : 1][3];
+
+    auto gload = [&](int64_t tile) {
+        const bool tv = tile < ntiles;
+        const int64_t tc = tv ? tile : 0;
+        const int n = (int)(tc / (g.tiles_h * g.tiles_w));
+        const int r = (int)(tc - (int64_t)n * g.tiles_h * g.tiles_w);
+        const int th0 = (r / g.tiles_w) * C16_TH, tw0 = (r % g.tiles_w) * C16_TW;
+#pragma unroll
+        for (int v = 0; v < DYV; ++v) {
+            const int idx = lane + v * 64;
+            const int px = idx >> 1, hf = idx & 1;
+            const int oh = th0 + px / C16_TW, ow = tw0 + px % C16_TW;
+            const bool ok = tv && oh < g.H && ow < g.W && hf * 8 < g.dy_ld;
+            rdy[v] = ldg16_masked(g.dy, ((((int64_t)n * g.H + oh) * g.W + ow) * g.dy_ld + hf * 8) * 2, ok);
+        }
+        if constexpr (XPIX == 16) {
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                const int idx = lane + v * 64;
+                const int hp = idx >> 1, hf = idx & 1;
+                const int ih = th0 - PAD + hp / HWD, iw = tw0 - PAD + hp % HWD;
+                const bool ok = tv && hp < HP && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+                rx16[v] = ldg16_masked(g.x, ((((int64_t)n * g.H + ih) * g.W + iw) * g.x_ld + hf * 8) * 2, ok);
+            }
+        } else {
+            const float* X = reinterpret_cast<const float*>(g.x);
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                const int hp = lane + v * 64;
+                const int ih = th0 - PAD + hp / HWD, iw = tw0 - PAD + hp % HWD;
+                const bool ok = tv && hp < HP && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const bool okc = ok && c < g.Ci;
+                    const float val = X[okc ? (((int64_t)n * g.Ci + c) * g.H + ih) * g.W + iw : 0];
+                    rx4[v][c] = okc ? val : 0.f;
+                }
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int v = 0; v < DYV; ++v) *reinterpret_cast<uint4*>(dyt + (lane + v * 64) * 8) = rdy[v];
+        if constexpr (XPIX == 16) {
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                const int idx = lane + v * 64;
+                if (idx < HP * 2) *reinterpret_cast<uint4*>(xh + idx * 8) = rx16[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                const int hp = lane + v * 64;
+                if (hp < HP) *reinterpret_cast<uint2*>(xh + hp * 4) = make_uint2(pk_bf16(rx4[v][0], rx4[v][1]), pk_bf16(rx4[v][2], 0.f));
+            }
+        }
+    };
+
+    const int64_t stride_t = (int64_t)gridDim.x * 4;
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    gload(tile);
+#pragma unroll 1
+    for (int it = 0; it < g.iters; ++it, tile += stride_t) {
+        __syncthreads();                       // every wave is done reading its previous tile
+        lstore();
+        __syncthreads();
+        gload(tile + stride_t);                // in flight while this tile is multiplied (masked past the end)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {          // 32-pixel chunk = tile rows 2c, 2c+1
+            const bf16x8_t fa = tr_frag_k32(dyt, lane, [&](int kk) { return (32 * c + kk) * 16; });
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+                for (int kwg = 0; kwg < KWG; ++kwg) {
+                    const int kwb = XPIX == 16 ? kwg : 4 * kwg;
+                    const bf16x8_t fb = tr_frag_k32(xh, lane, [&](int kk) { return ((2 * c + (kk >> 4) + kh) * HWD + (kk & 15) + kwb) * XPIX; });
+                    acc[kh * KWG + kwg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[kh * KWG + kwg], 0, 0, 0);
+                }
+        }
+    }
+
+    // fold the four waves, then one round of atomics per workgroup.  D[co = 4*(lane>>4)+r][n = lane&15]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);                               // [wave][NACC*4][64]
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * NACC * 4 + a * 4 + r) * 64 + lane] = acc[a][r];
+    __syncthreads();
+    for (int i = tid; i < NACC * 4 * 64; i += 256) {
+        const float s = red[i] + red[NACC * 4 * 64 + i] + red[2 * NACC * 4 * 64 + i] + red[3 * NACC * 4 * 64 + i];
+        const int l = i & 63, r = (i >> 6) & 3, a = i >> 8;
+        const int kh = a / KWG, kwg = a % KWG;
+        const int co = 4 * (l >> 4) + r, nn = l & 15;
+        const int ci = XPIX == 16 ? nn : (nn & 3);
+        const int kw = XPIX == 16 ? kwg : 4 * kwg + (nn >> 2);
+        if (co < g.Co && ci < g.Ci && kw < KW) atomicAdd(g.dw + (int64_t)co * g.os_co + (int64_t)ci * g.os_ci + (int64_t)(kh * KW + kw) * g.os_tap, s);
+    }
+}
+
+template <int XPIX, int KH, int KW>
+static void launch_c16(WgC16Geom& g, hipStream_t st) {
+    g.tiles_h = cdiv(g.H, C16_TH); g.tiles_w = cdiv(g.W, C16_TW);
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    g.iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
+    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+}
+
+// bf16 NHWC x, 3x3 / stride 1 / pad 1, Ci == 16, Co <= 16 -> packed dwp[co][tap*16 + ci]
+bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
+                           hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
+    if (disabled || Ci != 16 || Co > 16 || (x_ld & 7) || (dy_ld & 7) || dy_ld < 16) return false;
+    WgC16Geom g;
+    g.x = x; g.dy = (const bf16_t*)dy; g.dw = dwp; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld;
+    g.os_co = 9 * Ci; g.os_ci = 1; g.os_tap = Ci;
+    launch_c16<16, 3, 3>(g, st);
+    return true;
+}
+
+// fp32 NCHW x (the image), 7x7 / stride 1 / pad 3, Ci <= 3, Co <= 16 -> dw[co][ci][kh][kw]
+bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
+    if (disabled || Ci > 3 || Co > 16 || (dy_ld & 7) || dy_ld < 16) return false;
+    WgC16Geom g;
+    g.x = x; g.dy = (const bf16_t*)dy; g.dw = dw; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = 0; g.Co = Co; g.dy_ld = dy_ld;
+    g.os_co = Ci * 49; g.os_ci = 49; g.os_tap = 1;
+    launch_c16<4, 7, 7>(g, st);
+    return true;
+}
