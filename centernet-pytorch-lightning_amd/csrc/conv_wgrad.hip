@@ -248,13 +248,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
 #pragma unroll
     for (int j = 0; j < V; ++j) red[tid][j] = s[j];
     __syncthreads();
+    int top = 1;
+    while (top < RPB) top <<= 1;
+    for (int st = top >> 1; st > 0; st >>= 1) {           // tree over the row slots (a serial fold by CVB threads took longer than the loads)
+        if (prow < st && prow + st < RPB) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) red[tid][j] += red[tid + st * CVB][j];
+        }
+        __syncthreads();
+    }
     if (prow == 0 && cv * V < C) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float a = 0.f;
-            for (int p = 0; p < RPB; ++p) a += red[p * CVB + cvl][j];
-            if (cv * V + j < C) atomicAdd(db + cv * V + j, a);
-        }
+        for (int j = 0; j < V; ++j)
+            if (cv * V + j < C) atomicAdd(db + cv * V + j, red[tid][j]);
     }
 }
 

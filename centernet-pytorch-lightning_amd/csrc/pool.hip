@@ -87,11 +87,25 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 }
 
 // y[n,oh,ow,c] = sum_{kh,kw : (oh+p-kh) % s == 0 ...} x[n,(oh+p-kh)/s,(ow+p-kw)/s,c] * w[c,kh,kw]
+// The [C][k][k] fp32 weights are staged in LDS TRANSPOSED to [tap][C]: a lane then reads the 8 (or 4) weights of its
+// channel vector with one or two ds_read_b128 instead of 8 strided global loads per tap (those loads, not the data
+// stream, were what bounded these kernels).  Dynamic LDS = k*k*C floats.
+__device__ static inline void dw_stage_weights(const float* __restrict__ w, float* wl, int C, int kk) {
+    for (int i = threadIdx.x; i < C * kk; i += blockDim.x) {
+        const int c = i / kk, t = i - c * kk;
+        wl[t * C + c] = w[i];
+    }
+    __syncthreads();
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            T* __restrict__ y, int N, int H, int W, int CV, int k, int s,
                                                            int p, int OH, int OW) {
     constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int C = CV * V;
+    dw_stage_weights(w, wl, C, k * k);
     const int64_t total = (int64_t)N * OH * OW * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
@@ -110,8 +124,9 @@ __global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__
                 if (ow + p - kw < 0 || iw >= W) continue;
                 float v[V];
                 Vec16<T>::load(x + ((((int64_t)n * H + ih) * W + iw) * CV + cv) * V, v);
+                const float* wt = wl + (kh * k + kw) * C + cv * V;
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], w[((cv * V + j) * k + kh) * k + kw], acc[j]);
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], wt[j], acc[j]);
             }
         }
         Vec16<T>::store(y + i * V, acc);
@@ -124,6 +139,9 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_input_kernel(const T* __rest
                                                                  T* __restrict__ dx, int N, int H, int W, int CV, int k,
                                                                  int s, int p, int OH, int OW) {
     constexpr int V = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int C = CV * V;
+    dw_stage_weights(w, wl, C, k * k);
     const int64_t total = (int64_t)N * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
@@ -137,20 +155,24 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_input_kernel(const T* __rest
         for (int kh = 0; kh < k; ++kh) {
             const int oh = ih * s - p + kh;
             if ((unsigned)oh >= (unsigned)OH) continue;
+            const T* row = dy + ((((int64_t)n * OH + oh) * OW) * CV + cv) * V;
+            const float* wr = wl + kh * k * C + cv * V;
+#pragma unroll 4
             for (int kw = 0; kw < k; ++kw) {
                 const int ow = iw * s - p + kw;
                 if ((unsigned)ow >= (unsigned)OW) continue;
                 float v[V];
-                Vec16<T>::load(dy + ((((int64_t)n * OH + oh) * OW + ow) * CV + cv) * V, v);
+                Vec16<T>::load(row + (int64_t)ow * CV * V, v);
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], w[((cv * V + j) * k + kh) * k + kw], acc[j]);
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], wr[kw * C + j], acc[j]);
             }
         }
         Vec16<T>::store(dx + i * V, acc);
     }
 }
 
-// dw[c,kh,kw] += sum_{n,ih,iw} x[n,ih,iw,c] * dy[n, ih*s-p+kh, iw*s-p+kw, c]; lane = (tap, channel vector)
+// dw[c,kh,kw] += sum_{n,ih,iw} x[n,ih,iw,c] * dy[n, ih*s-p+kh, iw*s-p+kw, c]; lane = (tap, channel vector).
+// Four pixels per trip keep eight independent 16-byte loads in flight per lane (the one-pixel loop was latency bound).
 template <typename T>
 __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                   float* __restrict__ dw, int N, int H, int W, int CV, int k,
@@ -165,17 +187,37 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __res
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
-    for (int64_t pix = p0; pix < p1; ++pix) {
-        const int iw = (int)(pix % W);
-        const int64_t t = pix / W;
-        const int ih = (int)(t % H), n = (int)(t / H);
-        const int oh = ih * s - p + kh, ow = iw * s - p + kw;
-        if ((unsigned)oh >= (unsigned)OH || (unsigned)ow >= (unsigned)OW) continue;
-        float a[V], b[V];
-        Vec16<T>::load(x + (pix * CV + cv) * V, a);
-        Vec16<T>::load(dy + ((((int64_t)n * OH + oh) * OW + ow) * CV + cv) * V, b);
+    for (int64_t pb = p0; pb < p1; pb += 4) {
+        uint4 ra[4], rb[4];
+        bool ok[4];
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], b[j], acc[j]);
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pix = pb + u;
+            const int iw = (int)(pix % W);
+            const int64_t t = pix / W;
+            const int ih = (int)(t % H), n = (int)(t / H);
+            const int oh = ih * s - p + kh, ow = iw * s - p + kw;
+            ok[u] = pix < p1 && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+            ra[u] = ldg16_masked(x, (pix * CV + cv) * 16, ok[u]);
+            rb[u] = ldg16_masked(dy, (((((int64_t)n * OH + oh) * OW + ow) * CV) + cv) * 16, ok[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float a[V], b[V];
+            if constexpr (sizeof(T) == 2) {
+                const uint32_t wa[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w}, wb[4] = {rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a[2 * q] = __uint_as_float(wa[q] << 16); a[2 * q + 1] = __uint_as_float(wa[q] & 0xffff0000u);
+                    b[2 * q] = __uint_as_float(wb[q] << 16); b[2 * q + 1] = __uint_as_float(wb[q] & 0xffff0000u);
+                }
+            } else {
+                a[0] = __uint_as_float(ra[u].x); a[1] = __uint_as_float(ra[u].y); a[2] = __uint_as_float(ra[u].z); a[3] = __uint_as_float(ra[u].w);
+                b[0] = __uint_as_float(rb[u].x); b[1] = __uint_as_float(rb[u].y); b[2] = __uint_as_float(rb[u].z); b[3] = __uint_as_float(rb[u].w);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], b[j], acc[j]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) atomicAdd(dw + ((int64_t)(cv * V + j) * k + kh) * k + kw, acc[j]);
@@ -219,8 +261,14 @@ extern "C" int cn_dwdeconv_fwd(const void* x, const float* w, void* y, int N, in
     CN_CHECK_ARG(x && w && y, "cn_dwdeconv_fwd: null");
     POOL_ARGS_CHECK("cn_dwdeconv_fwd");
     int64_t total = (int64_t)N * OH * OW * (C / V);
-    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_fwd_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
-                                                   (hipStream_t)stream, (const T*)x, w, (T*)y, N, H, W, C / V, k, stride, pad, OH, OW));
+    const size_t wbytes = (size_t)C * k * k * sizeof(float);
+    if (wbytes > 160 * 1024 - 1024) CN_UNSUPPORTED("dwdeconv_fwd_kernel: C*k*k = %d weights do not fit LDS", C * k * k);
+    if (wbytes > 48 * 1024) {
+        if (dtype == CN_F32) (void)hipFuncSetAttribute((const void*)dwdeconv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes);
+        else (void)hipFuncSetAttribute((const void*)dwdeconv_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes);
+    }
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_fwd_kernel<T>, dim3(pool_grid(total) > 2048 ? 2048 : pool_grid(total)), dim3(256),
+                                                   (size_t)C * k * k * sizeof(float), (hipStream_t)stream, (const T*)x, w, (T*)y, N, H, W, C / V, k, stride, pad, OH, OW));
     CN_LAUNCH_CHECK("cn_dwdeconv_fwd");
     return CN_OK;
 }
@@ -230,8 +278,14 @@ extern "C" int cn_dwdeconv_bwd_input(const void* dy, const float* w, void* dx, i
     CN_CHECK_ARG(dy && w && dx, "cn_dwdeconv_bwd_input: null");
     POOL_ARGS_CHECK("cn_dwdeconv_bwd_input");
     int64_t total = (int64_t)N * H * W * (C / V);
-    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_bwd_input_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
-                                                   (hipStream_t)stream, (const T*)dy, w, (T*)dx, N, H, W, C / V, k, stride, pad, OH, OW));
+    const size_t wbytes = (size_t)C * k * k * sizeof(float);
+    if (wbytes > 160 * 1024 - 1024) CN_UNSUPPORTED("dwdeconv_bwd_input_kernel: C*k*k = %d weights do not fit LDS", C * k * k);
+    if (wbytes > 48 * 1024) {
+        if (dtype == CN_F32) (void)hipFuncSetAttribute((const void*)dwdeconv_bwd_input_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes);
+        else (void)hipFuncSetAttribute((const void*)dwdeconv_bwd_input_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes);
+    }
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_bwd_input_kernel<T>, dim3(pool_grid(total) > 2048 ? 2048 : pool_grid(total)), dim3(256),
+                                                   (size_t)C * k * k * sizeof(float), (hipStream_t)stream, (const T*)dy, w, (T*)dx, N, H, W, C / V, k, stride, pad, OH, OW));
     CN_LAUNCH_CHECK("cn_dwdeconv_bwd_input");
     return CN_OK;
 }
