@@ -281,11 +281,10 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
         hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
         return true;
     }
-    const int co32 = (g.Co + 31) / 32 * 32;
-    int bn = 32, bw = co32;
+    int bn = 32, bnb = (g.Co + 31) / 32;               // same rule as pick_tile(): fewest channel blocks
     for (int c : {64, 128}) {
-        int w = (co32 + c - 1) / c * c;
-        if (w <= bw) { bn = c; bw = w; }
+        int nb = (g.Co + c - 1) / c;
+        if (nb < bnb) { bn = c; bnb = nb; }
     }
     if (dtype == CN_BF16) {
         if (g.Ci % 64 == 0 && !(g.dbg & 64)) {

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     constexpr int MI = WM / 32, NJ = WN / 32;
     constexpr int KSTEPS = BK / Mma<T>::KSTEP;
 
-    __shared__ __attribute__((aligned(16))) T lds[2 * (BM + BN) * PITCH];
     constexpr int BUF = (BM + BN) * PITCH;  // elements per pipeline stage: [A tile | B tile]
+    constexpr int EPI_ELEMS = (sizeof(T) == 2 && !DOM) ? WGM * 32 * (BN + 4) * 2 : 0;   // fp32 slab of the LDS-staged epilogue
+    __shared__ __attribute__((aligned(16))) T lds[2 * BUF > EPI_ELEMS ? 2 * BUF : EPI_ELEMS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cls = blockIdx.z;
@@ -73,36 +74,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         }
     }
 
-    uint4 ra[APASS], rb[BPASS];
-    auto gload = [&](int step) {
+    // Two register sets: slices are fetched TWO steps ahead (one L2 round trip is longer than one slice of MFMA work), with
+    // branch-free guarded loads so the compiler can keep counting the loads in flight (vmcnt(N), not vmcnt(0)).
+    uint4 ra[2][APASS], rb[2][BPASS];
+    auto gload = [&](uint4 (&qa)[APASS], uint4 (&qb)[BPASS], int step_raw) {
+        const int step = step_raw < nsteps ? step_raw : nsteps - 1;      // past the end: re-read the last slice (never used)
         const int t = step / cpt;
         const int c0 = (step - t * cpt) * BK;
         const int dh = g.dh[cls][t], dw = g.dw[cls][t];
         const int wofs = (int)g.wt[cls][t] * g.Ci + c0 + vcol;
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
-            int ih = a_ihb[p] + dh, iw = a_iwb[p] + dw;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-                v = *reinterpret_cast<const uint4*>(X + (a_img[p] + (int64_t)ih * g.W + iw) * g.x_ld + c0 + vcol);
-            ra[p] = v;
+            const int ih = a_ihb[p] + dh, iw = a_iwb[p] + dw;
+            qa[p] = ldg16_masked(X, ((a_img[p] + (int64_t)ih * g.W + iw) * g.x_ld + c0 + vcol) * (int64_t)sizeof(T),
+                                 (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W);
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
-            int row = lrow + p * RPP;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < BN && n0 + row < g.co_pad)
-                v = *reinterpret_cast<const uint4*>(Wp + (int64_t)(n0 + row) * g.ktot + wofs);
-            rb[p] = v;
+            int row = n0 + lrow + p * RPP;                               // rows past the packed matrix re-read its last row
+            row = row < g.co_pad ? row : g.co_pad - 1;
+            qb[p] = *reinterpret_cast<const uint4*>(Wp + (int64_t)row * g.ktot + wofs);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const uint4 (&qa)[APASS], const uint4 (&qb)[BPASS], int buf) {
 #pragma unroll
-        for (int p = 0; p < APASS; ++p) lds_store_vec<T, PITCH>((lds + buf * BUF), lrow + p * RPP, vcol, ra[p]);
+        for (int p = 0; p < APASS; ++p) lds_store_vec<T, PITCH>((lds + buf * BUF), lrow + p * RPP, vcol, qa[p]);
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
-            int row = lrow + p * RPP;
-            if (row < BN) lds_store_vec<T, PITCH>((lds + buf * BUF + BM * PITCH), row, vcol, rb[p]);
+            const int row = lrow + p * RPP;
+            if (BN % RPP == 0 || row < BN) lds_store_vec<T, PITCH>((lds + buf * BUF + BM * PITCH), row, vcol, qb[p]);
         }
     };
 
@@ -115,18 +115,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
             for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
     const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
-
-    if (nsteps > 0) {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        const bool more = step + 1 < nsteps;
-        if (more) gload(step + 1);
-        const T* at = (lds + cur * BUF);
-        const T* bt = (lds + cur * BUF + BM * PITCH);
+    auto compute = [&](int buf) {
+        const T* at = (lds + buf * BUF);
+        const T* bt = (lds + buf * BUF + BM * PITCH);
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             typename Mma<T>::Frag fa[MI], fb[NJ];
@@ -139,9 +130,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acc[j][i] = Mma<T>::mma(fb[j], fa[i], acc[j][i]);
         }
-        if (more) lstore(cur ^ 1);
+    };
+
+    if (nsteps > 0) {
+        gload(ra[0], rb[0], 0);
+        gload(ra[1], rb[1], 1);
+        lstore(ra[0], rb[0], 0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int step = 0; step < nsteps; step += 2) {
+        // slice `step` is in LDS buffer 0, slice step+1 in register set 1 (in flight)
+        gload(ra[0], rb[0], step + 2);
+        compute(0);
+        lstore(ra[1], rb[1], 1);
         __syncthreads();
-        cur ^= 1;
+        gload(ra[1], rb[1], step + 3);
+        if (step + 1 < nsteps) compute(1);
+        lstore(ra[0], rb[0], 0);
+        __syncthreads();
     }
 
     // ---- epilogue ----
@@ -160,6 +167,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         }
     }
     if constexpr (!DOM) {
+        if constexpr (sizeof(T) == 2) {
+            if (g.epi_tile) {                          // main loop ended on a barrier: the LDS is free
+                conv_epilogue_tile<MI, NJ, WGM, WGN>(g, acc, reinterpret_cast<float*>(lds), n0, tid, [&](int ml) -> int64_t {
+                    const int m = m0 + ml;
+                    if (m >= Mc) return -1;
+                    if (g.so == 1) return m;
+                    const int n = m / (OHc * OWc);
+                    const int r = m - n * (OHc * OWc);
+                    const int oh = r / OWc, ow = r - oh * OWc;
+                    return ((int64_t)n * g.OH + oh * g.so + ph) * g.OW + ow * g.so + pw;
+                });
+                return;
+            }
+        }
         conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
     } else {
         // fused DCNv2 offset / mask gradient (the GEMM result dcol is never stored to HBM)
@@ -352,16 +373,20 @@ static void launch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
     int OHc = (g.OH + so - 1) / so, OWc = (g.OW + so - 1) / so;
     int64_t Mc = (int64_t)g.N * OHc * OWc;
     dim3 grid(cdiv(Mc, 128), cdiv(g.Co, BN), ncls);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, BK>), grid, dim3(256), 0, st, g);
+    static const bool no_tile = getenv("CN_DISABLE_EPI_TILE") != nullptr;
+    ConvGeom gg = g;
+    gg.epi_tile = (!no_tile && conv_epi_tile_ok(g, sizeof(T) == 2 ? CN_BF16 : CN_F32)) ? 1 : 0;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BN, BK>), grid, dim3(256), 0, st, gg);
 }
 
-// tile choice: BN = smallest padded waste over {32,64,128} (ties -> larger); BK by divisibility of Ci
+// tile choice: BN over {32,64,128}; BK by divisibility of Ci
 static void pick_tile(int Ci, int Co, int dtype, int* bn_out, int* bk_out) {
-    int co32 = (Co + 31) / 32 * 32;
-    int best = 32, bestw = co32;
+    // fewest channel blocks first (every channel block re-reads the whole pixel operand from HBM/L2, while padded MFMA
+    // columns are nearly free), then the least padding
+    int best = 32, bestn = (Co + 31) / 32;
     for (int bn : {64, 128}) {
-        int w = (co32 + bn - 1) / bn * bn;
-        if (w <= bestw) { best = bn; bestw = w; }
+        int nb = (Co + bn - 1) / bn;
+        if (nb < bestn) { best = bn; bestn = nb; }
     }
     int bk = 16;
     if (dtype == CN_BF16) {

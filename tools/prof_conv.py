@@ -18,6 +18,15 @@ def conv(ci, co, hw, reps=3):
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
 if which == "conv":
     conv(64, 256, 128); conv(256, 64, 128); conv(64, 64, 128); conv(128, 128, 64); conv(256, 256, 32)
+elif which == "head":
+    def conv1(ci, co, hw, reps=3):
+        x = torch.randn(N, hw, hw, ci, device=dev).to(dt)
+        w = torch.randn(co, ci, 1, 1, device=dev) * 0.05
+        wp = ops.pack_weight(w, 1, dt)
+        for _ in range(reps):
+            y = ops._igemm(x, wp, None, None, co, 1, 1, 1, 0, False, False, hw, hw)
+        torch.cuda.synchronize()
+    conv1(16, 256, 128); conv1(80, 256, 128); conv1(256, 80, 128); conv1(128, 64, 128); conv1(320, 128, 64)
 elif which == "dcn":
     m = hnn.DCN(64, 64).to(dev)
     torch.nn.init.normal_(m.conv_offset_mask.weight, std=0.01)
