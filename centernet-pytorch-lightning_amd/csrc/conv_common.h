@@ -31,6 +31,7 @@ struct ConvGeom {
     const float* dcn_om;
     float* dcn_dom;
     float* dcn_far;
+    int* far_flag;        // nullable: set by the dom kernels when a far sample was scattered; read (and dx_far restored to 0) by the dx kernel
     int dcn_Ci, dcn_H, dcn_W, dcn_xld, dcn_omld;
     const float* res32;   // optional fp32 residual added in the epilogue (pitch res32_ld)
     int res32_ld;
@@ -78,7 +79,8 @@ __device__ static inline void lds_store_vec(T* tile, int row, int col, uint4 v) 
 // channels (r&3) + 8*(r>>2) + 4*(lane>>5), i.e. four groups of 4 consecutive channels -> 8/16-byte NHWC stores.
 // pix[i] = flat NHWC pixel index of this lane's pixel in M-subtile i, or -1 when it is outside the problem.
 template <typename T, int MI, int NJ>
-__device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[NJ][MI], const int64_t (&pix)[MI], int ch0, int lane) {
+__device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[NJ][MI], const int64_t (&pix)[MI], int ch0, int lane,
+                                            bool use_res32 = true) {
     T* __restrict__ Y = reinterpret_cast<T*>(g.y);
     const T* __restrict__ R = reinterpret_cast<const T*>(g.res);
 #pragma unroll
@@ -105,10 +107,14 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                     for (int e = 0; e < 4; ++e)
                         if (ch + e < g.Co) v[e] += Elem<T>::ld(R + px * g.res_ld + ch + e);
                 }
-                if (g.res32) {
+                if (g.res32 && use_res32) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (ch + e < g.Co) v[e] += g.res32[px * g.res32_ld + ch + e];
+                        if (ch + e < g.Co) {
+                            float* r = const_cast<float*>(g.res32) + px * g.res32_ld + ch + e;
+                            v[e] += *r;
+                            if (g.far_flag) *r = 0.f;       // lazy dx_far protocol: consumed once, left clean
+                        }
                 }
                 if (g.relu) {
 #pragma unroll
@@ -266,6 +272,7 @@ __device__ static inline void dcn_dom_accumulate(const ConvGeom& g, f32x16_t (&a
                     s_y = fmaf(gj, (1.f - t.lw) * (x10[e] - x00[e]) + t.lw * (x11[e] - x01[e]), s_y);
                     s_x = fmaf(gj, (1.f - t.lh) * (x01[e] - x00[e]) + t.lh * (x11[e] - x10[e]), s_x);
                     if (any_far) {
+                        if (g.far_flag) *g.far_flag = 1;
                         const float gm = gj * m;
                         float* far = g.dcn_far + c + e;
                         if (t.w00 != 0.f && (far_h0 || far_w0)) atomicAdd(far + i00 * Ci, gm * t.w00);
@@ -289,7 +296,7 @@ __device__ static inline void dcn_dom_accumulate(const ConvGeom& g, f32x16_t (&a
 // fused DCNv2 data-gradient kernel (dcn_fused.hip)
 void dcn_bwd_dx_launch(const ConvGeom& g, int dtype, hipStream_t st);
 void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st);
-bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, float* far,
+bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, float* far, int* far_flag,
                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, hipStream_t st);
 
 // 3x3 / stride 1 / pad 1 halo-tile kernel (conv3x3.hip); returns false when the shape is not handled there

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
                 const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
                 if (live[u] && (far_h0 || far_h1 || far_w0 || far_w1)) {       // samples the adjoint-gather window cannot see
                     const int64_t i00 = img + (int64_t)t.h0 * W + t.w0;
+                    if (g.far_flag) *g.far_flag = 1;
                     float* far = g.dcn_far + cb + lg * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -465,11 +466,12 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
 
 // dom / dx_far of the DCNv2 backward, fused into the GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2: [9*Ci][Co_pad16])
 extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, float* dx_far,
-                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype, void* stream) {
+                              int* far_flag, int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype,
+                              void* stream) {
     CN_CHECK_ARG(dy && wpd2 && x && om && dom && dx_far && N > 0 && H > 0 && W > 0, "cn_dcn_bwd_dom: bad args");
     if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dom: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
     CN_CHECK_ARG(om_ld >= 27 && x_ld >= Ci, "cn_dcn_bwd_dom: bad pitches");
-    if (dtype == CN_BF16 && dcn_bwd_dom_tile_launch(dy, wpd2, x, om, dom, dx_far, N, H, W, Ci, Co, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
+    if (dtype == CN_BF16 && dcn_bwd_dom_tile_launch(dy, wpd2, x, om, dom, dx_far, far_flag, N, H, W, Ci, Co, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_bwd_dom(tile)");
         return CN_OK;
     }
@@ -480,7 +482,7 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
     g.ktot = dy_ld; g.co_pad = (9 * Ci + 31) / 32 * 32;
     (void)Co;
     build_geom(g, 1, 1, 1, 0, 0);
-    g.dcn_x = x; g.dcn_om = om; g.dcn_dom = dom; g.dcn_far = dx_far;
+    g.dcn_x = x; g.dcn_om = om; g.dcn_dom = dom; g.dcn_far = dx_far; g.far_flag = far_flag;
     g.dcn_Ci = Ci; g.dcn_H = H; g.dcn_W = W; g.dcn_xld = x_ld; g.dcn_omld = om_ld;
     hipStream_t st = (hipStream_t)stream;
     const int64_t M = (int64_t)N * H * W;
@@ -525,7 +527,7 @@ extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const 
 
 // dx of the DCNv2 backward (adjoint-gather + contraction, dcn_fused.hip).  wpd0 = cn_pack_weight mode 0 of the layer weight
 // ([Ci rows][tap*Co_pad16 + co]); dx_far = fp32 [P][Ci] from cn_dcn_bwd_dom (added in the epilogue); dx in `dtype`.
-extern "C" int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, const float* dx_far, void* dx,
+extern "C" int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, float* dx_far, int* far_flag, void* dx,
                              int N, int H, int W, int Ci, int dy_ld, int om_ld, int dtype, void* stream) {
     CN_CHECK_ARG(dy && wpd0 && om && dx_far && dx && N > 0 && H > 0 && W > 0, "cn_dcn_bwd_dx: bad args");
     if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dx: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
@@ -536,7 +538,7 @@ extern "C" int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, 
     g.x = dy; g.w = wpd0; g.y = dx;
     g.N = N; g.H = H; g.W = W; g.Ci = dy_ld; g.x_ld = dy_ld; g.OH = H; g.OW = W; g.Co = Ci; g.y_ld = Ci;
     g.ktot = 9 * dy_ld; g.co_pad = (Ci + 31) / 32 * 32; g.so = 1; g.sm = 1;
-    g.dcn_om = om; g.dcn_omld = om_ld; g.res32 = dx_far; g.res32_ld = Ci;
+    g.dcn_om = om; g.dcn_omld = om_ld; g.res32 = dx_far; g.res32_ld = Ci; g.far_flag = far_flag;
     dcn_bwd_dx_launch(g, dtype, (hipStream_t)stream);
     CN_LAUNCH_CHECK("cn_dcn_bwd_dx");
     return CN_OK;

@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
         const int oh = th0 + m / DX_TW, ow = tw0 + m % DX_TW;
         pix[i] = (oh < g.H && ow < g.W) ? img + (int64_t)oh * g.W + ow : -1;
     }
-    conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
+    // lazy dx_far: only touched (added, then restored to zero) when a dom kernel flagged far samples for this layer
+    const bool use_far = g.res32 != nullptr && (g.far_flag == nullptr || *g.far_flag != 0);
+    conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane, use_far);
 }
 
 template <typename T, int BN, int CK>
@@ -430,7 +432,7 @@ void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st) {
 #define DM_HP (DM_HH * DM_HW)
 
 struct DomGeom {
-    const bf16_t* dy; const bf16_t* wd2; const bf16_t* x; const float* om; float* dom; float* far;
+    const bf16_t* dy; const bf16_t* wd2; const bf16_t* x; const float* om; float* dom; float* far; int* far_flag;
     int N, H, W, Ci, Co, dy_ld, x_ld, om_ld;
 };
 
@@ -652,6 +654,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
                 if (live && (far_h0 || far_h1 || far_w0 || far_w1)) {
                     const bool in_h0 = (unsigned)h0 < (unsigned)g.H, in_h1 = (unsigned)(h0 + 1) < (unsigned)g.H;
                     const bool in_w0 = (unsigned)w0 < (unsigned)g.W, in_w1 = (unsigned)(w0 + 1) < (unsigned)g.W;
+                    if (g.far_flag) *g.far_flag = 1;
                     float* far = g.far + (img + (int64_t)h0 * g.W + w0) * g.Ci + ci0 + lq * 16;
                     float gc[16];
                     Vec16<bf16_t>::load(Ds + pl * DP + lq * 16, gc);
@@ -669,7 +672,10 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
                 if (lq == 0 && live) {
                     float* d = g.dom + (img + (int64_t)h * g.W + w) * g.om_ld;
                     const float vy = sy * mk, vx = sx * mk, vm = sm * mk * (1.f - mk);
-                    if (whole) { d[2 * tap] = vy; d[2 * tap + 1] = vx; d[18 + tap] = vm; }
+                    if (whole) {
+                        d[2 * tap] = vy; d[2 * tap + 1] = vx; d[18 + tap] = vm;
+                        if (tap == 0) for (int c = 27; c < g.om_ld; ++c) d[c] = 0.f;     // channel padding
+                    }
                     else { atomicAdd(d + 2 * tap, vy); atomicAdd(d + 2 * tap + 1, vx); atomicAdd(d + 18 + tap, vm); }
                 }
             }
@@ -685,13 +691,13 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
 }
 
 // returns false when the shape is not handled by the tile-resident kernel
-bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, float* far,
+bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, float* far, int* far_flag,
                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_DOM_TILE") != nullptr;
     if (disabled || Ci % 64 != 0 || (dy_ld != 64 && dy_ld != 128)) return false;
     (void)Co;
     DomGeom g;
-    g.dy = (const bf16_t*)dy; g.wd2 = (const bf16_t*)wd2; g.x = (const bf16_t*)x; g.om = om; g.dom = dom; g.far = far;
+    g.dy = (const bf16_t*)dy; g.wd2 = (const bf16_t*)wd2; g.x = (const bf16_t*)x; g.om = om; g.dom = dom; g.far = far; g.far_flag = far_flag;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.dy_ld = dy_ld; g.x_ld = x_ld; g.om_ld = om_ld;
     const int ntiles = ((H + DX_TH - 1) / DX_TH) * ((W + DX_TW - 1) / DX_TW) * N;
     int gx = 256 / (Ci / 64);                   // one persistent workgroup per CU

@@ -44,6 +44,18 @@ def _pack_dims(shape, mode):
     return rows_pad, inner_pad, (inner_pad if mode == 2 else taps * inner_pad)
 
 
+_FAR_BUFFERS = {}
+
+
+def _far_buffer(shape, device):
+    """persistent all-zero fp32 scratch for DCN far samples (cn_dcn_bwd_dx restores the zeros it consumes)"""
+    key = (tuple(shape), str(device))
+    buf = _FAR_BUFFERS.get(key)
+    if buf is None:
+        buf = _FAR_BUFFERS[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return buf
+
+
 class PackArena:
     """Every weight packing a training step needs, produced by ONE launch at the start of the step.
 
@@ -554,10 +566,10 @@ class DCNv2Fn(Function):
         else:
             dwp, db = main_wgrad(None, True)
             dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
-        dx_far = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
-        dom32 = torch.zeros_like(om)
         dx_s = torch.empty_like(x)
         if _DCN_UNFUSED:
+            dx_far = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
+            dom32 = torch.zeros_like(om)
             # reference pipeline kept for A/B profiling: materialise dcol, then source + gather kernels
             wpd = pack_weight(weight, 2, x.dtype)                 # [9*Ci][Co]
             dcol = _igemm(dy, wpd, None, None, 9 * Ci, 1, 1, 1, 0, False, False, H, W)
@@ -570,10 +582,17 @@ class DCNv2Fn(Function):
             # fused: the 9x-wide column gradient never reaches HBM
             #   dom  <- epilogue of the GEMM dY x W^T (against the bilinear corner differences of x)
             #   dx   <- adjoint bilinear gather of dY (LDS hit lists) contracted with W, + far samples
-            call("cn_dcn_bwd_dom", dy, pack_weight(weight, 2, x.dtype), x, om, dom32, dx_far, N, H, W, Ci, Co,
+            # dx_far (samples displaced > 3 px: rare) follows the lazy protocol of the header: one persistent all-zero
+            # buffer per shape + a per-call flag, instead of clearing and re-reading 4*P*Ci bytes per layer per step
+            dx_far = _far_buffer((N, H, W, Ci), x.device)
+            far_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+            tile_whole = (x.dtype == torch.bfloat16 and Ci == 64 and dy.shape[-1] in (64, 128)
+                          and not _os.environ.get("CN_DISABLE_DOM_TILE"))
+            dom32 = torch.empty_like(om) if tile_whole else torch.zeros_like(om)   # the tile kernel writes all 32 channels
+            call("cn_dcn_bwd_dom", dy, pack_weight(weight, 2, x.dtype), x, om, dom32, dx_far, far_flag, N, H, W, Ci, Co,
                  dy.shape[-1], Ci, om.shape[-1], dt)
-            call("cn_dcn_bwd_dx", dy, pack_weight(weight, 0, x.dtype), om, dx_far, dx_s, N, H, W, Ci, dy.shape[-1],
-                 om.shape[-1], dt)
+            call("cn_dcn_bwd_dx", dy, pack_weight(weight, 0, x.dtype), om, dx_far, far_flag, dx_s, N, H, W, Ci,
+                 dy.shape[-1], om.shape[-1], dt)
         del dx_far
         if x.dtype == torch.float32:
             dom = dom32

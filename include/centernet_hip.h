@@ -149,10 +149,15 @@ int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int
  *     corner differences of x -> dom fp32 [P][om_ld] (channels 0..26; zeroed by the caller when Ci > 128), and scatters
  *     samples displaced by more than 3 px into dx_far (fp32 [P][Ci], zeroed by the caller).
  *   cn_dcn_bwd_dx: dx[q] = sum_k W_k^T G_k[q], G_k = adjoint bilinear sampling of dY (hit lists in LDS, atomic-free),
- *     + dx_far in the epilogue.  wpd0 = cn_pack_weight mode 0.  dy_ld must equal the weights' inner_pad = rup16(Co). */
+ *     + dx_far in the epilogue.  wpd0 = cn_pack_weight mode 0.  dy_ld must equal the weights' inner_pad = rup16(Co).
+ * Lazy dx_far protocol (far_flag != NULL, one int32 on the device, zeroed by the caller): dom sets the flag when it
+ * scattered at least one far sample; dx adds dx_far only if the flag is set and then writes zeros back, so the caller
+ * keeps ONE persistent zero-initialised dx_far per shape instead of clearing (and reading) 4*P*Ci bytes per layer per
+ * step.  far_flag == NULL: dx_far is zeroed by the caller and always added.  When Ci == 64 (one channel block) dom also
+ * writes the padding channels 27..om_ld-1 of `dom`, so the caller need not clear it. */
 int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, float* dx_far,
-                   int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype, void* stream);
-int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, const float* dx_far, void* dx,
+                   int* far_flag, int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype, void* stream);
+int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, float* dx_far, int* far_flag, void* dx,
                   int N, int H, int W, int Ci, int dy_ld, int om_ld, int dtype, void* stream);
 /* out[i] = a[i] + b[i] for fp32 a, b -> out in `dtype` (combines dx_tile + dx_far into the activation dtype) */
 int cn_add_f32_to(const float* a, const float* b, void* out, int64_t n, int dtype, void* stream);
