@@ -241,22 +241,16 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvGeom g) {
             for (int m = 0; m < 5; ++m)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[m], __builtin_bit_cast(bf16x8_t, xb[gq][m]), acc, 0, 0, 0);
             const int wq = seg * 16 * C16_GROUPS + gq * 16 + px;
-            if (wq < g.W && 4 * kc < g.Co) {
+            if (wq < g.W && 4 * kc < g.y_ld) {           // y_ld is a multiple of 4; padding channels are written as zeros
                 float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-                if (g.relu) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    if (g.relu == 1) v[r] = fmaxf(v[r], 0.f);
+                    if (4 * kc + r >= g.Co) v[r] = 0.f;
                 }
-                bf16_t* dst = Y + ((row * g.W) + wq) * g.y_ld + 4 * kc;
-                if (4 * kc + 4 <= g.Co) {
-                    uint2 o;
-                    o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (4 * kc + r < g.Co) dst[r] = f2bf(v[r]);
-                }
+                uint2 o;
+                o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2*>(Y + ((row * g.W) + wq) * g.y_ld + 4 * kc) = o;
             }
         }
     }
@@ -274,7 +268,7 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     { const char* e = getenv("CN_DBG"); const_cast<ConvGeom&>(g).dbg = e ? atoi(e) : 0; }
     const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !(g.dbg & 32)) ? 1 : 0;
     if (dtype == CN_BF16 && g.Ci == 16 && g.Co <= 16 && g.co_pad >= 16 && !g.res && !g.res32 && !g.y_f32 &&
-        (g.y_ld & 3) == 0 && (g.x_ld & 7) == 0 && !(g.dbg & 128)) {
+        (g.y_ld & 3) == 0 && g.y_ld <= 16 && (g.x_ld & 7) == 0 && !(g.dbg & 128)) {
         const int64_t strips = (int64_t)g.N * g.H * ((g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS));
         int64_t blocks = (strips + 3) / 4;
         if (blocks > 4096) blocks = 4096;

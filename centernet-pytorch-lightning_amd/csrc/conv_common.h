@@ -81,8 +81,10 @@ __device__ static inline void lds_store_vec(T* tile, int row, int col, uint4 v) 
 template <typename T, int MI, int NJ>
 __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[NJ][MI], const int64_t (&pix)[MI], int ch0, int lane,
                                             bool use_res32 = true) {
+    // channels Co .. y_ld-1 (the activation's zero padding) are WRITTEN as zeros, so callers allocate with empty()
     T* __restrict__ Y = reinterpret_cast<T*>(g.y);
     const T* __restrict__ R = reinterpret_cast<const T*>(g.res);
+    const bool mask_mode = g.relu == 2;          // ReLU-backward mask: y = (res > 0) ? y : 0 instead of y += res
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         if (pix[i] < 0) continue;
@@ -92,11 +94,11 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int ch = ch0 + j * 32 + 8 * q + 4 * (lane >> 5);
-                if (ch >= g.Co) continue;
+                if (ch >= g.y_ld) continue;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[j][i][q * 4 + e];
-                const bool full = (ch + 4 <= g.Co) && ((g.y_ld & 3) == 0) && (g.res == nullptr || (g.res_ld & 3) == 0);
+                const bool full = (ch + 4 <= g.y_ld) && ((g.y_ld & 3) == 0) && (g.res == nullptr || (g.res_ld & 3) == 0);
                 if (g.bias) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -105,7 +107,10 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                 if (R) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (ch + e < g.Co) v[e] += Elem<T>::ld(R + px * g.res_ld + ch + e);
+                        if (ch + e < g.Co) {
+                            const float r = Elem<T>::ld(R + px * g.res_ld + ch + e);
+                            v[e] = mask_mode ? (r > 0.f ? v[e] : 0.f) : v[e] + r;
+                        }
                 }
                 if (g.res32 && use_res32) {
 #pragma unroll
@@ -116,10 +121,13 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                             if (g.far_flag) *r = 0.f;       // lazy dx_far protocol: consumed once, left clean
                         }
                 }
-                if (g.relu) {
+                if (g.relu == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ch + e >= g.Co) v[e] = 0.f;
                 if (sizeof(T) == 2 && g.y_f32) {
                     float* dstf = reinterpret_cast<float*>(g.y) + px * g.y_ld + ch;
                     if (full) {
@@ -127,7 +135,7 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (ch + e < g.Co) dstf[e] = v[e];
+                            if (ch + e < g.y_ld) dstf[e] = v[e];
                     }
                     continue;
                 }
@@ -144,7 +152,7 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (ch + e < g.Co) Elem<T>::st(dst + e, v[e]);
+                        if (ch + e < g.y_ld) Elem<T>::st(dst + e, v[e]);
                 }
             }
         }
@@ -198,10 +206,15 @@ __device__ static inline void conv_epilogue_tile(const ConvGeom& g, f32x16_t (&a
             if (Rr) {
                 float r[8];
                 Vec16<bf16_t>::load(Rr + px * g.res_ld + ch, r);
+                if (g.relu == 2) {                       // ReLU-backward mask instead of a residual add
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                    for (int e = 0; e < 8; ++e) v[e] = r[e] > 0.f ? v[e] : 0.f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
             }
-            if (g.relu) {
+            if (g.relu == 1) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }

@@ -16,7 +16,8 @@ class HeadConv(nn.Module):
                                 hnn.Conv2d(head_conv, out_channels, 1, 1, 0, bias=True))
 
     def forward(self, x):
-        y = self.fc[2](self.fc[0](x, relu=True))
+        # the hidden ReLU's backward mask is applied in the 1x1 conv's data-gradient epilogue (no separate relu_bwd pass)
+        y = self.fc[2](self.fc[0](x, relu=True, defer_relu_bwd=True), mask_dx=True)
         return ops.ToNCHWFn.apply(y, self.out_channels)
 
     def fill_fc_weights(self):

@@ -31,9 +31,9 @@ class Conv2d(nn.Module):
         co, ci, k, _ = self.weight.shape
         return f"{ci}, {co}, kernel_size={k}, stride={self.stride}, padding={self.padding}, bias={self.bias is not None}"
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, mask_dx=False, defer_relu_bwd=False):
         if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
-            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu)
+            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu, mask_dx, defer_relu_bwd)
         return self.infer(x, None, None, None, relu)
 
     def infer(self, x, scale, shift, residual, relu, out_dtype=None):

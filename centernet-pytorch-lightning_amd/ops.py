@@ -178,8 +178,7 @@ def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH,
     N, H, W, Ci = x.shape
     cp = rup(Co, 16)
     out_dtype = out_dtype or x.dtype
-    alloc = torch.empty if cp == Co else torch.zeros
-    y = alloc((N, OH, OW, cp), dtype=out_dtype, device=x.device)
+    y = torch.empty((N, OH, OW, cp), dtype=out_dtype, device=x.device)    # the kernels write the channel padding as zeros
     call("cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
          residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
          dtype_code(x.dtype), dtype_code(out_dtype))
@@ -202,15 +201,18 @@ class Conv2dFn(Function):
     """nn.Conv2d (+bias, +ReLU) on NHWC.  weight fp32 [Co,Ci,KH,KW]; x channels = rup(Ci,16) (zero padded)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu):
+    def forward(ctx, x, weight, bias, stride, pad, relu, mask_dx=False, defer_relu_bwd=False):
+        """mask_dx: x is the output of a fused-ReLU producer that was built with defer_relu_bwd=True; this layer's data
+        gradient is then masked by (x > 0) in its own epilogue (relu mode 2) and the producer skips its cn_relu_bwd pass."""
         Co, Ci, KH, KW = weight.shape
         N, H, W, Cx = x.shape
         assert Cx == rup(Ci, 16), f"conv input has {Cx} channels, weight expects {Ci}"
         wp = pack_weight(weight, 1, x.dtype)
         OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
         y = _igemm(x, wp, bias, None, Co, KH, KW, stride, pad, False, relu, OH, OW)
-        ctx.save_for_backward(x, weight, y if relu else None)
-        ctx.cfg = (stride, pad, relu, bias is not None)
+        ctx.save_for_backward(x, weight, y if (relu and not defer_relu_bwd) else None)
+        ctx.cfg = (stride, pad, relu and not defer_relu_bwd, bias is not None)
+        ctx.mask_dx = mask_dx
         ctx.bias_ref = bias
         return y
 
@@ -237,8 +239,11 @@ class Conv2dFn(Function):
             wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
             if Cx != Ci:
                 raise RuntimeError("data gradient through a channel-padded conv input is not supported")
-            dx = _igemm(dy, wpd, None, None, Ci, KH, KW, stride, pad, True, False, H, W)
-        return dx, dw, db, None, None, None
+            if ctx.mask_dx:
+                dx = _igemm(dy, wpd, None, x, Ci, KH, KW, stride, pad, True, 2, H, W)
+            else:
+                dx = _igemm(dy, wpd, None, None, Ci, KH, KW, stride, pad, True, False, H, W)
+        return dx, dw, db, None, None, None, None, None
 
 
 class ConvTranspose2dFn(Function):
@@ -695,8 +700,8 @@ class GatherL1Fn(Function):
 
 
 # ------------------------------------------------------------------------------------------------ functional aliases
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
-    return Conv2dFn.apply(x, weight, bias, stride, pad, relu)
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, defer_relu_bwd=False):
+    return Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd)
 
 
 def conv_transpose2d(x, weight, stride=2, pad=1):

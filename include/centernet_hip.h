@@ -68,7 +68,9 @@ int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, i
  *                    data-gradient of a strided conv), taps that do not divide are skipped
  * x pitch = x_ld channels, y pitch = y_ld, residual pitch = res_ld (same dtype as y); bias fp32 nullable.
  * out_dtype = dtype, or CN_F32 to keep a bf16-computed result in fp32 (DCN offsets / mask logits).
- * Requires Ci % 16 == 0. */
+ * relu: 0 none, 1 ReLU, 2 = ReLU-BACKWARD mask: `residual` is not added, the result is zeroed where residual <= 0
+ *   (fuses the hidden ReLU's backward of the heads, heads.py:11-17, into the 1x1 conv's data gradient).
+ * Channels Co .. y_ld-1 of y (the activation's zero padding) are written as zeros.  Requires Ci % 16 == 0. */
 int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                   int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
                   int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype, void* stream);

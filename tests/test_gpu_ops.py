@@ -281,3 +281,28 @@ def test_adam_matches_torch():
         opt.step(); ref.step()
     for p, q in zip(ps, qs):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_head_conv_fused_relu_backward(dt):
+    """heads.py:4-25: conv3x3+ReLU -> conv1x1; the hidden ReLU's backward runs as the mask mode (relu=2) of the 1x1
+    conv's data-gradient epilogue.  Reference: plain torch autograd on the same (rounded) operands."""
+    from centernet_amd.models.heads import HeadConv
+    torch.manual_seed(0)
+    N, H, W, Cin, Cmid, Cout = 2, 9, 11, 64, 32, 5
+    head = HeadConv(Cout, Cin, Cmid).to(DEV)
+    x = rng.t_normal(21, "hx", (N, Cin, H, W))
+    with torch.no_grad():
+        for i, prm in enumerate(head.parameters()):
+            prm.copy_(rng.t_normal(21, f"hp{i}", tuple(prm.shape), 0, 0.1))
+    w1, b1, w2, b2 = [p.detach().cpu().clone().requires_grad_(True) for p in head.parameters()]
+    xr = rnd(x, dt).requires_grad_(True)
+    hr = F.relu(F.conv2d(xr, rnd(w1, dt), b1, 1, 1))
+    yr = F.conv2d(rnd(hr, dt) + (hr - hr.detach()), rnd(w2, dt), b2)          # hidden rounded like the kernel's output
+    gy = rng.t_normal(21, "hg", tuple(yr.shape))
+    yr.backward(gy)
+    xg = to_nhwc(x, dt).requires_grad_(True)
+    y = head(xg)                                                              # NCHW fp32 [N, Cout, H, W]
+    close(y.detach().cpu(), yr, dt, "head fwd")
+    y.backward(gy.to(DEV))
+    close(to_nchw(xg.grad), xr.grad, dt, "head dgrad (mask mode)")
