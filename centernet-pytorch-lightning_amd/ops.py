@@ -155,16 +155,35 @@ class SideGrads:
     def usable(cls, *params):
         return cls.active and cls.stream is not None and all(p is None or p.grad is not None for p in params)
 
+    pending = []          # (event on the main stream, closure, tensors) not yet launched
+
     @classmethod
-    def fork(cls, *tensors):
-        cls.stream.wait_stream(torch.cuda.current_stream())
-        for t in tensors:
-            if t is not None:
-                t.record_stream(cls.stream)
-        return torch.cuda.stream(cls.stream)
+    def submit(cls, fn, *tensors):
+        """Run `fn` (weight-gradient launches) on the side stream once everything enqueued on the main stream so far is
+        done.  The launch itself is DEFERRED to the next submit()/join(): by then the main stream has enqueued its own
+        continuation (the data gradient), so under hipGraph capture that continuation is the FIRST child of the
+        producer node and keeps the producer's queue — when the side branch was captured first, replay put main-chain
+        kernels behind weight-gradient kernels on the same hardware queue (5 ms of main-stream stalls per step)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        cls._flush()
+        cls.pending.append((ev, fn, tensors))
+
+    @classmethod
+    def _flush(cls):
+        todo, cls.pending = cls.pending, []
+        for ev, fn, tensors in todo:
+            cls.stream.wait_event(ev)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(cls.stream)
+            with torch.cuda.stream(cls.stream):
+                fn()
 
     @classmethod
     def join(cls):
+        if cls.stream is not None:
+            cls._flush()
         if cls.active and cls.stream is not None:
             torch.cuda.current_stream().wait_stream(cls.stream)
         cls.active = False
@@ -229,9 +248,10 @@ class Conv2dFn(Function):
             dy = g
         dx = dw = db = None
         if ctx.needs_input_grad[1] and Cx == Ci and SideGrads.usable(weight, ctx.bias_ref):
-            with SideGrads.fork(x, dy):
-                dwp, _ = _wgrad(x, dy, Co, KH, KW, stride, pad, False, db_into=ctx.bias_ref.grad if has_bias else None)
+            def side_work(x=x, dy=dy, bias=ctx.bias_ref):
+                dwp, _ = _wgrad(x, dy, Co, KH, KW, stride, pad, False, db_into=bias.grad if has_bias else None)
                 unpack_wgrad(dwp, Co, Ci, KH, KW, into=weight.grad)
+            SideGrads.submit(side_work, x, dy)
         elif ctx.needs_input_grad[1]:
             dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, has_bias and ctx.needs_input_grad[2])
             dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
@@ -269,9 +289,10 @@ class ConvTranspose2dFn(Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[1] and SideGrads.usable(weight):
-            with SideGrads.fork(x, dy):
+            def side_work(x=x, dy=dy):
                 dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
                 unpack_wgrad(dwp, Ci, Co, KH, KW, into=weight.grad)
+            SideGrads.submit(side_work, x, dy)
         elif ctx.needs_input_grad[1]:
             # dW[ci][co][t] = sum x[n,ih,iw,ci] * dy[n, ih*s-p+kh, iw*s-p+kw, co]: the wgrad kernel with roles swapped
             dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
@@ -305,9 +326,10 @@ class StemConvFn(Function):
         N, _, H, W = img.shape
         dy = dy.contiguous()
         if SideGrads.usable(weight):
-            with SideGrads.fork(img, dy):   # the kernel accumulates with atomics: deposit straight into weight.grad
+            def side_work(img=img, dy=dy):  # the kernel accumulates with atomics: deposit straight into weight.grad
                 call("cn_stem_conv_wgrad", img, dy, weight.grad, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2],
                      dtype_code(dy.dtype))
+            SideGrads.submit(side_work, img, dy)
             return None, None, None, None, None
         dw = torch.zeros_like(weight, dtype=torch.float32)
         call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))
@@ -431,8 +453,9 @@ class DwDeconvFn(Function):
             dx = torch.empty_like(x)
             call("cn_dwdeconv_bwd_input", dy, weight.detach().contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
         if ctx.needs_input_grad[1] and SideGrads.usable(weight):
-            with SideGrads.fork(x, dy):
+            def side_work(x=x, dy=dy):
                 call("cn_dwdeconv_bwd_weight", x, dy, weight.grad, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+            SideGrads.submit(side_work, x, dy)
         elif ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight, dtype=torch.float32)
             call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
@@ -565,9 +588,10 @@ class DCNv2Fn(Function):
             return _wgrad(c, dy, Co, 1, 1, 1, 0, want_bias, db_into=db_into)
 
         if side:
-            with SideGrads.fork(x, om, dy, col):
+            def side_work():
                 dwp, _ = main_wgrad(ctx.params[0].grad, False)
                 unpack_wgrad(dwp, Co, Ci, 3, 3, into=weight.grad)
+            SideGrads.submit(side_work, x, om, dy, col)
         else:
             dwp, db = main_wgrad(None, True)
             dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
@@ -606,9 +630,10 @@ class DCNv2Fn(Function):
             call("cn_cast", dom32, 0, dom, dt, dom32.numel())
         # offset/mask conv backward (its data gradient is added to the sampling gradient through `residual`)
         if side:
-            with SideGrads.fork(x, dom):
-                dwp_om, _ = _wgrad(x, dom, 27, 3, 3, 1, 1, False, db_into=ctx.params[2].grad)
-                unpack_wgrad(dwp_om, 27, Ci, 3, 3, into=ctx.params[1].grad)
+            def side_work_om(x=x, dom=dom, p1=ctx.params[1], p2=ctx.params[2]):
+                dwp_om, _ = _wgrad(x, dom, 27, 3, 3, 1, 1, False, db_into=p2.grad)
+                unpack_wgrad(dwp_om, 27, Ci, 3, 3, into=p1.grad)
+            SideGrads.submit(side_work_om, x, dom)
         else:
             dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)
             dw_om = unpack_wgrad(dwp_om, 27, Ci, 3, 3)
