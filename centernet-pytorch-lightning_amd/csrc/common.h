@@ -10,6 +10,7 @@
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 void cn_set_error(const char* fmt, ...);
+int cn_wgrad_target_blocks();   // target workgroup count of the split-K weight-gradient kernels (cn_set_wgrad_parallelism)
 
 #define CN_CHECK_ARG(cond, ...)                                                                     \
     do {                                                                                            \

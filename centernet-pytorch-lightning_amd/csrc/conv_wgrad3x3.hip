@@ -164,7 +164,7 @@ static void launch_w3(Wgrad3Geom& g, hipStream_t st) {
     g.ci_tiles = cdiv(g.Ci, BNW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
-    int64_t want = (1536 + par - 1) / par;                 // ~6 workgroups per CU over the whole launch
+    int64_t want = (cn_wgrad_target_blocks() + par - 1) / par;   // workgroups over the whole launch (see cn_set_wgrad_parallelism)
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     g.tiles_per_block = (int)((ntiles + want - 1) / want);
@@ -360,7 +360,7 @@ static void launch_dw(DcnWgradGeom& g, hipStream_t st) {
     g.ci_tiles = cdiv(g.Ci, BNW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
-    int64_t want = (1536 + par - 1) / par;
+    int64_t want = (cn_wgrad_target_blocks() + par - 1) / par;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     g.tiles_per_block = (int)((ntiles + want - 1) / want);

@@ -175,7 +175,8 @@ static void launch_c16(WgC16Geom& g, hipStream_t st) {
     g.tiles_h = cdiv(g.H, C16_TH); g.tiles_w = cdiv(g.W, C16_TW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     int64_t blocks = (ntiles + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    const int cap = cn_wgrad_target_blocks() / 3 < 128 ? 128 : cn_wgrad_target_blocks() / 3;   // default 512
+    if (blocks > cap) blocks = cap;
     g.iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
     hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW>), dim3((unsigned)blocks), dim3(256), 0, st, g);
 }

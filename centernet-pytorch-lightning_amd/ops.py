@@ -149,6 +149,8 @@ class SideGrads:
     def enable(cls, on=True):
         if on and cls.stream is None:
             cls.stream = torch.cuda.Stream()
+        # background-shaped weight-gradient grids while they share the GPU with the data-gradient chain
+        call("cn_set_wgrad_parallelism", int(_os.environ.get("CN_WGRAD_BLOCKS", 384 if on else 1536)))
         return on
 
     @classmethod

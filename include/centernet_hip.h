@@ -84,6 +84,9 @@ int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
                     int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                     int KH, int KW, int stride, int pad, int dtype, void* stream);
 
+/* Tunable: number of workgroups the split-K weight-gradient kernels spread over (default 1536 = ~6 per CU).  A host that
+ * runs them on a second stream beside the data-gradient chain lowers it (~384) so they stay in the background. */
+int cn_set_wgrad_parallelism(int blocks);
 /* bias gradient alone: db[c] += sum_p dy[p][c] (db accumulated into; dy_ld a vector multiple) */
 int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype, void* stream);
 
