@@ -33,56 +33,96 @@ extern "C" size_t cn_bn_workspace_bytes(int64_t npix, int C) {
 }
 
 // MODE 0: (sum x, sum x^2)      MODE 1: (sum dy', sum dy' * xhat)
+// ReLU mask of MODE 1: from the forward output y when given, else recomputed as fma(x, scale, shift) > 0 with the very
+// coefficients the forward pass applied (bit-identical decision, one tensor less to read).
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, float* __restrict__ part,
-                                                         int64_t npix, int C, BnLayout L, int relu) {
+                                                         const float* __restrict__ invstd, const float* __restrict__ ss,
+                                                         float* __restrict__ part, int64_t npix, int C, BnLayout L, int relu) {
     constexpr int V = Vec16<T>::N;
+    constexpr int U = 4;                                   // rows in flight per thread
     __shared__ float red[2][256][V + 1];
     const int tid = threadIdx.x;
     const int cvl = tid % L.CVB, prow = tid / L.CVB;
     const int cv = blockIdx.y * L.CVB + cvl;
     const bool active = prow < L.RPB && cv < L.CV;
-    float s0[V], s1[V], mu[V], is[V];
+    float s0[V], s1[V], mu[V], is[V], sc[V], sh[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) { s0[j] = 0.f; s1[j] = 0.f; mu[j] = 0.f; is[j] = 1.f; }
+    for (int j = 0; j < V; ++j) { s0[j] = 0.f; s1[j] = 0.f; mu[j] = 0.f; is[j] = 1.f; sc[j] = 0.f; sh[j] = 0.f; }
+    const bool mask_x = MODE == 1 && relu && y == nullptr;
     if (active) {
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < V; ++j) { mu[j] = mean[cv * V + j]; is[j] = invstd[cv * V + j]; }
+            if (mask_x) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) { sc[j] = ss[cv * V + j]; sh[j] = ss[C + cv * V + j]; }
+            }
         }
         const int64_t r0 = (int64_t)blockIdx.x * L.rows_per_blk;
         const int64_t r1 = r0 + L.rows_per_blk < npix ? r0 + L.rows_per_blk : npix;
-        for (int64_t r = r0 + prow; r < r1; r += L.RPB) {
-            float xv[V];
-            Vec16<T>::load(x + r * C + cv * V, xv);
-            if (MODE == 0) {
+        for (int64_t rb = r0 + prow; rb < r1; rb += (int64_t)U * L.RPB) {
+            uint4 xr[U], gr[U], yr[U];
 #pragma unroll
-                for (int j = 0; j < V; ++j) { s0[j] += xv[j]; s1[j] = fmaf(xv[j], xv[j], s1[j]); }
-            } else {
-                float gv[V], yv[V];
-                Vec16<T>::load(dy + r * C + cv * V, gv);
-                if (relu) {
-                    Vec16<T>::load(y + r * C + cv * V, yv);
-#pragma unroll
-                    for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+            for (int u = 0; u < U; ++u) {                  // branch-free: rows past the end re-read row rb and are masked
+                const int64_t r = rb + (int64_t)u * L.RPB;
+                const int64_t rc = r < r1 ? r : rb;
+                xr[u] = *reinterpret_cast<const uint4*>(x + rc * C + cv * V);
+                if (MODE == 1) {
+                    gr[u] = *reinterpret_cast<const uint4*>(dy + rc * C + cv * V);
+                    if (relu && !mask_x) yr[u] = *reinterpret_cast<const uint4*>(y + rc * C + cv * V);
                 }
+            }
 #pragma unroll
-                for (int j = 0; j < V; ++j) { s0[j] += gv[j]; s1[j] = fmaf(gv[j], (xv[j] - mu[j]) * is[j], s1[j]); }
+            for (int u = 0; u < U; ++u) {
+                const bool ok = rb + (int64_t)u * L.RPB < r1;
+                float xv[V], gv[V], yv[V];
+                Vec16<T>::unpack(xr[u], xv);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const float xx = ok ? xv[j] : 0.f;
+                        s0[j] += xx; s1[j] = fmaf(xx, xx, s1[j]);
+                    }
+                } else {
+                    Vec16<T>::unpack(gr[u], gv);
+                    if (relu) {
+                        if (mask_x) {
+#pragma unroll
+                            for (int j = 0; j < V; ++j) gv[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? gv[j] : 0.f;
+                        } else {
+                            Vec16<T>::unpack(yr[u], yv);
+#pragma unroll
+                            for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < V; ++j) {
+                        const float gg = ok ? gv[j] : 0.f;
+                        s0[j] += gg; s1[j] = fmaf(gg, (xv[j] - mu[j]) * is[j], s1[j]);
+                    }
+                }
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < V; ++j) { red[0][tid][j] = s0[j]; red[1][tid][j] = s1[j]; }
     __syncthreads();
+    int top = 1;
+    while (top < L.RPB) top <<= 1;
+    for (int st = top >> 1; st > 0; st >>= 1) {            // fixed-shape tree over the row slots: deterministic
+        if (prow < st && prow + st < L.RPB) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { red[0][tid][j] += red[0][tid + st * L.CVB][j]; red[1][tid][j] += red[1][tid + st * L.CVB][j]; }
+        }
+        __syncthreads();
+    }
     if (prow == 0 && cv < L.CV) {
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            float a = 0.f, b = 0.f;
-            for (int p = 0; p < L.RPB; ++p) { a += red[0][p * L.CVB + cvl][j]; b += red[1][p * L.CVB + cvl][j]; }
-            part[((int64_t)blockIdx.x * 2 + 0) * C + cv * V + j] = a;
-            part[((int64_t)blockIdx.x * 2 + 1) * C + cv * V + j] = b;
+            part[((int64_t)blockIdx.x * 2 + 0) * C + cv * V + j] = red[0][tid][j];
+            part[((int64_t)blockIdx.x * 2 + 1) * C + cv * V + j] = red[1][tid][j];
         }
     }
 }
@@ -92,7 +132,8 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ rmean, float* __restrict__ rvar,
                                                               float* __restrict__ smean, float* __restrict__ sinvstd,
-                                                              float* __restrict__ coef, float momentum, float eps) {
+                                                              float* __restrict__ coef, float* __restrict__ save_ss,
+                                                              float momentum, float eps) {
     // one wave per channel: lanes stride over the per-workgroup partials, fp64 butterfly
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -112,8 +153,10 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
     }
     const float sc = gamma[c] * invstd;
+    const float shf = beta[c] - (float)m * sc;
     coef[c] = sc;
-    coef[C + c] = beta[c] - (float)m * sc;
+    coef[C + c] = shf;
+    if (save_ss) { save_ss[c] = sc; save_ss[C + c] = shf; }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int C, int64_t npix,
@@ -158,8 +201,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
-                                                           T* __restrict__ dx, T* __restrict__ dres, int64_t nvec, int CV,
-                                                           int C, int relu) {
+                                                           const float* __restrict__ ss, T* __restrict__ dx,
+                                                           T* __restrict__ dres, int64_t nvec, int CV, int C, int relu) {
     constexpr int V = Vec16<T>::N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
         const int cv = (int)(i % CV);
@@ -167,9 +210,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         Vec16<T>::load(dy + i * V, gv);
         Vec16<T>::load(x + i * V, xv);
         if (relu) {
-            Vec16<T>::load(y + i * V, yv);
+            if (y) {
+                Vec16<T>::load(y + i * V, yv);
 #pragma unroll
-            for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+                for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+            } else {                                       // same decision as the forward pass, without reading y
+#pragma unroll
+                for (int j = 0; j < V; ++j) gv[j] = fmaf(xv[j], ss[cv * V + j], ss[C + cv * V + j]) > 0.f ? gv[j] : 0.f;
+            }
         }
         if (dres) Vec16<T>::store(dres + i * V, gv);
 #pragma unroll
@@ -203,7 +251,7 @@ static int ew_grid(int64_t nvec) {
 
 extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                               int64_t npix, int C, float momentum, float eps, int relu, int dtype,
+                               float* save_scale_shift, int64_t npix, int C, float momentum, float eps, int relu, int dtype,
                                void* ws, size_t ws_bytes, void* stream) {
     CN_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && ws && npix > 0 && C > 0, "cn_bn_train_fwd: bad args");
     int V = dtype == CN_F32 ? 4 : 8;
@@ -215,10 +263,10 @@ extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, con
     float* coef = part + (size_t)BN_MAX_BLOCKS * 2 * C;
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3(L.nblk, L.ycols), dim3(256), 0, st,
                                                    (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                                                   (const float*)nullptr, part, npix, C, L, 0));
+                                                   (const float*)nullptr, (const float*)nullptr, part, npix, C, L, 0));
     CN_LAUNCH_CHECK("cn_bn_train_fwd(partial)");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, beta,
-                       running_mean, running_var, save_mean, save_invstd, coef, momentum, eps);
+                       running_mean, running_var, save_mean, save_invstd, coef, save_scale_shift, momentum, eps);
     CN_LAUNCH_CHECK("cn_bn_train_fwd(finalize)");
     int64_t nvec = npix * (C / V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, st,
@@ -241,11 +289,11 @@ extern "C" int cn_scale_shift_act(const void* x, const void* residual, void* y, 
 }
 
 extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-                               const float* save_invstd, void* dx, void* dres, float* dgamma, float* dbeta,
-                               int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                               const float* save_invstd, const float* scale_shift, void* dx, void* dres, float* dgamma,
+                               float* dbeta, int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
     CN_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && npix > 0 && C > 0,
                  "cn_bn_train_bwd: bad args");
-    CN_CHECK_ARG(!relu || y, "cn_bn_train_bwd: relu needs the forward output");
+    CN_CHECK_ARG(!relu || y || scale_shift, "cn_bn_train_bwd: relu needs the forward output or the saved scale/shift");
     int V = dtype == CN_F32 ? 4 : 8;
     CN_CHECK_ARG(C % V == 0, "cn_bn_train_bwd: C=%d must be a multiple of %d", C, V);
     if (ws_bytes < cn_bn_workspace_bytes(npix, C)) { cn_set_error("cn_bn_train_bwd: workspace too small"); return CN_EWORKSPACE; }
@@ -254,8 +302,8 @@ extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, con
     float* part = (float*)ws;
     float* coef = part + (size_t)BN_MAX_BLOCKS * 2 * C;
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3(L.nblk, L.ycols), dim3(256), 0, st,
-                                                   (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, part, npix,
-                                                   C, L, relu));
+                                                   (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, scale_shift, part,
+                                                   npix, C, L, relu));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(partial)");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, save_invstd,
                        dgamma, dbeta, coef);
@@ -263,7 +311,7 @@ extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, con
     int64_t nvec = npix * (C / V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, st,
                                                    (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, coef,
-                                                   (T*)dx, (T*)dres, nvec, C / V, C, relu));
+                                                   scale_shift, (T*)dx, (T*)dres, nvec, C / V, C, relu));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(apply)");
     return CN_OK;
 }

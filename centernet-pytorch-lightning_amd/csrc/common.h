@@ -97,12 +97,23 @@ template <> struct Vec16<float> {
     __device__ static inline void store(float* p, const float* in) {
         *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
     }
+    __device__ static inline void unpack(const uint4& v, float* out) {
+        out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y); out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+    }
 };
 template <> struct Vec16<bf16_t> {
     static constexpr int N = 8;
     __device__ static inline void load(const bf16_t* p, float* out) {
         uint4 v = *reinterpret_cast<const uint4*>(p);
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[2 * i] = __uint_as_float(w[i] << 16);
+            out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static inline void unpack(const uint4& v, float* out) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             out[2 * i] = __uint_as_float(w[i] << 16);

@@ -347,18 +347,21 @@ class BatchNormActFn(Function):
         C = x.shape[-1]
         npix = x.numel() // C
         y = torch.empty_like(x)
-        mean = torch.empty(C, dtype=torch.float32, device=x.device)
-        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        stats = torch.empty((4, C), dtype=torch.float32, device=x.device)     # mean, invstd, scale, shift
+        mean, invstd, ss = stats[0], stats[1], stats[2:]
         ws, n = _bn_ws(npix, C, x.device)
-        call("cn_bn_train_fwd", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd,
+        call("cn_bn_train_fwd", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd, ss,
              npix, C, BN_MOMENTUM, BN_EPS, int(relu), dtype_code(x.dtype), ws, n)
-        ctx.save_for_backward(x, y if relu else None, gamma, mean, invstd)
+        # ReLU backward mask: without a residual input it is recomputed from x and the saved affine (y is not re-read)
+        need_y = relu and residual is not None
+        ctx.save_for_backward(x, y if need_y else None, gamma, stats)
         ctx.cfg = (relu, residual is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, stats = ctx.saved_tensors
+        mean, invstd, ss = stats[0], stats[1], stats[2:]
         relu, has_res = ctx.cfg
         C = x.shape[-1]
         npix = x.numel() // C
@@ -368,7 +371,7 @@ class BatchNormActFn(Function):
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         ws, n = _bn_ws(npix, C, x.device)
-        call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, dx, dres, dgamma, dbeta, npix, C, int(relu),
+        call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, dgamma, dbeta, npix, C, int(relu),
              dtype_code(x.dtype), ws, n)
         return dx, dgamma, dbeta, None, None, dres, None
 

@@ -100,18 +100,21 @@ int cn_stem_conv_wgrad(const float* x_nchw, const void* dy, float* dw, int N, in
 /* ---- batch norm (nn.BatchNorm2d, momentum 0.1) + ReLU + residual add ---------------------- */
 size_t cn_bn_workspace_bytes(int64_t npix, int C);
 /* training forward: batch statistics over npix rows; y = act(gamma*(x-mean)*invstd + beta [+ residual]);
- * updates running stats (unbiased var) in place; saves mean / invstd for backward. */
+ * updates running stats (unbiased var) in place; saves mean / invstd for backward.  save_scale_shift (nullable,
+ * fp32 [2][C]) receives the per-channel affine the apply pass used (y = act(fma(x, scale, shift) [+ residual])). */
 int cn_bn_train_fwd(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* save_mean, float* save_invstd,
-                    int64_t npix, int C, float momentum, float eps, int relu, int dtype,
+                    float* save_scale_shift, int64_t npix, int C, float momentum, float eps, int relu, int dtype,
                     void* ws, size_t ws_bytes, void* stream);
 /* y = act(x*scale[c] + shift[c] [+ residual])  (eval-mode BN when it cannot be folded into a conv) */
 int cn_scale_shift_act(const void* x, const void* residual, void* y, const float* scale, const float* shift,
                        int64_t npix, int C, int relu, int dtype, void* stream);
-/* training backward.  y = forward output (for the ReLU mask).  dres (nullable) receives the gradient that flows
- * to the residual input (= dy masked by ReLU). */
+/* training backward.  ReLU mask: from y (the forward output) when given; with y == NULL and scale_shift (the forward's
+ * save_scale_shift) given it is recomputed as fma(x, scale, shift) > 0 — the same decision bit for bit, one tensor less
+ * to read in each of the two passes (only valid for layers without a residual input).  dres (nullable) receives the
+ * gradient that flows to the residual input (= dy masked by ReLU). */
 int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-                    const float* save_invstd, void* dx, void* dres, float* dgamma, float* dbeta,
+                    const float* save_invstd, const float* scale_shift, void* dx, void* dres, float* dgamma, float* dbeta,
                     int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* dx = dy * (y > 0)  (ReLU backward for conv+bias+ReLU heads) */
 int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
