@@ -102,6 +102,19 @@ class ConvProbe:
         return by
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (FETCH_SIZE and WRITE_SIZE are
+    collected in separate rocprofv3 --pmc runs, see profiles/r01_pmc_traffic.json for the recipe and the gfx950
+    correction); None when no measurement of that kernel is on file."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec["kernels"][kernel]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds_budget=30.0):
     """The oracle (torch-CPU restatement of the reference path: same op sequence, pure-torch DCNv2) on the host cores:
     DLA-34 ctdet train step + decode, fp32, batch 2, 512x512.  Threads are capped at 16: on the 256-thread GPU host
@@ -218,10 +231,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_probe:
         # same step, launched eagerly, with a HIP event pair around every implicit-GEMM launch on the launch stream
         probe = ConvProbe(_hip, all_ops=bool(args.probe_detail))
+        side_was, step.side = step.side, False      # weight gradients on the launch stream: every launch is timed alone
         with probe:
             for _ in range(args.probe_steps):
                 step._eager(batch)
             torch.cuda.synchronize()
+        step.side = side_was
         if args.probe_detail:
             probe.detail(args.probe_detail, args.probe_steps)
             probe.detail_all(args.probe_detail + ".ops", args.probe_steps)
@@ -239,7 +254,7 @@ def main():
             ach = fl / tt / 1e12
             allf = sum(v[0] for v in by.values()); allt = sum(v[1] for v in by.values())
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": None,
+                    "traffic": pmc_traffic(kname(var)),
                     "how": f"HIP events around each launch, {args.probe_steps} eagerly launched step(s) of the same workload right after the timed region",
                     "kernel": kname(var),
                     "launches": n, "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": round(fl / n, 1),
