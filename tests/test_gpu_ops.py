@@ -306,3 +306,54 @@ def test_head_conv_fused_relu_backward(dt):
     close(y.detach().cpu(), yr, dt, "head fwd")
     y.backward(gy.to(DEV))
     close(to_nchw(xg.grad), xr.grad, dt, "head dgrad (mask mode)")
+
+
+def test_pack_weight_batch_matches_single():
+    """ops.PackArena / cn_pack_weight_batch: one launch, same bits as per-layer cn_pack_weight in all three modes."""
+    o = ops()
+    ws = [rng.t_normal(31, f"w{i}", shp).to(DEV) for i, shp in enumerate([(64, 64, 3, 3), (27, 64, 3, 3), (80, 256, 1, 1), (16, 3, 7, 7)])]
+    o.PackArena.reset()
+    o.PackArena.active = o.PackArena.recording = True
+    singles = []
+    for w in ws:
+        for mode in (0, 1, 2):
+            singles.append((w, mode, o.pack_weight(w, mode, torch.bfloat16)))
+    o.PackArena.build()
+    for v in o.PackArena.slots.values():          # poison the destinations, then repack in one launch
+        v.fill_(7.0)
+    o.PackArena.repack()
+    for w, mode, ref in singles:
+        got = o.pack_weight(w, mode, torch.bfloat16)
+        assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref), f"mode {mode} shape {tuple(w.shape)}"
+    o.PackArena.reset()
+
+
+def test_wgrad_thin_grids_same_result():
+    """cn_set_wgrad_parallelism only reshapes the split-K grid: the gradients must not change (fp32 atomics: tolerance)."""
+    o = ops()
+    x = to_nhwc(rng.t_normal(32, "x", (2, 64, 24, 40)), torch.bfloat16)
+    dy = to_nhwc(rng.t_normal(32, "g", (2, 64, 24, 40)), torch.bfloat16)
+    outs = []
+    for blocks in (1536, 48):
+        o.call("cn_set_wgrad_parallelism", blocks)
+        dwp, db = o._wgrad(x, dy, 64, 3, 3, 1, 1, True)
+        outs.append((dwp.clone(), db.clone()))
+    o.call("cn_set_wgrad_parallelism", 1536)
+    close(outs[1][0], outs[0][0], torch.float32, "thin-grid dW")
+    close(outs[1][1], outs[0][1], torch.float32, "thin-grid db")
+
+
+def test_dcn_far_buffer_is_left_clean():
+    """lazy dx_far protocol: after a backward with samples displaced > 3 px the persistent scratch is all zeros again."""
+    from centernet_amd import nn as hnn
+    o = ops()
+    m = hnn.DCN(64, 64).to(DEV)
+    with torch.no_grad():
+        m.conv_offset_mask.weight.normal_(0, 0.05)
+        m.conv_offset_mask.bias[:18].fill_(6.0)        # every sample lands ~6 px away: the far path
+    x = to_nhwc(rng.t_normal(33, "x", (1, 64, 20, 24)), torch.bfloat16).requires_grad_(True)
+    y = m(x)
+    y.backward(torch.ones_like(y))
+    buf = o._FAR_BUFFERS[((1, 20, 24, 64), str(x.device))]
+    assert float(buf.abs().max()) == 0.0
+    assert float(x.grad.float().abs().sum()) > 0.0
