@@ -23,7 +23,7 @@ from oracle.dcn_ref import DCN as OracleDCN  # noqa: E402
 
 refshim.install(OracleDCN)
 
-from CenterNet.models.backbones import msra_resnet, pose_dla_dcn  # noqa: E402
+from CenterNet.models.backbones import msra_resnet, pose_dla_dcn, resnet_dcn  # noqa: E402
 from CenterNet.models.heads import CenterHead  # noqa: E402
 from CenterNet.utils.losses import FocalLoss, RegL1Loss, RegWeightedL1Loss  # noqa: E402
 from CenterNet.utils.decode import sigmoid_clamped, _nms, _topk, _topk_channel  # noqa: E402
@@ -171,7 +171,8 @@ def model_fixture(name, net, head_conv, size, seed, train):
         first = [n for n in params if n.endswith("conv1.weight") or n.endswith("base_layer.0.weight")][0]
         picks = [first, "heads.0.heatmap.fc.2.weight", "heads.0.width_height.fc.0.weight"]
         picks += [n for n in params if "layer3.0.conv1.weight" in n or "level3.tree1.tree1.conv1.weight" in n
-                  or "deconv_layers.0.weight" in n or "ida_up.proj_1.conv.weight" in n
+                  or "deconv_layers.0.weight" in n or "deconv_layers.0.conv_offset_mask.weight" in n
+                  or "deconv_layers.3.weight" in n or "ida_up.proj_1.conv.weight" in n
                   or "ida_up.proj_1.conv.conv_offset_mask.weight" in n or "ida_up.up_2.weight" in n
                   or n.endswith("level2.root.bn.weight") or n.endswith("layer2.0.bn1.bias")]
         for n in picks:
@@ -197,6 +198,8 @@ def gen_models():
         model_fixture(f"res18_{'train' if train else 'eval'}.npz", net, 64, 256, 31, train)
         net = pose_dla_dcn.DLASeg("dla34", pretrained=False, down_ratio=4, final_kernel=1, last_level=5)
         model_fixture(f"dla34_{'train' if train else 'eval'}.npz", net, 256, 128, 32, train)
+        net = resnet_dcn.PoseResNet(*resnet_dcn.resnet_spec[18])          # SURVEY 8 f-1 (no ImageNet download: init_weights skipped)
+        model_fixture(f"resdcn18_{'train' if train else 'eval'}.npz", net, 64, 128, 33, train)
 
 
 def gen_pose():

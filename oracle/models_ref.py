@@ -104,6 +104,24 @@ class PoseResNet(nn.Module):
         return [self.deconv_layers(x)]
 
 
+class PoseResNetDCN(PoseResNet):
+    """resnet_dcn.py:131-261: the same ResNet trunk, up path 3x(DCN 3x3 -> BN -> ReLU -> ConvT 4x4/s2 -> BN -> ReLU) with
+    256/128/64 filters (resnet_dcn.py:146-150, 189-234); out_channels = 64 (resnet_dcn.py:134)."""
+
+    def __init__(self, num_layers=18):
+        super().__init__(num_layers)
+        from .dcn_ref import DCN
+        block, _ = RESNET_SPEC[num_layers]
+        self.out_channels = 64
+        self.inplanes = 512 * block.expansion
+        up = []
+        for planes in (256, 128, 64):
+            up += [DCN(self.inplanes, planes), _bn(planes), nn.ReLU(inplace=True),
+                   nn.ConvTranspose2d(planes, planes, 4, 2, 1, 0, bias=False), _bn(planes), nn.ReLU(inplace=True)]
+            self.inplanes = planes
+        self.deconv_layers = nn.Sequential(*up)
+
+
 # ----------------------------------------------------------------------------- DLA-34 + DCN up path
 class DlaBasic(nn.Module):
     """pose_dla_dcn.py:28-68 (residual is added before the last ReLU)."""
@@ -340,6 +358,8 @@ def create_model(arch):
     name, _, n = arch.partition("_")
     if name == "res":
         return PoseResNet(int(n))
+    if name == "resdcn":
+        return PoseResNetDCN(int(n))
     if name == "dla":
         assert int(n) == 34
         return DLASeg()

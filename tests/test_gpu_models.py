@@ -21,9 +21,10 @@ def _model(arch, seed, dtype, task="ctdet"):
 
 
 @pytest.mark.parametrize("arch,size,train", [("res_18", 256, False), ("res_18", 256, True),
-                                             ("dla_34", 128, False), ("dla_34", 128, True)])
+                                             ("dla_34", 128, False), ("dla_34", 128, True),
+                                             ("resdcn_18", 128, False), ("resdcn_18", 128, True)])
 def test_network_fp32_vs_reference_golden(golden, arch, size, train):
-    name = {"res_18": "res18", "dla_34": "dla34"}[arch] + ("_train" if train else "_eval") + ".npz"
+    name = {"res_18": "res18", "dla_34": "dla34", "resdcn_18": "resdcn18"}[arch] + ("_train" if train else "_eval") + ".npz"
     g = golden(name)
     seed = int(g["seed"])
     m = _model(arch, seed, torch.float32)
@@ -37,7 +38,8 @@ def test_network_fp32_vs_reference_golden(golden, arch, size, train):
         assert out[k].dtype == torch.float32 and out[k].shape[2:] == (size // 4, size // 4)
         ref_s = g[f"{k}_s"]
         assert np.abs(strided(out[k]).cpu().numpy() - ref_s).max() < 1e-4 * np.abs(ref_s).max() + 1e-6, k
-        np.testing.assert_allclose(summary(out[k]), g[f"{k}_sum"], rtol=1e-4, err_msg=k)
+        # (sum, sum|x|, sum x^2): the signed sum cancels (|sum| << sum|x|), so its 1e-4 is taken relative to sum|x|
+        np.testing.assert_allclose(summary(out[k]), g[f"{k}_sum"], rtol=1e-4, atol=1e-4 * float(g[f"{k}_sum"][1]), err_msg=k)
     raw = {k: v.detach().clone() for k, v in out.items()}
     with torch.set_grad_enabled(train):
         loss, st = m.loss(outs, tg)
@@ -69,8 +71,21 @@ def test_network_fp32_vs_reference_golden(golden, arch, size, train):
             assert float(sd["backbone.base.level3.project.1.num_batches_tracked"]) == 1
     else:
         det = m.decode({"heatmap": raw["heatmap"], "width_height": raw["width_height"], "regression": raw["regression"]})
-        np.testing.assert_allclose(det.cpu().numpy(), g["det"], rtol=1e-3, atol=2e-3)
-        assert np.array_equal(det[..., 5].cpu().numpy(), g["det"][..., 5]), "decoded classes identical"
+        got, ref = det.cpu().numpy(), g["det"]
+        if arch == "resdcn_18":
+            # this fixture has top-100 scores closer together than the 1e-4 heat-map tolerance: neighbouring ranks may
+            # swap.  Every reference detection must be present (same class, same box, same score), ranks may differ only
+            # between scores that are within 2e-4 of each other.
+            for b in range(ref.shape[0]):
+                for i, r in enumerate(ref[b]):
+                    d = np.abs(got[b][:, :4] - r[:4]).max(1) + 1e3 * (got[b][:, 5] != r[5])
+                    j = int(d.argmin())
+                    cutoff = abs(r[4] - ref[b][-1, 4]) < 2e-4 * r[4]           # may fall off the end of the top-100
+                    assert cutoff or (d[j] < 2e-3 + 1e-3 * np.abs(r[:4]).max() and abs(got[b][j, 4] - r[4]) < 1e-4), (b, i)
+                    assert cutoff or j == i or abs(ref[b][j, 4] - r[4]) < 2e-4 * r[4], (b, i, j)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-3)
+            assert np.array_equal(got[..., 5], ref[..., 5]), "decoded classes identical"
 
 
 @pytest.mark.parametrize("arch,size", [("res_18", 128), ("dla_34", 128)])

@@ -57,7 +57,7 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in src and "from oracle" not in src, f"{f} reaches into oracle/"
 
 
-@pytest.mark.parametrize("arch", ["res_18", "res_101", "dla_34"])
+@pytest.mark.parametrize("arch", ["res_18", "res_101", "dla_34", "resdcn_18", "resdcn_101"])
 def test_state_dict_surface_matches_reference_layout(arch):
     from centernet_amd.models import create_model
     from oracle import models_ref

@@ -107,9 +107,10 @@ def test_pose_decode(golden):
 
 
 @pytest.mark.parametrize("arch,size,train", [("res_18", 256, False), ("res_18", 256, True),
-                                             ("dla_34", 128, False), ("dla_34", 128, True)])
+                                             ("dla_34", 128, False), ("dla_34", 128, True),
+                                             ("resdcn_18", 128, False), ("resdcn_18", 128, True)])
 def test_model_matches_reference_graph(golden, arch, size, train):
-    name = {"res_18": "res18", "dla_34": "dla34"}[arch] + ("_train" if train else "_eval") + ".npz"
+    name = {"res_18": "res18", "dla_34": "dla34", "resdcn_18": "resdcn18"}[arch] + ("_train" if train else "_eval") + ".npz"
     g = golden(name)
     seed = int(g["seed"])
     net = models_ref.CenterNetRef(arch)
