@@ -192,6 +192,14 @@ int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uint8_t* mask,
                      const float* out3, const float* gout, float* dfeat,
                      int B, int C, int64_t HW, int N, int mask_has_c, void* stream);
 
+/* ---- ground-truth encoding (replaces the per-sample host loop of sample/ctdet.py:39-90) -------------- */
+/* boxes fp32 [B][M][4] = COCO (x, y, w, h) in input pixels, cls int32 [B][M], nobj int32 [B] (objects beyond nobj[b] are
+ * ignored).  heatmap fp32 [B][C][OH][OW] must be ZEROED by the caller (gaussians are max-splatted into it);
+ * mask uint8 [B][M], indices int64 [B][M], wh / reg fp32 [B][M][2] are fully written.  umich gaussians,
+ * min_overlap 0.7 (utils/gaussian.py:6-58). */
+int cn_encode_ctdet(const float* boxes, const int* cls, const int* nobj, float* heatmap, unsigned char* mask,
+                    int64_t* indices, float* wh, float* reg, int B, int M, int C, int OH, int OW, int down_ratio, void* stream);
+
 /* ---- decode (utils/decode.py, decode/ctdet.py, decode/multi_pose.py) -------------------------- */
 /* keep[b,c,h,w] = heat * (maxpool3x3(heat) == heat)   (utils/decode.py:5-10) */
 int cn_nms3x3(const float* heat, float* out, int B, int C, int H, int W, void* stream);

@@ -176,3 +176,43 @@ def test_focal_broadcast_gt():
     ref = ops_ref.focal_loss(pred, gt.expand_as(pred))
     out = FocalLoss()(pred.to(DEV), gt.to(DEV))
     assert out.item() == pytest.approx(ref.item(), rel=1e-5)
+
+
+def test_encode_ctdet_on_device(golden):
+    """cn_encode_ctdet vs the host restatement of sample/ctdet.py (synth.encode_ctdet, itself pinned to the
+    reference by encode_fixture.npz): indices / masks bit-exact, fp32 targets exact, gaussians within one ulp of expf."""
+    from centernet_amd import synth
+    from centernet_amd.sample import CenterDetectionSample, encode_ctdet_batch
+    B, M = 6, 128
+    boxes = np.zeros((B, M, 4), np.float32); cls = np.zeros((B, M), np.int32); cnt = np.zeros((B,), np.int32)
+    ref = []
+    for b in range(B):
+        bl = list(synth.FIXTURE_BOXES) if b == 0 else synth.random_boxes(77, b)
+        if b == 1:                                   # degenerate boxes (clipped to zero extent) and a box hanging over the border
+            bl = bl + [([600.0, 10.0, 20.0, 20.0], 3), ([500.0, 500.0, 40.0, 40.0], 5), ([-30.0, -30.0, 60.0, 90.0], 7)]
+        bl = [([float(np.float32(v)) for v in bb], c) for bb, c in bl]
+        for k, (bb, c) in enumerate(bl):
+            boxes[b, k], cls[b, k] = bb, c
+        cnt[b] = len(bl)
+        ref.append(synth.encode_ctdet(bl))
+    t = encode_ctdet_batch(torch.from_numpy(boxes).to(DEV), torch.from_numpy(cls).to(DEV), torch.from_numpy(cnt).to(DEV), 512, 512)
+    for b in range(B):
+        r = ref[b]
+        assert np.array_equal(t["regression_mask"][b].cpu().numpy(), r["regression_mask"])
+        assert np.array_equal(t["indices"][b].cpu().numpy(), r["indices"])
+        assert np.array_equal(t["width_height"][b].cpu().numpy(), r["width_height"])
+        assert np.array_equal(t["regression"][b].cpu().numpy(), r["regression"])
+        hm = t["heatmap"][b].cpu().numpy()
+        assert np.array_equal(hm != 0, r["heatmap"] != 0), "same support (gaussian truncation)"
+        np.testing.assert_allclose(hm, r["heatmap"], rtol=3e-7, atol=1e-7)
+        assert np.array_equal(hm == 1.0, r["heatmap"] == 1.0), "peaks are exactly 1"
+    # the reference's transform signature, on the reference's own annotation fixture
+    g = golden("encode_fixture.npz")
+    ann = [{"bbox": [float(v) for v in bb], "class_id": int(c)} for bb, c in zip(g["boxes"], g["cls"])]
+    _, one = CenterDetectionSample()(torch.zeros(3, 512, 512, device=DEV), ann)
+    assert np.array_equal(one["indices"].cpu().numpy(), g["indices"])
+    flat = one["heatmap"].flatten()
+    assert np.array_equal(torch.nonzero(flat).flatten().cpu().numpy(), g["heatmap_nz_idx"])
+    np.testing.assert_allclose(flat[flat != 0].cpu().numpy(), g["heatmap_nz_val"], rtol=3e-7, atol=1e-7)
+    np.testing.assert_allclose(one["width_height"].cpu().numpy(), g["width_height"], rtol=1e-6)
+    np.testing.assert_allclose(one["regression"].cpu().numpy(), g["regression"], rtol=1e-5, atol=1e-6)
