@@ -27,6 +27,14 @@ elif which == "head":
             y = ops._igemm(x, wp, None, None, co, 1, 1, 1, 0, False, False, hw, hw)
         torch.cuda.synchronize()
     conv1(16, 256, 128); conv1(80, 256, 128); conv1(256, 80, 128); conv1(128, 64, 128); conv1(320, 128, 64)
+elif which == "bn":
+    for (npix, C) in ((1 << 20, 64), (1 << 24, 16), (1 << 18, 128)):
+        bn = hnn.BatchNorm2d(C).to(dev)
+        x = torch.randn(npix // 1024, 32, 32, C, device=dev).to(dt).requires_grad_(True)
+        for _ in range(3):
+            y = bn(x, None, True)
+            y.backward(torch.randn_like(y))
+    torch.cuda.synchronize()
 elif which == "dcn":
     m = hnn.DCN(64, 64).to(dev)
     torch.nn.init.normal_(m.conv_offset_mask.weight, std=0.01)
