@@ -43,3 +43,20 @@ extern "C" int cn_adam_step(float* p, const float* g, float* m, float* v, int64_
     CN_LAUNCH_CHECK("cn_adam_step");
     return CN_OK;
 }
+
+// Step counter and bias corrections live ON THE DEVICE: hyper = {lr, 1-b1^t, 1-b2^t, t (int bits)}.  A captured graph
+// advances them itself, so a host that runs many replays ahead cannot race an asynchronous upload of per-step values.
+__global__ void adam_advance_kernel(float* __restrict__ hyper, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int t = __float_as_int(hyper[3]) + 1;
+    hyper[3] = __int_as_float(t);
+    hyper[1] = (float)(1.0 - pow((double)b1, (double)t));
+    hyper[2] = (float)(1.0 - pow((double)b2, (double)t));
+}
+
+extern "C" int cn_adam_advance(float* hyper, float b1, float b2, void* stream) {
+    CN_CHECK_ARG(hyper, "cn_adam_advance: null");
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, b1, b2);
+    CN_LAUNCH_CHECK("cn_adam_advance");
+    return CN_OK;
+}

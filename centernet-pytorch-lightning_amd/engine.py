@@ -43,9 +43,10 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)
         self.t = 0
         self.grad_scale = 1.0
-        # {lr, 1-b1^t, 1-b2^t} live in HBM so that a captured hipGraph replays with fresh values (cn_adam_step `hyper`)
-        self.hyper = torch.zeros(3, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(3)
+        # {lr, 1-b1^t, 1-b2^t, t} live in HBM and are advanced ON THE DEVICE (cn_adam_advance) inside the captured graph:
+        # a host that runs many replays ahead must not race per-step uploads
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._lr_dev = None
 
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
@@ -55,18 +56,25 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def prepare_step(self):
-        """Host half of a step: advance t and refresh the device-side hyper-parameters (never captured in a graph)."""
+        """Host half of a step (never captured in a graph): mirror t, upload the learning rate only when it changed."""
         g = self.param_groups[0]
         self.t += 1
-        b1, b2 = g["betas"]
-        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = float(g["lr"]), 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        if self._lr_dev != float(g["lr"]):
+            self._lr_dev = float(g["lr"])
+            self.hyper[0:1].fill_(self._lr_dev)
+
+    @torch.no_grad()
+    def set_step(self, t):
+        """restore the step counter (checkpoint resume): host mirror + device copy"""
+        self.t = int(t)
+        self.hyper[3:4].copy_(torch.tensor([self.t], dtype=torch.int32).view(torch.float32))
 
     @torch.no_grad()
     def launch(self):
         """Device half: one fused kernel over the flat buffers (hipGraph-capturable)."""
         g = self.param_groups[0]
         b1, b2 = g["betas"]
+        _hip.call("cn_adam_advance", self.hyper, float(b1), float(b2))
         _hip.call("cn_adam_step", self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.numel, float(g["lr"]),
                   float(b1), float(b2), float(g["eps"]), 1.0, 1.0, float(self.grad_scale), self.hyper)
 

@@ -228,6 +228,10 @@ int cn_multi_pose_decode(const float* heat, const float* wh, const float* kps, c
  * fp32[3] = {lr, bc1, bc2}) overrides the scalar arguments so that a captured hipGraph sees fresh values per replay. */
 int cn_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float bc1, float bc2, float grad_scale, const float* hyper, void* stream);
+/* t += 1 and the bias corrections of cn_adam_step's `hyper` buffer, on the device: hyper fp32[4] = {lr, 1-b1^t, 1-b2^t,
+ * t as int32 bits}.  Launched right before cn_adam_step (inside the same captured graph), so replays never depend on a
+ * per-step host upload; the host only writes hyper[0] when the learning rate changes and hyper[3] when it restores t. */
+int cn_adam_advance(float* hyper, float b1, float b2, void* stream);
 
 #ifdef __cplusplus
 }
