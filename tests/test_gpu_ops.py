@@ -345,7 +345,10 @@ def test_wgrad_thin_grids_same_result():
 
 def test_dcn_far_buffer_is_left_clean():
     """lazy dx_far protocol: after a backward with samples displaced > 3 px the persistent scratch is all zeros again."""
+    import os
     from centernet_amd import nn as hnn
+    if os.environ.get("CN_DCN_UNFUSED"):
+        pytest.skip("the A/B column-tensor pipeline clears its own dx_far")
     o = ops()
     m = hnn.DCN(64, 64).to(DEV)
     with torch.no_grad():
