@@ -23,6 +23,7 @@ __device__ static inline float key2f(uint32_t k) {
 struct __attribute__((aligned(16))) TkShared {   // sizeof is a multiple of 16 so the dynamic LDS behind it stays 16-B aligned
     uint32_t hist[256];
     uint32_t prefix, mask, need, cnt_g, cnt_e, n_eq, idx_thr, pad_;
+    uint32_t wsum[4];
     uint32_t sel_key[TK_MAXK];
     uint32_t sel_idx[TK_MAXK];
 };
@@ -42,28 +43,40 @@ __device__ static void block_topk(const uint32_t* keys, int L, int K, TkShared& 
             const int i = i0 + tid;
             const bool ok = i < L && ((keys[i] & mask) == prefix);
             const uint32_t bin = ok ? ((keys[i] >> shift) & 255u) : 0xffffffffu;
-            // wave-aggregate the most common case (every active lane in the same bin, e.g. the zeros left by NMS)
-            const uint32_t first = __shfl(bin, __ffsll((long long)__ballot(ok)) - 1, 64);
-            const unsigned long long same = __ballot(ok && bin == first);
-            if (ok) {
-                if (bin == first) {
-                    if (lane == __ffsll((long long)same) - 1) atomicAdd(&sh.hist[bin], (uint32_t)__popcll(same));
-                } else {
-                    atomicAdd(&sh.hist[bin], 1u);
-                }
+            // wave-level aggregation per DISTINCT bin (usually 1-3 per wave: the zeros left by the pseudo-NMS and one or two
+            // exponent bins of the peaks): one LDS atomic per bin instead of up to 64 same-address atomics
+            unsigned long long todo = __ballot(ok);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t lb = __shfl(bin, leader, 64);
+                const unsigned long long same = __ballot(ok && bin == lb);
+                if (lane == leader) atomicAdd(&sh.hist[lb], (uint32_t)__popcll(same));
+                todo &= ~same;
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            uint32_t need = sh.need, acc = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (acc + sh.hist[b] >= need) break;
-                acc += sh.hist[b];
+        // which bin holds the need-th largest key: descending inclusive scan of the histogram by 256 threads (a serial
+        // walk by one thread cost ~12 us per pass, 4 passes per map, 5120 maps per batch)
+        uint32_t h = 0, incl = 0;
+        if (tid < 256) {
+            h = sh.hist[255 - tid];
+            incl = h;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
             }
-            sh.need = need - acc;           // how many are still needed inside bin b
-            sh.prefix = prefix | ((uint32_t)b << shift);
-            sh.mask = mask | (255u << shift);
+            if (lane == 63) sh.wsum[tid >> 6] = incl;   // waves 0..3 own bins 255..192, 191..128, 127..64, 63..0
+        }
+        __syncthreads();
+        if (tid < 256) {
+            for (int w = 0; w < (tid >> 6); ++w) incl += sh.wsum[w];
+            const uint32_t need = sh.need;
+            if (incl >= need && incl - h < need) {      // exactly one thread: the crossing bin
+                sh.need = need - (incl - h);            // how many are still needed inside that bin
+                sh.prefix = prefix | ((uint32_t)(255 - tid) << shift);
+            }
+            if (tid == 0) sh.mask = mask | (255u << shift);
         }
         __syncthreads();
     }

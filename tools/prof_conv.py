@@ -27,6 +27,16 @@ elif which == "head":
             y = ops._igemm(x, wp, None, None, co, 1, 1, 1, 0, False, False, hw, hw)
         torch.cuda.synchronize()
     conv1(16, 256, 128); conv1(80, 256, 128); conv1(256, 80, 128); conv1(128, 64, 128); conv1(320, 128, 64)
+elif which == "topk":
+    from centernet_amd._hip import call
+    heat = torch.sigmoid(torch.randn(64, 80, 128, 128, device=dev) * 0.5 - 2.19)
+    sc = torch.empty(64, 80, 100, device=dev); ind = torch.empty(64, 80, 100, dtype=torch.int32, device=dev)
+    for nms in (1, 0, 1):
+        call("cn_topk_channel", heat, sc, ind, 64, 80, 128, 128, 100, nms)
+    nm = torch.empty_like(heat)
+    call("cn_nms3x3", heat, nm, 64, 80, 128, 128)
+    call("cn_topk_channel", nm, sc, ind, 64, 80, 128, 128, 100, 0)
+    torch.cuda.synchronize()
 elif which == "bn":
     for (npix, C) in ((1 << 20, 64), (1 << 24, 16), (1 << 18, 128)):
         bn = hnn.BatchNorm2d(C).to(dev)
