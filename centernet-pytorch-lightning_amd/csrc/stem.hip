@@ -180,7 +180,8 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
                            hipStream_t st);
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, hipStream_t st);
-bool stem7_fwd_launch(const float* x, const float* w, void* y, int N, int Ci, int H, int W, int Co, hipStream_t st);
+bool stem7_fwd_launch(const float* x, const float* w, void* y, int N, int Ci, int H, int W, int Co, int stride, int OH, int OW,
+                      hipStream_t st);
 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
                         int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st) {
@@ -209,8 +210,8 @@ extern "C" int cn_stem_conv_fwd(const float* x, const float* w, void* y, int N, 
     CN_CHECK_ARG(x && w && y && N > 0 && Co > 0, "cn_stem_conv_fwd: bad args");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
-    if (dtype == CN_BF16 && KH == 7 && KW == 7 && stride == 1 && pad == 3 && OH == H && OW == W &&
-        stem7_fwd_launch(x, w, y, N, Ci, H, W, Co, (hipStream_t)stream)) {
+    if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H + 6 - 7) / stride + 1 && OW == (W + 6 - 7) / stride + 1 &&
+        stem7_fwd_launch(x, w, y, N, Ci, H, W, Co, stride, OH, OW, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_stem_conv_fwd(mfma)");
         return CN_OK;
     }

@@ -205,34 +205,39 @@ bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int
 }
 
 // ---- 7x7 stem forward on the matrix cores (bf16 mode) --------------------------------------------------------------
-// y[p][co] = sum_{kh} sum_{(kw,ci)} w[co][ci][kh][kw] * x[ci][p + (kh-3, kw-3)].  With the halo stored as {c0,c1,c2,0}
-// per pixel, a whole kernel ROW (8 kw slots x 4 channel slots, 7 x 3 real) is exactly K = 32 of one
-// v_mfma_f32_16x16x32_bf16: A = weights [co][k = 4*kw + ci] (7 fragments in registers), B[k][px]: lane (px = lane&15,
-// g4 = lane>>4) needs k = 8*g4..+7 = pixels px+2*g4, px+2*g4+1 x 4 channels = 16 contiguous bytes of the halo row.
-// One wave = one 8x16 pixel tile = 8 x 7 MFMAs; D[co = 4*(lane>>4)+r][px]: 8-byte stores, 512 contiguous bytes per row.
+// y[p][co] = sum_{kh} sum_{(kw,ci)} w[co][ci][kh][kw] * x[ci][p*S + (kh-3, kw-3)]   (S = 1: DLA base layer, S = 2: ResNet stem).
+// With the halo stored as {c0,c1,c2,0} per input pixel, a whole kernel ROW (8 kw slots x 4 channel slots, 7 x 3 real) is
+// exactly K = 32 of one v_mfma_f32_16x16x32_bf16: A = weights [co][k = 4*kw + ci] (one fragment per kernel row and 16-channel
+// block, built once per workgroup in LDS), B[k][px]: lane (px = lane&15, g4 = lane>>4) needs k = 8*g4..+7 = input pixels
+// px*S+2*g4, px*S+2*g4+1 x 4 channels = 16 contiguous bytes of the halo row.  One wave = one 8x16 output tile = 8 rows x 7
+// MFMAs per 16-channel block; D[co = 4*(lane>>4)+r][px]: 8-byte stores.
+#define ST7_MAXCB 4
+template <int S>
 __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16_t* __restrict__ y,
-                                                        int N, int Ci, int H, int W, int Co, int y_ld, int tiles_h, int tiles_w, int iters) {
-    constexpr int HH = C16_TH + 6, HWD = C16_TW + 7, HP = HH * HWD;           // 14 x 23 halo pixels, 8 bytes each
+                                                        int N, int Ci, int H, int W, int Co, int y_ld, int OH, int OW, int tiles_h,
+                                                        int tiles_w, int iters) {
+    constexpr int HH = (C16_TH - 1) * S + 7, HWD = (C16_TW - 1) * S + 8, HP = HH * HWD;   // +1 column: the 8th (masked) kw slot
     constexpr int XV = (HP + 63) / 64;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * HP * 4];
+    __shared__ __attribute__((aligned(16))) uint4 wfrag[ST7_MAXCB * 7 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t halo[4 * HP * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    bf16_t* const xh = lds + wave * HP * 4;
+    bf16_t* const xh = halo + wave * HP * 4;
     const int px = lane & 15, g4 = lane >> 4;
+    const int ncb = (Co + 15) / 16;
     const int64_t ntiles = (int64_t)N * tiles_h * tiles_w;
 
-    bf16x8_t wa[7];
-#pragma unroll
-    for (int kh = 0; kh < 7; ++kh) {
+    for (int f = tid; f < ncb * 7 * 64; f += 256) {        // weight fragments: [cb][kh][lane]
+        const int l = f & 63, kh = (f >> 6) % 7, cb = f / (7 * 64);
+        const int co = cb * 16 + (l & 15), gg = l >> 4;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int kw = 2 * g4 + (j >> 2), ci = j & 3;
-            const bool ok = px < Co && ci < Ci && kw < 7;
-            const float val = w[ok ? ((int64_t)(px * Ci + ci) * 7 + kh) * 7 + kw : 0];
+            const int kw = 2 * gg + (j >> 2), ci = j & 3;
+            const bool ok = co < Co && ci < Ci && kw < 7;
+            const float val = w[ok ? ((int64_t)(co * Ci + ci) * 7 + kh) * 7 + kw : 0];
             v[j] = ok ? val : 0.f;
         }
-        const uint4 pk = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
-        wa[kh] = __builtin_bit_cast(bf16x8_t, pk);
+        wfrag[f] = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
     }
 
     float rx[XV][3];
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
             const int hp = lane + v * 64;
-            const int ih = th0 - 3 + hp / HWD, iw = tw0 - 3 + hp % HWD;
+            const int ih = th0 * S - 3 + hp / HWD, iw = tw0 * S - 3 + hp % HWD;
             const bool ok = tv && hp < HP && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -273,36 +278,46 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
         const int r = (int)(tc - (int64_t)n * tiles_h * tiles_w);
         const int th0 = (r / tiles_w) * C16_TH, tw0 = (r % tiles_w) * C16_TW;
         gload(tile + stride_t);
-#pragma unroll
+#pragma unroll 1
         for (int ty = 0; ty < C16_TH; ++ty) {
-            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            bf16x8_t fb[7];
 #pragma unroll
             for (int kh = 0; kh < 7; ++kh) {
-                const bf16_t* src = xh + ((ty + kh) * HWD + px + 2 * g4) * 4;       // 8-byte aligned: two ds_read_b64
+                const bf16_t* src = xh + ((ty * S + kh) * HWD + px * S + 2 * g4) * 4;      // 8-byte aligned: two ds_read_b64
                 const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 4);
-                const uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kh], __builtin_bit_cast(bf16x8_t, bv), acc, 0, 0, 0);
+                fb[kh] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
             }
             const int oh = th0 + ty, ow = tw0 + px;
-            if (tv && oh < H && ow < W && 4 * g4 < Co) {
-                bf16_t* dst = y + (((int64_t)n * H + oh) * W + ow) * y_ld + 4 * g4;
-                if (4 * g4 + 4 <= Co) *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
-                else
-                    for (int q = 0; q < 4 && 4 * g4 + q < Co; ++q) dst[q] = f2bf(acc[q]);
+            for (int cb = 0; cb < ncb; ++cb) {
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[(cb * 7 + kh) * 64 + lane]), fb[kh], acc, 0, 0, 0);
+                const int c0 = cb * 16 + 4 * g4;
+                if (tv && oh < OH && ow < OW && c0 < Co) {
+                    bf16_t* dst = y + (((int64_t)n * OH + oh) * OW + ow) * y_ld + c0;
+                    if (c0 + 4 <= Co) *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
+                    else
+                        for (int q = 0; q < 4 && c0 + q < Co; ++q) dst[q] = f2bf(acc[q]);
+                }
             }
         }
     }
 }
 
-// bf16 output, 7x7 / stride 1 / pad 3, Ci <= 3, Co <= 16
-bool stem7_fwd_launch(const float* x, const float* w, void* y, int N, int Ci, int H, int W, int Co, hipStream_t st) {
+// bf16 output, 7x7 / stride 1|2 / pad 3, Ci <= 3, Co <= 64 (multiple of 4)
+bool stem7_fwd_launch(const float* x, const float* w, void* y, int N, int Ci, int H, int W, int Co, int stride, int OH, int OW,
+                      hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
-    if (disabled || Ci > 3 || Co > 16 || (Co & 3)) return false;
-    const int tiles_h = cdiv(H, C16_TH), tiles_w = cdiv(W, C16_TW);
+    if (disabled || Ci > 3 || Co > 16 * ST7_MAXCB || (Co & 3) || (stride != 1 && stride != 2)) return false;
+    const int tiles_h = cdiv(OH, C16_TH), tiles_w = cdiv(OW, C16_TW);
     const int64_t ntiles = (int64_t)N * tiles_h * tiles_w;
     int64_t blocks = (ntiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const int iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
-    hipLaunchKernelGGL(stem7_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, tiles_h, tiles_w, iters);
+    if (stride == 1)
+        hipLaunchKernelGGL(stem7_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters);
+    else
+        hipLaunchKernelGGL(stem7_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters);
     return true;
 }
