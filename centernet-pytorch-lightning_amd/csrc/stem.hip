@@ -13,7 +13,8 @@
 template <typename T>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        T* __restrict__ y, int Ci, int H, int W, int Co, int KH, int KW,
-                                                       int stride, int pad, int OH, int OW, int tiles_w) {
+                                                       int stride, int pad, int OH, int OW, int tiles_w,
+                                                       const float* __restrict__ scale, const float* __restrict__ bias, int relu) {
     extern __shared__ float smem[];
     const int IH = (ST_TH - 1) * stride + KH, IW = (ST_TW - 1) * stride + KW;
     float* xt = smem;                       // [Ci][IH][IW]
@@ -57,6 +58,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
                 }
             }
         }
+    if (scale || bias || relu) {                 // folded eval-mode BN (+ReLU): y = act(fma(conv, scale, shift))
+#pragma unroll
+        for (int c = 0; c < ST_COB; ++c) {
+            const bool in = co0 + c < Co;
+            float v = acc[c];
+            v = fmaf(v, (scale && in) ? scale[co0 + c] : 1.f, (bias && in) ? bias[co0 + c] : 0.f);
+            acc[c] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
     const int oh = th0 + ty, ow = tw0 + tx;
     if (oh < OH && ow < OW) {
         T* dst = y + (((int64_t)n * OH + oh) * OW + ow) * Co + co0;
@@ -180,8 +190,8 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
                            hipStream_t st);
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, hipStream_t st);
-bool stem7_fwd_launch(const float* x, const float* w, void* y, int N, int Ci, int H, int W, int Co, int stride, int OH, int OW,
-                      hipStream_t st);
+bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
+                      int stride, int OH, int OW, hipStream_t st);
 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
                         int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st) {
@@ -205,13 +215,13 @@ static int stem_check(int Ci, int KH, int KW, int stride) {
     return CN_OK;
 }
 
-extern "C" int cn_stem_conv_fwd(const float* x, const float* w, void* y, int N, int Ci, int H, int W, int Co, int KH,
-                                int KW, int stride, int pad, int OH, int OW, int dtype, void* stream) {
+extern "C" int cn_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H,
+                                int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream) {
     CN_CHECK_ARG(x && w && y && N > 0 && Co > 0, "cn_stem_conv_fwd: bad args");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
     if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H + 6 - 7) / stride + 1 && OW == (W + 6 - 7) / stride + 1 &&
-        stem7_fwd_launch(x, w, y, N, Ci, H, W, Co, stride, OH, OW, (hipStream_t)stream)) {
+        stem7_fwd_launch(x, w, scale, bias, relu, y, N, Ci, H, W, Co, stride, OH, OW, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_stem_conv_fwd(mfma)");
         return CN_OK;
     }
@@ -220,7 +230,7 @@ extern "C" int cn_stem_conv_fwd(const float* x, const float* w, void* y, int N, 
     size_t smem = (size_t)(Ci * IH * IW + Ci * KH * KW * ST_COB) * sizeof(float);
     dim3 grid(tiles_h * tiles_w, cdiv(Co, ST_COB), N);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(stem_fwd_kernel<T>, grid, dim3(256), smem, (hipStream_t)stream, x, w, (T*)y,
-                                                   Ci, H, W, Co, KH, KW, stride, pad, OH, OW, tiles_w));
+                                                   Ci, H, W, Co, KH, KW, stride, pad, OH, OW, tiles_w, scale, bias, relu));
     CN_LAUNCH_CHECK("cn_stem_conv_fwd");
     return CN_OK;
 }

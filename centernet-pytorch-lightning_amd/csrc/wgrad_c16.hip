@@ -215,7 +215,8 @@ bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int
 template <int S>
 __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16_t* __restrict__ y,
                                                         int N, int Ci, int H, int W, int Co, int y_ld, int OH, int OW, int tiles_h,
-                                                        int tiles_w, int iters) {
+                                                        int tiles_w, int iters, const float* __restrict__ scale, const float* __restrict__ bias,
+                                                        int relu) {
     constexpr int HH = (C16_TH - 1) * S + 7, HWD = (C16_TW - 1) * S + 8, HP = HH * HWD;   // +1 column: the 8th (masked) kw slot
     constexpr int XV = (HP + 63) / 64;
     __shared__ __attribute__((aligned(16))) uint4 wfrag[ST7_MAXCB * 7 * 64];
@@ -289,11 +290,19 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
             }
             const int oh = th0 + ty, ow = tw0 + px;
             for (int cb = 0; cb < ncb; ++cb) {
+                const int c0 = cb * 16 + 4 * g4;
                 f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kh = 0; kh < 7; ++kh)
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[(cb * 7 + kh) * 64 + lane]), fb[kh], acc, 0, 0, 0);
-                const int c0 = cb * 16 + 4 * g4;
+                if (scale || bias || relu) {                // folded eval-mode BN (+ReLU): y = act(fma(conv, scale, shift))
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool in = c0 + q < Co;
+                        const float v = fmaf(acc[q], (scale && in) ? scale[c0 + q] : 1.f, (bias && in) ? bias[c0 + q] : 0.f);
+                        acc[q] = relu ? fmaxf(v, 0.f) : v;
+                    }
+                }
                 if (tv && oh < OH && ow < OW && c0 < Co) {
                     bf16_t* dst = y + (((int64_t)n * OH + oh) * OW + ow) * y_ld + c0;
                     if (c0 + 4 <= Co) *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
@@ -306,8 +315,8 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
 }
 
 // bf16 output, 7x7 / stride 1|2 / pad 3, Ci <= 3, Co <= 64 (multiple of 4)
-bool stem7_fwd_launch(const float* x, const float* w, void* y, int N, int Ci, int H, int W, int Co, int stride, int OH, int OW,
-                      hipStream_t st) {
+bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
+                      int stride, int OH, int OW, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
     if (disabled || Ci > 3 || Co > 16 * ST7_MAXCB || (Co & 3) || (stride != 1 && stride != 2)) return false;
     const int tiles_h = cdiv(OH, C16_TH), tiles_w = cdiv(OW, C16_TW);
@@ -316,8 +325,8 @@ bool stem7_fwd_launch(const float* x, const float* w, void* y, int N, int Ci, in
     if (blocks > 2048) blocks = 2048;
     const int iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
     if (stride == 1)
-        hipLaunchKernelGGL(stem7_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters);
+        hipLaunchKernelGGL(stem7_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters, scale, bias, relu);
     else
-        hipLaunchKernelGGL(stem7_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters);
+        hipLaunchKernelGGL(stem7_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters, scale, bias, relu);
     return true;
 }

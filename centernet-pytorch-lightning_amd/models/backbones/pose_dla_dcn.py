@@ -123,7 +123,7 @@ class DLA(nn.Module):
         return x
 
     def forward(self, img):
-        x = self.base_layer[1](self.base_layer[0](img, self.compute_dtype))
+        x = hnn.stem_bn_act(self.base_layer[0], self.base_layer[1], img, self.compute_dtype)
         y = []
         for i in range(6):
             level = getattr(self, f"level{i}")

@@ -40,7 +40,7 @@ class PoseResNet(_MsraPoseResNet):
         self.deconv_layers = nn.Sequential(*mods)
 
     def forward(self, img):
-        x = self.bn1(self.conv1(img, self.compute_dtype))
+        x = hnn.stem_bn_act(self.conv1, self.bn1, img, self.compute_dtype)
         x = self.maxpool(x)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         d = self.deconv_layers

@@ -107,6 +107,18 @@ class StemConv(nn.Module):
     def forward(self, img, dtype):
         return ops.StemConvFn.apply(img, self.weight, self.stride, self.padding, dtype)
 
+    def infer(self, img, dtype, scale, shift, relu):
+        """no-grad path with the following eval-mode BN (+ReLU) folded into the kernel's epilogue"""
+        return ops.stem_conv_infer(img, self.weight, scale, shift, self.stride, self.padding, relu, dtype)
+
+
+def stem_bn_act(stem, bn, img, dtype, relu=True):
+    """stem conv -> BN -> ReLU; one fused kernel in eval / no-grad mode"""
+    if bn.training or (torch.is_grad_enabled() and stem.weight.requires_grad):
+        return bn(stem(img, dtype), None, relu)
+    s, b = bn.folded()
+    return stem.infer(img, dtype, s, b, relu)
+
 
 class ConvTranspose2d(nn.Module):
     def __init__(self, cin, cout, k, stride, padding):

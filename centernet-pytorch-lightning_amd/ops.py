@@ -305,6 +305,17 @@ class ConvTranspose2dFn(Function):
         return dx, dw, None, None
 
 
+def stem_conv_infer(img, weight, scale, bias, stride, pad, relu, dtype):
+    """no-grad stem with an eval-mode BN (+ReLU) folded into the epilogue"""
+    Co, Ci, KH, KW = weight.shape
+    N, _, H, W = img.shape
+    OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
+    y = torch.empty((N, OH, OW, Co), dtype=dtype, device=img.device)
+    call("cn_stem_conv_fwd", img.contiguous(), weight.detach().contiguous(), scale, bias, y, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, int(relu),
+         dtype_code(dtype))
+    return y
+
+
 class StemConvFn(Function):
     """7x7 conv on the NCHW fp32 image (3 channels) -> NHWC activations; no data gradient (it is the input)."""
 
@@ -315,7 +326,8 @@ class StemConvFn(Function):
         OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
         img = img.contiguous()
         y = torch.empty((N, OH, OW, Co), dtype=dtype, device=img.device)
-        call("cn_stem_conv_fwd", img, weight.detach().contiguous(), y, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, dtype_code(dtype))
+        call("cn_stem_conv_fwd", img, weight.detach().contiguous(), None, None, y, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, 0,
+             dtype_code(dtype))
         ctx.save_for_backward(img, weight)
         ctx.cfg = (stride, pad)
         return y

@@ -91,9 +91,10 @@ int cn_set_wgrad_parallelism(int blocks);
 int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype, void* stream);
 
 /* Stem convolution for tiny Ci (3 input channels, 7x7): direct kernel on the NCHW fp32 image
- * (msra_resnet.py:110, pose_dla_dcn.py:282).  w is the raw fp32 parameter [Co,Ci,KH,KW]. */
-int cn_stem_conv_fwd(const float* x_nchw, const float* w, void* y, int N, int Ci, int H, int W, int Co,
-                     int KH, int KW, int stride, int pad, int OH, int OW, int dtype, void* stream);
+ * (msra_resnet.py:110, pose_dla_dcn.py:282).  w is the raw fp32 parameter [Co,Ci,KH,KW]; scale / bias (nullable fp32[Co])
+ * and relu fold an eval-mode BN + ReLU into the epilogue: y = act(fma(conv, scale, bias)). */
+int cn_stem_conv_fwd(const float* x_nchw, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H, int W, int Co,
+                     int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream);
 int cn_stem_conv_wgrad(const float* x_nchw, const void* dy, float* dw, int N, int Ci, int H, int W, int Co,
                        int KH, int KW, int stride, int pad, int OH, int OW, int dtype, void* stream);
 
