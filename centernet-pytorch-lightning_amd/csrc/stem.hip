@@ -189,7 +189,8 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 // used by cn_conv2d_wgrad for Ci <= 16 (packed output layout dwp[co][tap*Ci + ci])
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
                            hipStream_t st);
-bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, hipStream_t st);
+bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
+                           int OH, int OW, hipStream_t st);
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
                       int stride, int OH, int OW, hipStream_t st);
 
@@ -241,8 +242,8 @@ extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
     bool ok;
-    if (dtype == CN_BF16 && KH == 7 && KW == 7 && stride == 1 && pad == 3 && OH == H && OW == W &&
-        wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, (hipStream_t)stream))
+    if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
+        wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream))
         ok = true;
     else if (dtype == CN_F32)
         ok = launch_small_wgrad<float>(x, true, (const float*)dy, dw, N, Ci, 0, H, W, Co, Co, KH, KW, stride, pad, OH, OW,

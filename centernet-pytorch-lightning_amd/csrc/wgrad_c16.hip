@@ -26,7 +26,7 @@ struct WgC16Geom {
     const void* x;
     const bf16_t* dy;
     float* dw;
-    int N, H, W, Ci, x_ld, Co, dy_ld;
+    int N, H, W, Ci, x_ld, Co, dy_ld, OH, OW;      // dy is [N][OH][OW][dy_ld]; a launch's grid.y walks 16-channel blocks of Co
     int os_co, os_ci, os_tap;          // dw[co*os_co + ci*os_ci + (kh*KW+kw)*os_tap]
     int tiles_h, tiles_w, iters;
 };
@@ -42,12 +42,12 @@ __device__ static inline bf16x8_t tr_frag_k32(const bf16_t* tile, int lane, RowF
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int XPIX, int KH, int KW>
+template <int XPIX, int KH, int KW, int S = 1>
 __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     constexpr int PAD = KH / 2;
-    constexpr int HH = C16_TH + KH - 1;
+    constexpr int HH = (C16_TH - 1) * S + KH;
     constexpr int KWG = XPIX == 16 ? KW : (KW + 3) / 4;                       // MFMA column groups per kernel row
-    constexpr int HWD = XPIX == 16 ? C16_TW + KW - 1 : C16_TW + 4 * KWG - 1;  // halo row length (the last 4-pixel window starts at tx + 4*(KWG-1))
+    constexpr int HWD = XPIX == 16 ? C16_TW + KW - 1 : (C16_TW - 1) * S + 4 * KWG;   // halo row length (the last 4-pixel window starts at S*tx + 4*(KWG-1))
     constexpr int HP = HH * HWD;
     constexpr int DY_ELEMS = C16_TH * C16_TW * 16;
     constexpr int X_ELEMS = HP * XPIX;
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     bf16_t* const dyt = lds + wave * SLAB;
     bf16_t* const xh = dyt + DY_ELEMS;
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int co0 = blockIdx.y * 16;
 
     f32x4_t acc[NACC];
 #pragma unroll
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
             const int idx = lane + v * 64;
             const int px = idx >> 1, hf = idx & 1;
             const int oh = th0 + px / C16_TW, ow = tw0 + px % C16_TW;
-            const bool ok = tv && oh < g.H && ow < g.W && hf * 8 < g.dy_ld;
-            rdy[v] = ldg16_masked(g.dy, ((((int64_t)n * g.H + oh) * g.W + ow) * g.dy_ld + hf * 8) * 2, ok);
+            const bool ok = tv && oh < g.OH && ow < g.OW && co0 + hf * 8 < g.dy_ld;
+            rdy[v] = ldg16_masked(g.dy, ((((int64_t)n * g.OH + oh) * g.OW + ow) * g.dy_ld + co0 + hf * 8) * 2, ok);
         }
         if constexpr (XPIX == 16) {
 #pragma unroll
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
 #pragma unroll
             for (int v = 0; v < XV; ++v) {
                 const int hp = lane + v * 64;
-                const int ih = th0 - PAD + hp / HWD, iw = tw0 - PAD + hp % HWD;
+                const int ih = th0 * S - PAD + hp / HWD, iw = tw0 * S - PAD + hp % HWD;
                 const bool ok = tv && hp < HP && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
 #pragma unroll
                 for (int kwg = 0; kwg < KWG; ++kwg) {
                     const int kwb = XPIX == 16 ? kwg : 4 * kwg;
-                    const bf16x8_t fb = tr_frag_k32(xh, lane, [&](int kk) { return ((2 * c + (kk >> 4) + kh) * HWD + (kk & 15) + kwb) * XPIX; });
+                    const bf16x8_t fb = tr_frag_k32(xh, lane, [&](int kk) { return ((S * (2 * c + (kk >> 4)) + kh) * HWD + S * (kk & 15) + kwb) * XPIX; });
                     acc[kh * KWG + kwg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[kh * KWG + kwg], 0, 0, 0);
                 }
         }
@@ -163,22 +164,22 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
         const float s = red[i] + red[NACC * 4 * 64 + i] + red[2 * NACC * 4 * 64 + i] + red[3 * NACC * 4 * 64 + i];
         const int l = i & 63, r = (i >> 6) & 3, a = i >> 8;
         const int kh = a / KWG, kwg = a % KWG;
-        const int co = 4 * (l >> 4) + r, nn = l & 15;
+        const int co = co0 + 4 * (l >> 4) + r, nn = l & 15;
         const int ci = XPIX == 16 ? nn : (nn & 3);
         const int kw = XPIX == 16 ? kwg : 4 * kwg + (nn >> 2);
         if (co < g.Co && ci < g.Ci && kw < KW) atomicAdd(g.dw + (int64_t)co * g.os_co + (int64_t)ci * g.os_ci + (int64_t)(kh * KW + kw) * g.os_tap, s);
     }
 }
 
-template <int XPIX, int KH, int KW>
+template <int XPIX, int KH, int KW, int S = 1>
 static void launch_c16(WgC16Geom& g, hipStream_t st) {
-    g.tiles_h = cdiv(g.H, C16_TH); g.tiles_w = cdiv(g.W, C16_TW);
+    g.tiles_h = cdiv(g.OH, C16_TH); g.tiles_w = cdiv(g.OW, C16_TW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     int64_t blocks = (ntiles + 3) / 4;
     const int cap = cn_wgrad_target_blocks() / 3 < 128 ? 128 : cn_wgrad_target_blocks() / 3;   // default 512
     if (blocks > cap) blocks = cap;
     g.iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
-    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
 }
 
 // bf16 NHWC x, 3x3 / stride 1 / pad 1, Ci == 16, Co <= 16 -> packed dwp[co][tap*16 + ci]
@@ -188,19 +189,22 @@ bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int
     if (disabled || Ci != 16 || Co > 16 || (x_ld & 7) || (dy_ld & 7) || dy_ld < 16) return false;
     WgC16Geom g;
     g.x = x; g.dy = (const bf16_t*)dy; g.dw = dwp; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld;
+    g.OH = H; g.OW = W;
     g.os_co = 9 * Ci; g.os_ci = 1; g.os_tap = Ci;
     launch_c16<16, 3, 3>(g, st);
     return true;
 }
 
-// fp32 NCHW x (the image), 7x7 / stride 1 / pad 3, Ci <= 3, Co <= 16 -> dw[co][ci][kh][kw]
-bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, hipStream_t st) {
+// fp32 NCHW x (the image), 7x7 / stride 1|2 / pad 3, Ci <= 3, Co % 16 == 0 -> dw[co][ci][kh][kw]
+bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
+                           int OH, int OW, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
-    if (disabled || Ci > 3 || Co > 16 || (dy_ld & 7) || dy_ld < 16) return false;
+    if (disabled || Ci > 3 || (Co & 15) || (dy_ld & 7) || dy_ld < Co || (stride != 1 && stride != 2)) return false;
     WgC16Geom g;
     g.x = x; g.dy = (const bf16_t*)dy; g.dw = dw; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = 0; g.Co = Co; g.dy_ld = dy_ld;
+    g.OH = OH; g.OW = OW;
     g.os_co = Ci * 49; g.os_ci = 49; g.os_tap = 1;
-    launch_c16<4, 7, 7>(g, st);
+    if (stride == 1) launch_c16<4, 7, 7, 1>(g, st); else launch_c16<4, 7, 7, 2>(g, st);
     return true;
 }
 
