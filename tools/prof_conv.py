@@ -27,6 +27,16 @@ elif which == "head":
             y = ops._igemm(x, wp, None, None, co, 1, 1, 1, 0, False, False, hw, hw)
         torch.cuda.synchronize()
     conv1(16, 256, 128); conv1(80, 256, 128); conv1(256, 80, 128); conv1(128, 64, 128); conv1(320, 128, 64)
+elif which == "headbwd":
+    hw = 128
+    for ci in (16, 80):
+        dy = torch.randn(N, hw, hw, ci, device=dev).to(dt)
+        hid = torch.randn(N, hw, hw, 256, device=dev).to(dt)
+        w = torch.randn(ci, 256, 1, 1, device=dev) * 0.05            # forward weight [Co=ci][Ci=256]
+        wpd = ops.pack_weight(w, 0, dt)
+        for mode in (2, 0, 2):
+            dx = ops._igemm(dy, wpd, None, hid if mode == 2 else None, 256, 1, 1, 1, 0, True, mode, hw, hw)
+    torch.cuda.synchronize()
 elif which == "topk":
     from centernet_amd._hip import call
     heat = torch.sigmoid(torch.randn(64, 80, 128, 128, device=dev) * 0.5 - 2.19)
