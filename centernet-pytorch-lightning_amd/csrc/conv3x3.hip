@@ -102,14 +102,6 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
         }
     };
 
-    if (g.dbg >> 8) {                                  // experiment: de-phase the first wave of workgroups
-        const unsigned lb = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (lb < 2048) {
-            const unsigned hsh = (lb * 2654435761u) >> 29;           // 0..7
-            const uint64_t t0 = wall_clock64(), dt = (uint64_t)(g.dbg >> 8) * 6 * hsh;   // 100 MHz ticks; unit 0.5 us / 8
-            while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
-        }
-    }
     const int nchunks = g.Ci / CK;
     aload(0);
 #pragma unroll
@@ -165,7 +157,6 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
         const int oh = th0 + m / T3_TW, ow = tw0 + m % T3_TW;
         pix[i] = (oh < g.OH && ow < g.OW) ? ((int64_t)n * g.OH + oh) * g.OW + ow : -1;
     }
-    if ((g.dbg & 1) && acc[0][0][0] != 12345.678f) return;
     if constexpr (sizeof(T) == 2) {
         if (g.epi_tile) {                              // main loop ended on a barrier: the LDS is free
             conv_epilogue_tile<MI, NJ, WGM, WGN>(g, acc, reinterpret_cast<float*>(lds), n0, tid, [&](int m) -> int64_t {
@@ -265,10 +256,10 @@ static void launch3(const ConvGeom& g, hipStream_t st) {
 bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     // caller guarantees: 3x3, stride 1, pad 1 geometry in class 0 of g (normal or mirrored taps), OH == H, OW == W
     if (g.N > 65535) return false;
-    { const char* e = getenv("CN_DBG"); const_cast<ConvGeom&>(g).dbg = e ? atoi(e) : 0; }
-    const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !(g.dbg & 32)) ? 1 : 0;
+    static const bool no_tile = getenv("CN_DISABLE_EPI_TILE") != nullptr, no_c16 = getenv("CN_DISABLE_CONV_C16") != nullptr;
+    const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !no_tile) ? 1 : 0;
     if (dtype == CN_BF16 && g.Ci == 16 && g.Co <= 16 && g.co_pad >= 16 && !g.res && !g.res32 && !g.y_f32 &&
-        (g.y_ld & 3) == 0 && g.y_ld <= 16 && (g.x_ld & 7) == 0 && !(g.dbg & 128)) {
+        (g.y_ld & 3) == 0 && g.y_ld <= 16 && (g.x_ld & 7) == 0 && !no_c16) {
         const int64_t strips = (int64_t)g.N * g.H * ((g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS));
         int64_t blocks = (strips + 3) / 4;
         if (blocks > 4096) blocks = 4096;
@@ -281,7 +272,7 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
         if (nb < bnb) { bn = c; bnb = nb; }
     }
     if (dtype == CN_BF16) {
-        if (g.Ci % 64 == 0 && !(g.dbg & 64)) {
+        if (g.Ci % 64 == 0) {
             if (bn == 128) launch3<bf16_t, 128, 64>(g, st); else if (bn == 64) launch3<bf16_t, 64, 64>(g, st); else launch3<bf16_t, 32, 64>(g, st);
         } else if (g.Ci % 32 == 0) {
             if (bn == 128) launch3<bf16_t, 128, 32>(g, st); else if (bn == 64) launch3<bf16_t, 64, 32>(g, st); else launch3<bf16_t, 32, 32>(g, st);

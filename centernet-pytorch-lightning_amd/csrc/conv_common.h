@@ -35,7 +35,6 @@ struct ConvGeom {
     int dcn_Ci, dcn_H, dcn_W, dcn_xld, dcn_omld;
     const float* res32;   // optional fp32 residual added in the epilogue (pitch res32_ld)
     int res32_ld;
-    int dbg;              // perf experiments only (CN_DBG env), 0 in production
     int epi_tile;         // bf16 output rows are 16-byte aligned vectors: use the LDS-staged epilogue
 };
 
