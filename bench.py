@@ -115,7 +115,7 @@ def pmc_traffic(kernel):
         return None
 
 
-def cpu_baseline(seconds_budget=30.0):
+def cpu_baseline(seconds_budget=20.0):
     """The oracle (torch-CPU restatement of the reference path: same op sequence, pure-torch DCNv2) on the host cores:
     DLA-34 ctdet train step + decode, fp32, batch 2, 512x512.  Threads are capped at 16: on the 256-thread GPU host
     torch's intra-op pool gets SLOWER beyond that (measured: 16 threads 0.5 s, 128 threads 11.9 s for the same step)."""
@@ -145,7 +145,7 @@ def cpu_baseline(seconds_budget=30.0):
     t0 = time.time()
     one()                                   # warm-up (also sizes the sample)
     warm = time.time() - t0
-    n_max = max(1, min(5, int((seconds_budget - warm) / max(warm, 1e-3))))
+    n_max = max(1, min(20, int((seconds_budget - warm) / max(warm, 1e-3))))
     n, t0 = 0, time.time()
     while n < n_max and time.time() - t0 < seconds_budget:
         one()
