@@ -275,7 +275,9 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g1):
+        # with a process group alive, its watchdog thread polls events while we capture: only police THIS thread's calls
+        mode = "thread_local" if (dist.is_initialized() or os.environ.get("CN_CAPTURE_THREAD_LOCAL")) else "global"
+        with torch.cuda.graph(self._g1, capture_error_mode=mode):
             self.opt.zero_grad()
             self._begin_packs()
             loss = self.model.training_step(static, 0)
@@ -288,7 +290,7 @@ class TrainStep:
             self._loss = loss.detach()
         for m in self._bns:
             m._pending -= 1          # the capture pass ran host code only; nothing executed on the device
-        with torch.cuda.graph(self._g2, pool=self._g1.pool()):
+        with torch.cuda.graph(self._g2, pool=self._g1.pool(), capture_error_mode=mode):
             self.opt.launch()
             if self.post_step is not None:
                 with torch.no_grad():
