@@ -268,7 +268,7 @@ def main():
                 "config": {"workload": f"{args.arch} ctdet (80 classes) train step (fwd+loss+bwd+Adam) + ctdet_decode, "
                                        f"{args.size}x{args.size}, batch {args.batch}/GPU, {args.dtype} compute / fp32 master weights",
                            "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                           "launch": "eager" if args.no_graph else "hipGraph replay (2 graphs/step)",
+                           "launch": "hipGraph replay (2 graphs/step)" if step.graph else "eager",
                            "final_loss": round(float(loss.detach()), 4)},
                 "roofline": roof,
                 "cpu_baseline": None}

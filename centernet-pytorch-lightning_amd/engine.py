@@ -274,6 +274,8 @@ class TrainStep:
                 self._eager(static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if os.environ.get("CN_FAIL_CAPTURE"):
+            raise RuntimeError("CN_FAIL_CAPTURE set (test hook for the eager fallback)")
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # with a process group alive, its watchdog thread polls events while we capture: only police THIS thread's calls
         mode = "thread_local" if (dist.is_initialized() or os.environ.get("CN_CAPTURE_THREAD_LOCAL")) else "global"
@@ -300,7 +302,18 @@ class TrainStep:
         if not self.graph:
             return self._eager(batch, batch_idx)
         if self._g1 is None:
-            self._capture(batch)
+            try:
+                self._capture(batch)
+            except Exception as e:      # e.g. a runtime that refuses capture next to a live process group: keep training
+                import sys
+                print(f"[centernet_amd] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                      file=sys.stderr, flush=True)
+                self._g1 = self._g2 = None
+                self.graph = False
+                SideGrads.pending, SideGrads.active = [], False
+                PackArena.active = PackArena.recording = False
+                torch.cuda.synchronize()
+                return self._eager(batch, batch_idx)
         if batch[0] is not self._sx:
             self._sx.copy_(batch[0], non_blocking=True)
             for k, v in batch[1].items():
