@@ -200,7 +200,7 @@ class TrainStep:
     def __init__(self, model, lr=None, distributed=None, graph=False, post_step=None, side_grads=True, post_forward=None):
         self.model = model
         self.post_forward, self._pf_stream = post_forward, None
-        PackArena.reset()
+        self._packs = PackArena()
         lr = lr if lr is not None else getattr(model.hparams, "learning_rate", 1e-4)
         self.opt = FlatAdam(model.parameters(), lr=lr)
         self.graph, self.post_step, self.post_out = graph, post_step, None
@@ -232,16 +232,16 @@ class TrainStep:
         """one launch packs every weight operand of the step (recorded during the first step)"""
         if not self.opt.flat_p.is_cuda:
             return
-        PackArena.active = True
-        if PackArena.table is not None:
-            PackArena.repack()
-        elif not PackArena.slots:
-            PackArena.recording = True
+        PackArena.current = self._packs
+        if self._packs.table is not None:
+            self._packs.repack()
+        elif not self._packs.slots:
+            self._packs.recording = True
 
     def _end_packs(self):
-        if PackArena.recording:
-            PackArena.build()
-        PackArena.active = False
+        if self._packs.recording:
+            self._packs.build()
+        PackArena.current = None
 
     def _eager(self, batch, batch_idx=0):
         self.opt.zero_grad()
@@ -311,7 +311,7 @@ class TrainStep:
                 self._g1 = self._g2 = None
                 self.graph = False
                 SideGrads.pending, SideGrads.active = [], False
-                PackArena.active = PackArena.recording = False
+                PackArena.current, self._packs.recording = None, False
                 torch.cuda.synchronize()
                 return self._eager(batch, batch_idx)
         if batch[0] is not self._sx:

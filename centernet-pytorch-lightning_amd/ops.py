@@ -60,65 +60,58 @@ class PackArena:
     """Every weight packing a training step needs, produced by ONE launch at the start of the step.
 
     A step packs each convolution weight once per use (forward operand, data-gradient operand, the DCN variants): ~160
-    launches of a few microseconds each.  The weights only change in the optimizer, so `TrainStep` records the requests
-    of its first step (`recording`), `build()`s persistent destinations plus the device table, and from then on calls
-    `repack()` once per step; `pack_weight` then returns the resident copy.  Only live inside a TrainStep
-    (`active`), keyed by (storage pointer, shape, mode, dtype); anything else falls back to a direct pack."""
-    active = False
-    recording = False
-    requests = {}
-    slots = {}
-    table = None
-    n_blocks = 0
-    dtype = None
+    launches of a few microseconds each.  The weights only change in the optimizer, so a `TrainStep` owns one arena:
+    it records the requests of its first step (`recording`), `build()`s persistent destinations plus the device table,
+    and from then on calls `repack()` once per step; `pack_weight` then returns the resident copy.  `PackArena.current`
+    is the arena of the TrainStep whose step is running (None otherwise -> direct packs); entries are keyed by
+    (storage pointer, shape, mode, dtype)."""
+    current = None
 
-    @classmethod
-    def key(cls, w, mode, dtype):
+    def __init__(self):
+        self.recording = False
+        self.requests, self.slots, self.table, self.n_blocks, self.dtype = {}, {}, None, 0, None
+
+    @staticmethod
+    def key(w, mode, dtype):
         return (w.data_ptr(), tuple(w.shape), mode, dtype)
 
-    @classmethod
-    def reset(cls):
-        cls.active = cls.recording = False
-        cls.requests, cls.slots, cls.table, cls.n_blocks, cls.dtype = {}, {}, None, 0, None
-
-    @classmethod
-    def build(cls):
-        cls.recording = False
-        reqs = list(cls.requests.items())
-        cls.requests = {}
+    def build(self):
+        self.recording = False
+        reqs = list(self.requests.items())
+        self.requests = {}
         if not reqs:
             return
         dts = {k[3] for k, _ in reqs}
         if len(dts) != 1:                     # mixed compute dtypes: keep the per-layer packs
             return
-        cls.dtype = dts.pop()
+        self.dtype = dts.pop()
         rows, blk = [], 0
         for k, w in reqs:
             mode = k[2]
             A, B, KH, KW = w.shape
             rows_pad, inner_pad, cols = _pack_dims(w.shape, mode)
-            wp = torch.empty((rows_pad, cols), dtype=cls.dtype, device=w.device)
-            cls.slots[k] = wp
+            wp = torch.empty((rows_pad, cols), dtype=self.dtype, device=w.device)
+            self.slots[k] = wp
             rows.append([w.data_ptr(), wp.data_ptr(), A, B, KH * KW, mode, rows_pad, inner_pad, blk, 0])
             blk += (rows_pad * cols + 2047) // 2048
-        cls.table = torch.tensor(rows, dtype=torch.int64).to(reqs[0][1].device)
-        cls.n_blocks = blk
+        self.table = torch.tensor(rows, dtype=torch.int64).to(reqs[0][1].device)
+        self.n_blocks = blk
 
-    @classmethod
-    def repack(cls):
-        if cls.table is not None:
-            call("cn_pack_weight_batch", cls.table, cls.table.shape[0], cls.n_blocks, dtype_code(cls.dtype))
+    def repack(self):
+        if self.table is not None:
+            call("cn_pack_weight_batch", self.table, self.table.shape[0], self.n_blocks, dtype_code(self.dtype))
 
 
 def pack_weight(w, mode, dtype, row_scale=None):
     """w: fp32 [A,B,KH,KW] parameter -> packed GEMM operand (see cn_pack_weight)."""
-    if PackArena.active and row_scale is None:
+    arena = PackArena.current
+    if arena is not None and row_scale is None:
         k = PackArena.key(w, mode, dtype)
-        hit = PackArena.slots.get(k)
+        hit = arena.slots.get(k)
         if hit is not None:
             return hit
-        if PackArena.recording:
-            PackArena.requests[k] = w.detach()
+        if arena.recording:
+            arena.requests[k] = w.detach()
     A, B, KH, KW = w.shape
     rows_pad, inner_pad, cols = _pack_dims(w.shape, mode)
     wp = torch.empty((rows_pad, cols), dtype=dtype, device=w.device)

@@ -313,20 +313,20 @@ def test_pack_weight_batch_matches_single():
     """ops.PackArena / cn_pack_weight_batch: one launch, same bits as per-layer cn_pack_weight in all three modes."""
     o = ops()
     ws = [rng.t_normal(31, f"w{i}", shp).to(DEV) for i, shp in enumerate([(64, 64, 3, 3), (27, 64, 3, 3), (80, 256, 1, 1), (16, 3, 7, 7)])]
-    o.PackArena.reset()
-    o.PackArena.active = o.PackArena.recording = True
+    arena = o.PackArena()
+    o.PackArena.current, arena.recording = arena, True
     singles = []
     for w in ws:
         for mode in (0, 1, 2):
             singles.append((w, mode, o.pack_weight(w, mode, torch.bfloat16)))
-    o.PackArena.build()
-    for v in o.PackArena.slots.values():          # poison the destinations, then repack in one launch
+    arena.build()
+    for v in arena.slots.values():                # poison the destinations, then repack in one launch
         v.fill_(7.0)
-    o.PackArena.repack()
+    arena.repack()
     for w, mode, ref in singles:
         got = o.pack_weight(w, mode, torch.bfloat16)
         assert got.data_ptr() != ref.data_ptr() and torch.equal(got, ref), f"mode {mode} shape {tuple(w.shape)}"
-    o.PackArena.reset()
+    o.PackArena.current = None
 
 
 def test_wgrad_thin_grids_same_result():
