@@ -470,13 +470,19 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
 }
 
 // dom / dx_far of the DCNv2 backward, fused into the GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2: [9*Ci][Co_pad16])
-extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, float* dx_far,
-                              int* far_flag, int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype,
-                              void* stream) {
+extern "C" int cn_dcn_bwd_dom_slabs(int Ci, int dy_ld, int dtype) {
+    static const bool disabled = getenv("CN_DISABLE_DOM_TILE") != nullptr;
+    return (!disabled && dtype == CN_BF16 && Ci % 64 == 0 && (dy_ld == 64 || dy_ld == 128)) ? Ci / 64 : 1;
+}
+
+extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, int dom_slabs,
+                              float* dx_far, int* far_flag, int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld,
+                              int dtype, void* stream) {
     CN_CHECK_ARG(dy && wpd2 && x && om && dom && dx_far && N > 0 && H > 0 && W > 0, "cn_dcn_bwd_dom: bad args");
     if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dom: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
     CN_CHECK_ARG(om_ld >= 27 && x_ld >= Ci, "cn_dcn_bwd_dom: bad pitches");
-    if (dtype == CN_BF16 && dcn_bwd_dom_tile_launch(dy, wpd2, x, om, dom, dx_far, far_flag, N, H, W, Ci, Co, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
+    CN_CHECK_ARG(dom_slabs == 1 || dom_slabs == cn_dcn_bwd_dom_slabs(Ci, dy_ld, dtype), "cn_dcn_bwd_dom: dom_slabs=%d (ask cn_dcn_bwd_dom_slabs)", dom_slabs);
+    if (dtype == CN_BF16 && dcn_bwd_dom_tile_launch(dy, wpd2, x, om, dom, dom_slabs, dx_far, far_flag, N, H, W, Ci, Co, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_bwd_dom(tile)");
         return CN_OK;
     }

@@ -434,6 +434,7 @@ void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st) {
 struct DomGeom {
     const bf16_t* dy; const bf16_t* wd2; const bf16_t* x; const float* om; float* dom; float* far; int* far_flag;
     int N, H, W, Ci, Co, dy_ld, x_ld, om_ld;
+    int64_t slab;      // elements between the per-channel-block copies of dom (0: one copy, channel blocks meet with atomics)
 };
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
     const int tiles_img = tiles_w * tiles_h, ntiles = tiles_img * g.N;
     const int ci0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    const bool whole = g.Ci == BN;
+    const bool whole = g.Ci == BN || g.slab != 0;     // this workgroup's results are the only ones written to its dom rows
     // contiguous tile run per workgroup; consecutive runs stay on one XCD (workgroups are dealt round-robin to the 8 XCDs)
     const int G = gridDim.x;
     const int lb = (G % 8 == 0) ? (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8 : blockIdx.x;
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
                 }
                 sm = quad_sum(sm); sy = quad_sum(sy); sx = quad_sum(sx);
                 if (lq == 0 && live) {
-                    float* d = g.dom + (img + (int64_t)h * g.W + w) * g.om_ld;
+                    float* d = g.dom + (int64_t)blockIdx.y * g.slab + (img + (int64_t)h * g.W + w) * g.om_ld;
                     const float vy = sy * mk, vx = sx * mk, vm = sm * mk * (1.f - mk);
                     if (whole) {
                         d[2 * tap] = vy; d[2 * tap + 1] = vx; d[18 + tap] = vm;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
 }
 
 // returns false when the shape is not handled by the tile-resident kernel
-bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, float* far, int* far_flag,
+bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, int dom_slabs, float* far, int* far_flag,
                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_DOM_TILE") != nullptr;
     if (disabled || Ci % 64 != 0 || (dy_ld != 64 && dy_ld != 128)) return false;
@@ -699,6 +700,7 @@ bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, con
     DomGeom g;
     g.dy = (const bf16_t*)dy; g.wd2 = (const bf16_t*)wd2; g.x = (const bf16_t*)x; g.om = om; g.dom = dom; g.far = far; g.far_flag = far_flag;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.dy_ld = dy_ld; g.x_ld = x_ld; g.om_ld = om_ld;
+    g.slab = (dom_slabs > 1 && dom_slabs == Ci / 64) ? (int64_t)N * H * W * om_ld : 0;
     const int ntiles = ((H + DX_TH - 1) / DX_TH) * ((W + DX_TW - 1) / DX_TW) * N;
     int gx = 256 / (Ci / 64);                   // one persistent workgroup per CU
     if (gx < 8) gx = 8;

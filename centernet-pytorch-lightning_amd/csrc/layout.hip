@@ -165,6 +165,31 @@ extern "C" int cn_cast(const void* src, int sd, void* dst, int dd, int64_t n, vo
     return CN_OK;
 }
 
+// dst[i] = sum_s src[s][i]  (fp32 slabs -> activation dtype): folds the per-channel-block copies of the DCN offset gradient
+template <typename D>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ src, D* __restrict__ dst, int S, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(src)[i];
+        for (int sIdx = 1; sIdx < S; ++sIdx) {
+            const float4 b = reinterpret_cast<const float4*>(src)[(int64_t)sIdx * n4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if constexpr (sizeof(D) == 4) reinterpret_cast<float4*>(dst)[i] = a;
+        else *reinterpret_cast<uint2*>(dst + i * 4) = make_uint2(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w));
+    }
+}
+
+extern "C" int cn_sum_slabs(const float* src, void* dst, int S, int64_t n, int dtype, void* stream) {
+    CN_CHECK_ARG(src && dst && S >= 1 && n > 0 && n % 4 == 0, "cn_sum_slabs: bad args");
+    int grid = (int)((n / 4 + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (dtype == CN_F32) hipLaunchKernelGGL(sum_slabs_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, S, n / 4);
+    else if (dtype == CN_BF16) hipLaunchKernelGGL(sum_slabs_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, S, n / 4);
+    else CN_CHECK_ARG(false, "cn_sum_slabs: bad dtype %d", dtype);
+    CN_LAUNCH_CHECK("cn_sum_slabs");
+    return CN_OK;
+}
+
 template <typename D>
 __global__ __launch_bounds__(256) void add_f32_to_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          D* __restrict__ out, int64_t n4) {

@@ -625,19 +625,28 @@ class DCNv2Fn(Function):
             # buffer per shape + a per-call flag, instead of clearing and re-reading 4*P*Ci bytes per layer per step
             dx_far = _far_buffer((N, H, W, Ci), x.device)
             far_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
-            tile_whole = (x.dtype == torch.bfloat16 and Ci == 64 and dy.shape[-1] in (64, 128)
-                          and not _os.environ.get("CN_DISABLE_DOM_TILE"))
-            dom32 = torch.empty_like(om) if tile_whole else torch.zeros_like(om)   # the tile kernel writes all 32 channels
-            call("cn_dcn_bwd_dom", dy, pack_weight(weight, 2, x.dtype), x, om, dom32, dx_far, far_flag, N, H, W, Ci, Co,
+            slabs = _hip.query("cn_dcn_bwd_dom_slabs", int(Ci), int(dy.shape[-1]), dt)
+            if x.dtype == torch.bfloat16 and slabs == Ci // 64:
+                # tile kernel: one fp32 copy of dom per 64-channel block of x, plain stores (no atomics, nothing to clear)
+                dom32 = torch.empty((slabs,) + tuple(om.shape), dtype=torch.float32, device=x.device)
+            else:
+                slabs, dom32 = 1, torch.zeros_like(om)
+            call("cn_dcn_bwd_dom", dy, pack_weight(weight, 2, x.dtype), x, om, dom32, slabs, dx_far, far_flag, N, H, W, Ci, Co,
                  dy.shape[-1], Ci, om.shape[-1], dt)
             call("cn_dcn_bwd_dx", dy, pack_weight(weight, 0, x.dtype), om, dx_far, far_flag, dx_s, N, H, W, Ci,
                  dy.shape[-1], om.shape[-1], dt)
+            if slabs > 1 or x.dtype != torch.float32:
+                dom = torch.empty(om.shape, dtype=x.dtype, device=x.device)
+                call("cn_sum_slabs", dom32, dom, slabs, om.numel(), dt)
+            else:
+                dom = dom32
         del dx_far
-        if x.dtype == torch.float32:
-            dom = dom32
-        else:
-            dom = torch.empty(om.shape, dtype=x.dtype, device=x.device)
-            call("cn_cast", dom32, 0, dom, dt, dom32.numel())
+        if _DCN_UNFUSED:
+            if x.dtype == torch.float32:
+                dom = dom32
+            else:
+                dom = torch.empty(om.shape, dtype=x.dtype, device=x.device)
+                call("cn_cast", dom32, 0, dom, dt, dom32.numel())
         # offset/mask conv backward (its data gradient is added to the sampling gradient through `residual`)
         if side:
             def side_work_om(x=x, dom=dom, p1=ctx.params[1], p2=ctx.params[2]):

@@ -163,9 +163,16 @@ int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int
  * scattered at least one far sample; dx adds dx_far only if the flag is set and then writes zeros back, so the caller
  * keeps ONE persistent zero-initialised dx_far per shape instead of clearing (and reading) 4*P*Ci bytes per layer per
  * step.  far_flag == NULL: dx_far is zeroed by the caller and always added.  When Ci == 64 (one channel block) dom also
- * writes the padding channels 27..om_ld-1 of `dom`, so the caller need not clear it. */
-int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, float* dx_far,
+ * writes the padding channels 27..om_ld-1 of `dom`, so the caller need not clear it.
+ * Slabs: with Ci > 64 the offset gradient is summed over 64-channel blocks of x.  Global fp32 atomics for that cost 2.3x
+ * the kernel, so the caller may pass dom as S = cn_dcn_bwd_dom_slabs() consecutive copies [S][P][om_ld] (dom_slabs = S):
+ * every channel block then writes its own copy with plain stores (all om_ld channels, nothing to clear) and the caller
+ * folds them with cn_sum_slabs.  dom_slabs = 1 keeps the single-copy / atomic behaviour. */
+int cn_dcn_bwd_dom_slabs(int Ci, int dy_ld, int dtype);
+int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, int dom_slabs, float* dx_far,
                    int* far_flag, int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype, void* stream);
+/* dst[i] = sum_s src[s*n + i] for S fp32 slabs of n elements -> dst in `dtype` */
+int cn_sum_slabs(const float* src, void* dst, int S, int64_t n, int dtype, void* stream);
 int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, float* dx_far, int* far_flag, void* dx,
                   int N, int H, int W, int Ci, int dy_ld, int om_ld, int dtype, void* stream);
 /* out[i] = a[i] + b[i] for fp32 a, b -> out in `dtype` (combines dx_tile + dx_far into the activation dtype) */

@@ -55,6 +55,14 @@ elif which == "bn":
             y = bn(x, None, True)
             y.backward(torch.randn_like(y))
     torch.cuda.synchronize()
+elif which == "dcn2":
+    for (ci, co, hw) in ((128, 64, 64), (128, 128, 64), (256, 128, 32), (64, 64, 128)):
+        m = hnn.DCN(ci, co).to(dev)
+        torch.nn.init.normal_(m.conv_offset_mask.weight, std=0.01)
+        x = torch.randn(N, hw, hw, ci, device=dev).to(dt).requires_grad_(True)
+        for _ in range(2):
+            y = m(x); y.backward(torch.randn_like(y))
+    torch.cuda.synchronize()
 elif which == "dcn":
     m = hnn.DCN(64, 64).to(dev)
     torch.nn.init.normal_(m.conv_offset_mask.weight, std=0.01)
