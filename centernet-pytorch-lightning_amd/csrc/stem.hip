@@ -188,7 +188,7 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 
 // used by cn_conv2d_wgrad for Ci <= 16 (packed output layout dwp[co][tap*Ci + ci])
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                           hipStream_t st);
+                           int stride, int OH, int OW, hipStream_t st);
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
                            int OH, int OW, hipStream_t st);
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
@@ -197,8 +197,8 @@ bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
                         int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st) {
     if (Ci > 16) return false;
-    if (dtype == CN_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W &&
-        wgrad_c16_nhwc_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, st))
+    if (dtype == CN_BF16 && KH == 3 && KW == 3 && pad == 1 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
+        wgrad_c16_nhwc_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, stride, OH, OW, st))
         return true;
     if (dtype == CN_F32)
         return launch_small_wgrad<float>(x, false, (const float*)dy, dwp, N, Ci, x_ld, H, W, Co, dy_ld, KH, KW, stride, pad, OH, OW,

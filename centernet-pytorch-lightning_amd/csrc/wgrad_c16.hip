@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     constexpr int PAD = KH / 2;
     constexpr int HH = (C16_TH - 1) * S + KH;
     constexpr int KWG = XPIX == 16 ? KW : (KW + 3) / 4;                       // MFMA column groups per kernel row
-    constexpr int HWD = XPIX == 16 ? C16_TW + KW - 1 : (C16_TW - 1) * S + 4 * KWG;   // halo row length (the last 4-pixel window starts at S*tx + 4*(KWG-1))
+    constexpr int HWD = XPIX == 16 ? (C16_TW - 1) * S + KW : (C16_TW - 1) * S + 4 * KWG;   // halo row length (the last 4-pixel window starts at S*tx + 4*(KWG-1))
     constexpr int HP = HH * HWD;
     constexpr int DY_ELEMS = C16_TH * C16_TW * 16;
     constexpr int X_ELEMS = HP * XPIX;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
             for (int v = 0; v < XV; ++v) {
                 const int idx = lane + v * 64;
                 const int hp = idx >> 1, hf = idx & 1;
-                const int ih = th0 - PAD + hp / HWD, iw = tw0 - PAD + hp % HWD;
+                const int ih = th0 * S - PAD + hp / HWD, iw = tw0 * S - PAD + hp % HWD;
                 const bool ok = tv && hp < HP && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
                 rx16[v] = ldg16_masked(g.x, ((((int64_t)n * g.H + ih) * g.W + iw) * g.x_ld + hf * 8) * 2, ok);
             }
@@ -182,16 +182,16 @@ static void launch_c16(WgC16Geom& g, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
 }
 
-// bf16 NHWC x, 3x3 / stride 1 / pad 1, Ci == 16, Co <= 16 -> packed dwp[co][tap*16 + ci]
+// bf16 NHWC x, 3x3 / stride 1|2 / pad 1, Ci == 16, Co in 16-channel blocks -> packed dwp[co][tap*16 + ci]
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                           hipStream_t st) {
+                           int stride, int OH, int OW, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
-    if (disabled || Ci != 16 || Co > 16 || (x_ld & 7) || (dy_ld & 7) || dy_ld < 16) return false;
+    if (disabled || Ci != 16 || (x_ld & 7) || (dy_ld & 7) || dy_ld < ((Co + 15) & ~15) || (stride != 1 && stride != 2)) return false;
     WgC16Geom g;
     g.x = x; g.dy = (const bf16_t*)dy; g.dw = dwp; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld;
-    g.OH = H; g.OW = W;
+    g.OH = OH; g.OW = OW;
     g.os_co = 9 * Ci; g.os_ci = 1; g.os_tap = Ci;
-    launch_c16<16, 3, 3>(g, st);
+    if (stride == 1) launch_c16<16, 3, 3, 1>(g, st); else launch_c16<16, 3, 3, 2>(g, st);
     return true;
 }
 
