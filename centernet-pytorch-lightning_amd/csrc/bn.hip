@@ -162,15 +162,15 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int C, int64_t npix,
                                                               const float* __restrict__ gamma, const float* __restrict__ sinvstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coef) {
+                                                              float* __restrict__ coef, int accumulate) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int b = lane; b < nblk; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
     s = wave_sum_d(s); q = wave_sum_d(q);
     if (lane != 0) return;
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
+    dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;      // accumulate: deposit straight into the .grad buffers
+    dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
     coef[c] = gamma[c] * sinvstd[c];
     coef[C + c] = (float)(s / (double)npix);
     coef[2 * C + c] = (float)(q / (double)npix);
@@ -290,7 +290,8 @@ extern "C" int cn_scale_shift_act(const void* x, const void* residual, void* y, 
 
 extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
                                const float* save_invstd, const float* scale_shift, void* dx, void* dres, float* dgamma,
-                               float* dbeta, int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
+                               float* dbeta, int accumulate, int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes,
+                               void* stream) {
     CN_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && npix > 0 && C > 0,
                  "cn_bn_train_bwd: bad args");
     CN_CHECK_ARG(!relu || y || scale_shift, "cn_bn_train_bwd: relu needs the forward output or the saved scale/shift");
@@ -306,7 +307,7 @@ extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, con
                                                    npix, C, L, relu));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(partial)");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, save_invstd,
-                       dgamma, dbeta, coef);
+                       dgamma, dbeta, coef, accumulate);
     CN_LAUNCH_CHECK("cn_bn_train_bwd(finalize)");
     int64_t nvec = npix * (C / V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, st,

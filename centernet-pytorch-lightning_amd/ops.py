@@ -360,6 +360,7 @@ class BatchNormActFn(Function):
         # ReLU backward mask: without a residual input it is recomputed from x and the saved affine (y is not re-read)
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, gamma, stats)
+        ctx.beta_ref = beta
         ctx.cfg = (relu, residual is not None)
         return y
 
@@ -373,10 +374,15 @@ class BatchNormActFn(Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
+        ws, n = _bn_ws(npix, C, x.device)
+        beta = ctx.beta_ref
+        if SideGrads.usable(gamma, beta):      # inside a TrainStep: deposit straight into the flat gradient buffer
+            call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, gamma.grad, beta.grad, 1, npix, C,
+                 int(relu), dtype_code(x.dtype), ws, n)
+            return dx, None, None, None, None, dres, None
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        ws, n = _bn_ws(npix, C, x.device)
-        call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, dgamma, dbeta, npix, C, int(relu),
+        call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, dgamma, dbeta, 0, npix, C, int(relu),
              dtype_code(x.dtype), ws, n)
         return dx, dgamma, dbeta, None, None, dres, None
 

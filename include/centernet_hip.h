@@ -113,10 +113,11 @@ int cn_scale_shift_act(const void* x, const void* residual, void* y, const float
 /* training backward.  ReLU mask: from y (the forward output) when given; with y == NULL and scale_shift (the forward's
  * save_scale_shift) given it is recomputed as fma(x, scale, shift) > 0 — the same decision bit for bit, one tensor less
  * to read in each of the two passes (only valid for layers without a residual input).  dres (nullable) receives the
- * gradient that flows to the residual input (= dy masked by ReLU). */
+ * gradient that flows to the residual input (= dy masked by ReLU).  accumulate != 0: dgamma / dbeta are ADDED to (the
+ * caller passes the parameters' .grad buffers and skips a separate accumulation launch per parameter). */
 int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
                     const float* save_invstd, const float* scale_shift, void* dx, void* dres, float* dgamma, float* dbeta,
-                    int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+                    int accumulate, int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* dx = dy * (y > 0)  (ReLU backward for conv+bias+ReLU heads) */
 int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 
