@@ -43,16 +43,22 @@ __device__ static void block_topk(const uint32_t* keys, int L, int K, TkShared& 
             const int i = i0 + tid;
             const bool ok = i < L && ((keys[i] & mask) == prefix);
             const uint32_t bin = ok ? ((keys[i] >> shift) & 255u) : 0xffffffffu;
-            // wave-level aggregation per DISTINCT bin (usually 1-3 per wave: the zeros left by the pseudo-NMS and one or two
-            // exponent bins of the peaks): one LDS atomic per bin instead of up to 64 same-address atomics
+            // Histogram update, robust to both extremes: a wave whose keys share a few bins (the zeros left by the
+            // pseudo-NMS, a flat map, one exponent) aggregates them — one LDS atomic per DISTINCT bin, up to four bins in the first
+            // pass and the leading bin in the later ones —
+            // and whatever is left (survivors spread over many bins) adds itself directly.
             unsigned long long todo = __ballot(ok);
-            while (todo) {
+            bool mine = ok;
+#pragma unroll 1
+            for (int rep = 0; rep < (shift == 24 ? 4 : 1) && todo; ++rep) {
                 const int leader = __ffsll((long long)todo) - 1;
                 const uint32_t lb = __shfl(bin, leader, 64);
-                const unsigned long long same = __ballot(ok && bin == lb);
+                const unsigned long long same = __ballot(mine && bin == lb);
                 if (lane == leader) atomicAdd(&sh.hist[lb], (uint32_t)__popcll(same));
+                if (bin == lb) mine = false;
                 todo &= ~same;
             }
+            if (mine) atomicAdd(&sh.hist[bin], 1u);
         }
         __syncthreads();
         // which bin holds the need-th largest key: descending inclusive scan of the histogram by 256 threads (a serial
@@ -157,36 +163,77 @@ __global__ __launch_bounds__(TK_THREADS) void topk_channel_kernel(const float* _
     }
     __syncthreads();
     uint32_t kreg[EPT];
+    // Element ownership.  Column strips (thread = one x, RPS consecutive rows) let the 3x3 max be separable — a running
+    // window of three row-maxima: 3 LDS reads per row instead of 9 per element; otherwise threads stride over the map.
+    const int strips = (W > 0 && TK_THREADS % W == 0) ? TK_THREADS / W : 0;
+    const int RPS = strips ? (H + strips - 1) / strips : 0;
+    const bool by_strip = apply_nms && strips > 0 && RPS <= EPT;
+    if (by_strip) {
+        const int x = tid % W, y0 = (tid / W) * RPS;
+        auto rowmax = [&](int y, float& c) {
+            c = -INFINITY;
+            if ((unsigned)y >= (unsigned)H) return -INFINITY;
+            const float* row = fmap + y * W;
+            c = row[x];
+            float m = c;
+            if (x > 0) m = fmaxf(m, row[x - 1]);
+            if (x + 1 < W) m = fmaxf(m, row[x + 1]);
+            return m;
+        };
+        float c_prev, c_cur, c_next;
+        float m_prev = rowmax(y0 - 1, c_prev), m_cur = rowmax(y0, c_cur);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * TK_THREADS;
-        uint32_t key = 0;
-        if (i < HW) {
-            const float v = fmap[i];
-            float out = v;
-            if (apply_nms) {
-                const int y = i / W, x = i - y * W;
-                float m = v;
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int yy = y + dy;
-                    if ((unsigned)yy >= (unsigned)H) continue;
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int xx = x + dx;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        m = fmaxf(m, fmap[yy * W + xx]);
-                    }
+        for (int e = 0; e < EPT; ++e) {
+            uint32_t key = 0;
+            if (e < RPS) {
+                const float m_next = rowmax(y0 + e + 1, c_next);
+                if (y0 + e < H) {
+                    const float m = fmaxf(fmaxf(m_prev, m_cur), m_next);
+                    key = f2key(c_cur * (m == c_cur ? 1.f : 0.f));       // heat * keep  (utils/decode.py:9-10)
                 }
-                out = v * (m == v ? 1.f : 0.f);   // heat * keep  (utils/decode.py:9-10)
+                m_prev = m_cur; m_cur = m_next; c_cur = c_next;
             }
-            key = f2key(out);
+            kreg[e] = key;
         }
-        kreg[e] = key;
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * TK_THREADS;
+            uint32_t key = 0;
+            if (i < HW) {
+                const float v = fmap[i];
+                float out = v;
+                if (apply_nms) {
+                    const int y = i / W, x = i - y * W;
+                    float m = v;
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const int yy = y + dy;
+                        if ((unsigned)yy >= (unsigned)H) continue;
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int xx = x + dx;
+                            if ((unsigned)xx >= (unsigned)W) continue;
+                            m = fmaxf(m, fmap[yy * W + xx]);
+                        }
+                    }
+                    out = v * (m == v ? 1.f : 0.f);   // heat * keep  (utils/decode.py:9-10)
+                }
+                key = f2key(out);
+            }
+            kreg[e] = key;
+        }
     }
     __syncthreads();
+    if (by_strip) {
+        const int x = tid % W, y0 = (tid / W) * RPS;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * TK_THREADS;
-        if (i < HW) dyn[i] = kreg[e];
+        for (int e = 0; e < EPT; ++e)
+            if (e < RPS && y0 + e < H) dyn[(y0 + e) * W + x] = kreg[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid + e * TK_THREADS;
+            if (i < HW) dyn[i] = kreg[e];
+        }
     }
     __syncthreads();
     block_topk(dyn, HW, K, sh);
