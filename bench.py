@@ -208,7 +208,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -220,7 +220,7 @@ def main():
         loss = step(batch)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -228,7 +228,13 @@ def main():
     assert det.shape == (args.batch, 100, 6) and bool(torch.isfinite(det).all())
 
     probe = None
-    if rank == 0 and world == 1 and not args.no_probe:
+    if rank != 0 and not args.no_probe:      # the probe steps hold collectives: every rank runs them, rank 0 measures
+        side_was, step.side = step.side, False
+        for _ in range(args.probe_steps):
+            step._eager(batch)
+        torch.cuda.synchronize()
+        step.side = side_was
+    if rank == 0 and not args.no_probe:
         # same step, launched eagerly, with a HIP event pair around every implicit-GEMM launch on the launch stream
         probe = ConvProbe(_hip, all_ops=bool(args.probe_detail))
         side_was, step.side = step.side, False      # weight gradients on the launch stream: every launch is timed alone
@@ -275,7 +281,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -101,6 +101,8 @@ class GradSync:
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         opt.grad_scale = 1.0 / self.world
+        # CN_FORCE_EXCHANGE: run the collectives on a 1-rank group too (exercises RCCL next to the hipGraphs on a 1-GPU box)
+        self.exchange = self.world > 1 or bool(os.environ.get("CN_FORCE_EXCHANGE"))
         self.buckets = []      # (start, end, [param indices]) over the flat buffer, built in REVERSE parameter order
         cur, size, end = [], 0, opt.numel
         for i in reversed(range(len(opt.params))):
@@ -115,7 +117,7 @@ class GradSync:
                 self.bucket_of[i] = b
         self.live = None       # params that receive gradients (learned on the first backward)
         self._seen, self._pending, self._works, self._launched = set(), [], [], set()
-        if self.world > 1 and hooks:
+        if self.exchange and hooks:
             for i, p in enumerate(opt.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -143,7 +145,7 @@ class GradSync:
 
     def finish(self):
         """Call after backward: launches whatever is left (first step / dead parameters) and waits for all buckets."""
-        if self.world == 1:
+        if not self.exchange:
             return
         for b in range(len(self.buckets)):
             self._launch(b)
@@ -154,7 +156,7 @@ class GradSync:
 
     def allreduce_all(self):
         """Non-overlapped variant (used between the two captured graphs): every bucket, then wait."""
-        if self.world == 1:
+        if not self.exchange:
             return
         works = [dist.all_reduce(self.opt.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for s, e, _ in self.buckets]
@@ -163,7 +165,7 @@ class GradSync:
 
     def broadcast_state(self, module):
         """DDP init: parameters (flat) + buffers from rank 0."""
-        if self.world == 1:
+        if not self.exchange:
             return
         dist.broadcast(self.opt.flat_p, 0, group=self.group)
         for buf in module.buffers():
@@ -177,7 +179,7 @@ def init_distributed():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("CN_FORCE_EXCHANGE")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
@@ -208,7 +210,7 @@ class TrainStep:
         self.sync = GradSync(self.opt, hooks=not graph) if use_dist else None
         # weight gradients on a second stream (deposited straight into the flat gradient buffer) unless grad-ready hooks
         # need autograd to see every parameter gradient (eager multi-GPU mode)
-        hooks_on = self.sync is not None and self.sync.world > 1 and not graph
+        hooks_on = self.sync is not None and self.sync.exchange and not graph
         self.side = SideGrads.enable(side_grads and not hooks_on and self.opt.flat_p.is_cuda and not os.environ.get("CN_NO_SIDE"))
         if self.sync is not None:
             self.sync.broadcast_state(model)

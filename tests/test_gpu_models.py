@@ -1,5 +1,7 @@
 """GPU: whole-network parity (backbone -> heads -> losses -> backward -> decode) of the HIP path in fp32 compute mode
 against the golden vectors produced by the reference's own modules, plus bf16 sanity and a short training run."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -194,3 +196,45 @@ def test_extension_is_loaded_and_required():
     assert _hip.lib().cn_version() >= 100
     with pytest.raises(RuntimeError):
         _hip.call("cn_add", torch.zeros(8), torch.zeros(8), torch.zeros(8), 8, 0)   # CPU tensors: no fallback path
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CN_REPO"])
+from centernet_amd import rng, synth
+from centernet_amd.engine import TrainStep, init_distributed
+from centernet_amd.centernet_detection import CenterNetDetection
+rank, local, world = init_distributed()
+assert dist.is_initialized() and dist.get_backend() == "nccl"
+x, tgt = synth.ctdet_batch(97, 2, 128, 128)
+batch = (x.cuda(), {k: v.cuda() for k, v in tgt.items()})
+out = {}
+for graph in (False, True):
+    m = CenterNetDetection("res_18", compute_dtype=torch.float32)
+    rng.fill_state_dict(m, 97)
+    m = m.cuda().train()
+    step = TrainStep(m, lr=2e-4, graph=graph)
+    assert step.sync is not None and step.sync.exchange
+    out["graph" if graph else "eager"] = [float(step(batch)) for _ in range(4)]
+    out["is_graph_" + str(graph)] = bool(step.graph)
+dist.barrier(); dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_rccl_exchange_next_to_graphs(tmp_path):
+    """The gradient exchange through RCCL (backend "nccl") on a 1-rank group: bucketed hooks in eager mode, the
+    all-reduce between the two hipGraphs in graph mode (capture with a live process group + watchdog thread)."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CN_FORCE_EXCHANGE="1", CN_REPO=repo, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_SCRIPT)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["is_graph_True"], "capture fell back to eager next to the process group:\n" + r.stderr[-2000:]
+    assert all(np.isfinite(res["eager"])) and all(np.isfinite(res["graph"]))
+    assert res["graph"][0] == pytest.approx(res["eager"][2], rel=5e-3)     # 2 warm-up steps precede the capture
+    assert res["eager"][3] < res["eager"][0]
