@@ -223,6 +223,66 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __res
     for (int j = 0; j < V; ++j) atomicAdd(dw + ((int64_t)(cv * V + j) * k + kh) * k + kw, acc[j]);
 }
 
+// ---- nearest-neighbour x2 up-sampling fused with the hourglass merge (large_hourglass.py:108-125, 196-204) ----------------
+// y[n, oh, ow, :] = a[n, oh, ow, :] + low[n, oh>>1, ow>>1, :]   (a == nullptr: plain nn.Upsample(scale_factor=2)).
+// One thread owns one LOW pixel vector and writes its 2x2 output footprint: low is read once, a/y stream as 16-byte vectors.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(const T* __restrict__ a, const T* __restrict__ low, T* __restrict__ y,
+                                                             int N, int H, int W, int CV) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        const int w = (int)(pix % W);
+        pix /= W;
+        const int h = (int)(pix % H), n = (int)(pix / H);
+        float lv[V];
+        Vec16<T>::load(low + i * V, lv);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int64_t o = ((((int64_t)n * 2 * H + 2 * h + dy) * 2 * W + 2 * w + dx) * CV + cv) * V;
+                float v[V];
+                if (a) {
+                    Vec16<T>::load(a + o, v);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[j] += lv[j];
+                    Vec16<T>::store(y + o, v);
+                } else
+                    Vec16<T>::store(y + o, lv);
+            }
+    }
+}
+
+// adjoint: dlow[n, h, w, :] = sum of the 2x2 footprint of dy (fp32 accumulation)
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ dy, T* __restrict__ dlow, int N, int H, int W, int CV) {
+    constexpr int V = Vec16<T>::N;
+    const int64_t total = (int64_t)N * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t pix = i / CV;
+        const int w = (int)(pix % W);
+        pix /= W;
+        const int h = (int)(pix % H), n = (int)(pix / H);
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[V];
+                Vec16<T>::load(dy + ((((int64_t)n * 2 * H + 2 * h + dy_) * 2 * W + 2 * w + dx) * CV + cv) * V, v);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += v[j];
+            }
+        Vec16<T>::store(dlow + i * V, acc);
+    }
+}
+
 static int pool_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g > 32768 ? 32768 : (g < 1 ? 1 : g));
@@ -301,5 +361,27 @@ extern "C" int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw, 
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_bwd_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (const T*)dy, dw, N, H, W, C / V, k, stride, pad, OH, OW, chunk));
     CN_LAUNCH_CHECK("cn_dwdeconv_bwd_weight");
+    return CN_OK;
+}
+
+extern "C" int cn_upsample2x_add(const void* a, const void* low, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+    CN_CHECK_ARG(low && y && N > 0 && H > 0 && W > 0 && C > 0, "cn_upsample2x_add: bad args");
+    const int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0, "cn_upsample2x_add: C=%d must be a multiple of %d", C, V);
+    int64_t total = (int64_t)N * H * W * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(upsample2x_add_kernel<T>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)a, (const T*)low, (T*)y, N, H, W, C / V));
+    CN_LAUNCH_CHECK("cn_upsample2x_add");
+    return CN_OK;
+}
+
+extern "C" int cn_sumpool2x2(const void* dy, void* dlow, int N, int H, int W, int C, int dtype, void* stream) {
+    CN_CHECK_ARG(dy && dlow && N > 0 && H > 0 && W > 0 && C > 0, "cn_sumpool2x2: bad args");
+    const int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0, "cn_sumpool2x2: C=%d must be a multiple of %d", C, V);
+    int64_t total = (int64_t)N * H * W * (C / V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(sumpool2x2_kernel<T>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dy, (T*)dlow, N, H, W, C / V));
+    CN_LAUNCH_CHECK("cn_sumpool2x2");
     return CN_OK;
 }

@@ -318,19 +318,28 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
     }
 }
 
-// bf16 output, 7x7 / stride 1|2 / pad 3, Ci <= 3, Co <= 64 (multiple of 4)
+// bf16 output, 7x7 / stride 1|2 / pad 3, Ci <= 3, Co a multiple of 4; more than 64 output channels (Hourglass: 128) run as
+// 64-channel chunks over the same image (the 3-channel fp32 input is small next to the output).
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
                       int stride, int OH, int OW, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
-    if (disabled || Ci > 3 || Co > 16 * ST7_MAXCB || (Co & 3) || (stride != 1 && stride != 2)) return false;
+    if (disabled || Ci > 3 || (Co & 3) || (stride != 1 && stride != 2)) return false;
     const int tiles_h = cdiv(OH, C16_TH), tiles_w = cdiv(OW, C16_TW);
     const int64_t ntiles = (int64_t)N * tiles_h * tiles_w;
     int64_t blocks = (ntiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const int iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
-    if (stride == 1)
-        hipLaunchKernelGGL(stem7_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters, scale, bias, relu);
-    else
-        hipLaunchKernelGGL(stem7_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, OH, OW, tiles_h, tiles_w, iters, scale, bias, relu);
+    constexpr int CHUNK = 16 * ST7_MAXCB;
+    for (int c0 = 0; c0 < Co; c0 += CHUNK) {
+        const int cc = Co - c0 < CHUNK ? Co - c0 : CHUNK;
+        const float* wc = w + (int64_t)c0 * Ci * 49;
+        const float* sc = scale ? scale + c0 : nullptr;
+        const float* bc = bias ? bias + c0 : nullptr;
+        bf16_t* yc = (bf16_t*)y + c0;
+        if (stride == 1)
+            hipLaunchKernelGGL(stem7_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, yc, N, Ci, H, W, cc, Co, OH, OW, tiles_h, tiles_w, iters, sc, bc, relu);
+        else
+            hipLaunchKernelGGL(stem7_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, yc, N, Ci, H, W, cc, Co, OH, OW, tiles_h, tiles_w, iters, sc, bc, relu);
+    }
     return true;
 }

@@ -4,20 +4,15 @@ import torch
 from .backbones.msra_resnet import get_pose_net
 from .backbones.pose_dla_dcn import get_pose_net as get_dla_dcn
 from .backbones.resnet_dcn import get_pose_net as get_pose_net_dcn
+from .backbones.large_hourglass import get_large_hourglass_net
 
-
-def _unsupported(name):
-    def factory(num_layers, **kw):
-        raise NotImplementedError(f"backbone family '{name}' is outside this build's hot-path scope (SURVEY.md §8 f); "
-                                  f"available: res_*, resdcn_*, dla_34")
-    return factory
 
 
 _model_factory = {
     "res": get_pose_net,          # ResNet + deconv
     "dla": get_dla_dcn,           # DLA-34 + DCNv2
     "resdcn": get_pose_net_dcn,   # ResNet + DCNv2 / deconv up path
-    "hourglass": _unsupported("hourglass"),
+    "hourglass": get_large_hourglass_net,   # 2-stack Hourglass-104
 }
 
 

@@ -490,6 +490,27 @@ class AddFn(Function):
         return dy, dy
 
 
+class UpsampleAddFn(Function):
+    """y = a + nn.Upsample(scale_factor=2)(low)  — the hourglass merge (large_hourglass.py:196-204); a may be None."""
+
+    @staticmethod
+    def forward(ctx, a, low):
+        N, H, W, C = low.shape
+        low = low.contiguous()
+        y = _empty_like_shape(low, (N, 2 * H, 2 * W, C))
+        call("cn_upsample2x_add", None if a is None else a.contiguous(), low, y, N, H, W, C, dtype_code(low.dtype))
+        ctx.has_a = a is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, OH, OW, C = dy.shape
+        dy = dy.contiguous()
+        dlow = _empty_like_shape(dy, (N, OH // 2, OW // 2, C))
+        call("cn_sumpool2x2", dy, dlow, N, OH // 2, OW // 2, C, dtype_code(dy.dtype))
+        return (dy if ctx.has_a else None), dlow
+
+
 class ConcatFn(Function):
     """torch.cat(xs, channel) on NHWC (pose_dla_dcn.py:182)."""
 
@@ -768,6 +789,10 @@ def max_pool(x, k, stride, pad=0):
 
 def add(a, b):
     return AddFn.apply(a, b)
+
+
+def upsample2x_add(a, low):
+    return UpsampleAddFn.apply(a, low)
 
 
 def concat(xs):

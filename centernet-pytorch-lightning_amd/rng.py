@@ -63,13 +63,15 @@ def t_normal(seed, tag, shape, mean=0.0, std=1.0):
     return torch.from_numpy(normal(seed, tag, tuple(shape), mean, std))
 
 
-def fill_state_dict(module, seed=1234, bn_jitter=True):
+def fill_state_dict(module, seed=1234, bn_jitter=True, var_scale=1.0):
     """Deterministic weights for any module exposing the reference's state_dict names.
 
     conv / deconv weights ~ N(0, sqrt(2/fan_in)); biases small; BN gamma ~ U[0.8,1.2],
     beta ~ U[-0.1,0.1], running_mean ~ N(0,0.1), running_var ~ U[0.5,1.5].
     Heads follow the reference init (heads.py:45-50): ``heatmap*`` last bias -2.19.
     DCN ``conv_offset_mask`` gets small non-zero values so sampling is exercised.
+    ``var_scale`` multiplies every running_var (eval-mode fixtures of very deep residual stacks: without it the
+    ~50 un-normalised residual additions of Hourglass-104 double the variance each and the maps reach 1e7).
     """
     sd = module.state_dict()
     out = {}
@@ -85,7 +87,7 @@ def fill_state_dict(module, seed=1234, bn_jitter=True):
         if leaf == "running_mean":
             v = normal(seed, name, shape, 0.0, 0.1)
         elif leaf == "running_var":
-            v = uniform(seed, name, shape, 0.5, 1.5)
+            v = uniform(seed, name, shape, 0.5, 1.5) * np.float32(var_scale)
         elif t.dim() == 1 and leaf == "weight":      # BN gamma
             v = uniform(seed, name, shape, 0.8, 1.2) if bn_jitter else np.ones(shape, np.float32)
         elif t.dim() == 1:                           # bias / BN beta

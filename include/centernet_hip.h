@@ -126,6 +126,11 @@ int cn_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, in
                    int OH, int OW, int dtype, void* stream);
 int cn_maxpool_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
                    int OH, int OW, int dtype, void* stream);
+/* Hourglass merge (large_hourglass.py:108-125 MergeUp/make_unpool_layer, :196-204 kp_module.forward):
+ * y[N,2H,2W,C] = a + nearest_up2x(low[N,H,W,C]); a == NULL gives plain nn.Upsample(scale_factor=2).  Backward of the
+ * up-sampled operand: dlow[N,H,W,C] = 2x2 block sums of dy[N,2H,2W,C] (the `a` operand's gradient is dy itself). */
+int cn_upsample2x_add(const void* a, const void* low, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int cn_sumpool2x2(const void* dy, void* dlow, int N, int H, int W, int C, int dtype, void* stream);
 /* depthwise ConvTranspose2d(o,o,2f,stride=f,padding=f/2,groups=o) — pose_dla_dcn.py:466-475; w fp32 [C,1,k,k] */
 int cn_dwdeconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int k, int stride, int pad,
                     int OH, int OW, int dtype, void* stream);

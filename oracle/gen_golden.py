@@ -23,7 +23,7 @@ from oracle.dcn_ref import DCN as OracleDCN  # noqa: E402
 
 refshim.install(OracleDCN)
 
-from CenterNet.models.backbones import msra_resnet, pose_dla_dcn, resnet_dcn  # noqa: E402
+from CenterNet.models.backbones import msra_resnet, pose_dla_dcn, resnet_dcn, large_hourglass  # noqa: E402
 from CenterNet.models.heads import CenterHead  # noqa: E402
 from CenterNet.utils.losses import FocalLoss, RegL1Loss, RegWeightedL1Loss  # noqa: E402
 from CenterNet.utils.decode import sigmoid_clamped, _nms, _topk, _topk_channel  # noqa: E402
@@ -202,6 +202,78 @@ def gen_models():
         model_fixture(f"resdcn18_{'train' if train else 'eval'}.npz", net, 64, 128, 33, train)
 
 
+HG_VAR_SCALE = 16.0     # see rng.fill_state_dict: keeps the eval-mode hourglass maps O(1)
+
+
+def gen_hourglass():
+    """the reference's own HourglassNet (2 stacks) + one CenterHead per stack; the loss follows
+    centernet_detection.py:97-130 (per-stack terms summed, weighted, divided by num_stacks)."""
+    seed, size, B = 34, 256, 2
+    for train in (False, True):
+        net = large_hourglass.HourglassNet()
+        heads = torch.nn.ModuleList([CenterHead({"heatmap": 80, "width_height": 2, "regression": 2}, net.out_channels, 256)
+                                     for _ in range(2)])
+        full = torch.nn.ModuleDict({"backbone": net, "heads": heads})
+        rng.fill_state_dict(full, seed, var_scale=HG_VAR_SCALE)
+        full.train(train)
+        x, tgt = synth.ctdet_batch(seed, B, size, size)
+        feats = net(x)
+        outs = [h(f) for h, f in zip(heads, feats)]
+        kw = dict(seed=seed, size=size, train=int(train), var_scale=HG_VAR_SCALE)
+        hm = wh = off = 0
+        for s_, (f, out) in enumerate(zip(feats, outs)):
+            kw[f"feat{s_}_s"], kw[f"feat{s_}_sum"] = strided(f), summary(f)
+            for k, v in out.items():
+                kw[f"{k}{s_}_s"], kw[f"{k}{s_}_sum"] = strided(v), summary(v)
+            out["heatmap"] = sigmoid_clamped(out["heatmap"])
+            hm = hm + FocalLoss()(out["heatmap"], tgt["heatmap"])
+            wh = wh + RegL1Loss()(out["width_height"], tgt["regression_mask"], tgt["indices"], tgt["width_height"])
+            off = off + RegL1Loss()(out["regression"], tgt["regression_mask"], tgt["indices"], tgt["regression"])
+        loss = (hm + 0.1 * wh + off) / 2
+        kw.update(hm=hm, wh=wh, off=off, loss=loss)
+        if train:
+            loss.backward()
+            params = dict(full.named_parameters())
+            picks = ["backbone.pre.0.conv.weight", "backbone.pre.1.skip.0.weight", "backbone.kps.0.up1.0.conv1.weight",
+                     "backbone.kps.0.low2.low2.low2.low2.low2.3.conv2.weight", "backbone.kps.0.low2.low1.0.skip.0.weight",
+                     "backbone.kps.1.low3.1.conv1.weight", "backbone.kps.1.low2.low3.1.bn2.weight", "backbone.cnvs.0.conv.weight",
+                     "backbone.inters.0.conv2.weight", "backbone.inters_.0.0.weight", "backbone.cnvs_.0.1.bias",
+                     "heads.0.heatmap.fc.2.weight", "heads.1.width_height.fc.0.weight"]
+            for n in picks:
+                g = params[n].grad
+                kw["g:" + n + ":s"], kw["g:" + n + ":sum"] = strided(g, 512), summary(g)
+            kw["dead_params"] = np.array([n for n, p in params.items() if p.grad is None])
+            sd = full.state_dict()
+            kw["bn_running_mean"] = sd["backbone.pre.0.bn.running_mean"]
+            kw["bn_running_var"] = sd["backbone.pre.0.bn.running_var"]
+            # The same reference modules in fp64: the "exact" values.  Behind ~100 convs with batch statistics over as few
+            # as 8 samples the reference's OWN fp32 run is 1e-4 (maps) / 3e-2 (deep gradients) away from these, so the HIP
+            # path is judged by its distance to the fp64 values relative to the reference's fp32 distance to them.
+            full64 = torch.nn.ModuleDict({"backbone": large_hourglass.HourglassNet(), "heads": torch.nn.ModuleList(
+                [CenterHead({"heatmap": 80, "width_height": 2, "regression": 2}, 256, 256) for _ in range(2)])})
+            rng.fill_state_dict(full64, seed, var_scale=HG_VAR_SCALE)
+            full64 = full64.double().train()
+            t64 = {k: (v.double() if v.is_floating_point() else v) for k, v in tgt.items()}
+            outs64 = [h(f) for h, f in zip(full64["heads"], full64["backbone"](x.double()))]
+            l64 = 0
+            for s_, out in enumerate(outs64):
+                for k, v in out.items():
+                    kw[f"{k}{s_}_s64"] = strided(v)
+                hm64 = sigmoid_clamped(out["heatmap"])
+                l64 = l64 + FocalLoss()(hm64, t64["heatmap"]) \
+                    + 0.1 * RegL1Loss()(out["width_height"], t64["regression_mask"], t64["indices"], t64["width_height"]) \
+                    + RegL1Loss()(out["regression"], t64["regression_mask"], t64["indices"], t64["regression"])
+            (l64 / 2).backward()
+            p64 = dict(full64.named_parameters())
+            for n in picks:
+                kw["g64:" + n + ":s"] = strided(p64[n].grad, 512)
+            kw["loss64"] = (l64 / 2).detach()
+        else:
+            o = outs[-1]
+            kw["det"] = ctdet_decode(o["heatmap"].detach().clone(), o["width_height"].detach(), o["regression"].detach())
+        save(f"hourglass_{'train' if train else 'eval'}.npz", **kw)
+
+
 def gen_pose():
     seed, B, K = 41, 2, 100
     while True:
@@ -220,6 +292,6 @@ def gen_pose():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode", "decode", "losses", "models", "pose"]
+    which = sys.argv[1:] or ["encode", "decode", "losses", "models", "hourglass", "pose"]
     for w in which:
         globals()["gen_" + w]()

@@ -318,6 +318,85 @@ class DLASeg(nn.Module):
         return [y[-1]]
 
 
+# ----------------------------------------------------------------------------- Hourglass-104
+class HgConvolution(nn.Module):
+    """large_hourglass.py:11-31 (default BN momentum, unlike the ResNet/DLA files)."""
+
+    def __init__(self, k, cin, cout, stride=1):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return torch.relu(self.bn(self.conv(x)))
+
+
+class HgResidual(nn.Module):
+    """large_hourglass.py:52-92."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.skip = (nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+                     if stride != 1 or cin != cout else nn.Sequential())
+
+    def forward(self, x):
+        y = torch.relu(self.bn1(self.conv1(x)))
+        return torch.relu(self.bn2(self.conv2(y)) + self.skip(x))
+
+
+def _hg_layer(cin, cout, n, stride=1):      # make_layer :95-99, make_hg_layer :325-328
+    return nn.Sequential(HgResidual(cin, cout, stride), *[HgResidual(cout, cout) for _ in range(n - 1)])
+
+
+def _hg_layer_revr(cin, cout, n):           # make_layer_revr :102-107
+    return nn.Sequential(*[HgResidual(cin, cin) for _ in range(n - 1)], HgResidual(cin, cout))
+
+
+class HgModule(nn.Module):
+    """kp_module, large_hourglass.py:143-204: up1(x) + nearest_up2x(low3(low2(low1(x)))); pool layer is empty (:120-121)."""
+
+    def __init__(self, n, dims, mods):
+        super().__init__()
+        self.up1 = _hg_layer(dims[0], dims[0], mods[0])
+        self.low1 = _hg_layer(dims[0], dims[1], mods[0], stride=2)
+        self.low2 = HgModule(n - 1, dims[1:], mods[1:]) if n > 1 else _hg_layer(dims[1], dims[1], mods[1])
+        self.low3 = _hg_layer_revr(dims[1], dims[0], mods[0])
+
+    def forward(self, x):
+        low = self.low3(self.low2(self.low1(x)))
+        return self.up1(x) + nn.functional.interpolate(low, scale_factor=2, mode="nearest")
+
+
+class Hourglass(nn.Module):
+    """exkp :207-322 with HourglassNet's constants :331-348; returns one 256-channel map per stack."""
+
+    def __init__(self, nstack=2):
+        super().__init__()
+        dims, mods = [256, 256, 384, 384, 384, 512], [2, 2, 2, 2, 2, 4]
+        self.nstack, self.out_channels = nstack, 256
+        self.pre = nn.Sequential(HgConvolution(7, 3, 128, 2), HgResidual(128, 256, 2))
+        self.kps = nn.ModuleList([HgModule(5, dims, mods) for _ in range(nstack)])
+        self.cnvs = nn.ModuleList([HgConvolution(3, 256, 256) for _ in range(nstack)])
+        self.inters = nn.ModuleList([HgResidual(256, 256) for _ in range(nstack - 1)])
+        self.inters_ = nn.ModuleList([nn.Sequential(nn.Conv2d(256, 256, 1, bias=False), nn.BatchNorm2d(256)) for _ in range(nstack - 1)])
+        self.cnvs_ = nn.ModuleList([nn.Sequential(nn.Conv2d(256, 256, 1, bias=False), nn.BatchNorm2d(256)) for _ in range(nstack - 1)])
+
+    def forward(self, x):
+        inter, outs = self.pre(x), []
+        for i in range(self.nstack):
+            cnv = self.cnvs[i](self.kps[i](inter))
+            outs.append(cnv)
+            if i < self.nstack - 1:
+                inter = self.inters[i](torch.relu(self.inters_[i](inter) + self.cnvs_[i](cnv)))
+        return outs
+
+
+
+
 # ----------------------------------------------------------------------------- heads
 class HeadConv(nn.Module):
     """heads.py:4-25."""
@@ -363,6 +442,8 @@ def create_model(arch):
     if name == "dla":
         assert int(n) == 34
         return DLASeg()
+    if name == "hourglass":
+        return Hourglass()
     raise KeyError(arch)
 
 
@@ -378,10 +459,11 @@ class CenterNetRef(nn.Module):
         super().__init__()
         from . import ops_ref
         self.backbone = create_model(arch)
-        head_conv = 256 if "dla" in arch else 64                                         # centernet.py:15
+        head_conv = 256 if "dla" in arch or "hourglass" in arch else 64                  # centernet.py:15
+        num_stacks = 2 if "hourglass" in arch else 1                                     # centernet.py:16
         self.task = task
         heads = dict(heads or (CTDET_HEADS if task == "ctdet" else POSE_HEADS))
-        self.heads = nn.ModuleList([CenterHead(heads, self.backbone.out_channels, head_conv)])
+        self.heads = nn.ModuleList([CenterHead(heads, self.backbone.out_channels, head_conv) for _ in range(num_stacks)])
         self._ops = ops_ref
 
     def forward(self, x):
@@ -389,4 +471,10 @@ class CenterNetRef(nn.Module):
 
     def loss(self, outputs, target):
         fn = self._ops.ctdet_loss if self.task == "ctdet" else self._ops.multi_pose_loss
-        return fn(outputs[0], target)
+        if len(outputs) == 1:
+            return fn(outputs[0], target)
+        # centernet_detection.py:99-123: per-stack terms are SUMMED, the weighted total is divided by num_stacks
+        per = [fn(o, target)[1] for o in outputs]
+        stats = {k: sum(p[k] for p in per) for k in per[0]}
+        stats["loss"] = stats["loss"] / len(outputs)
+        return stats["loss"], stats

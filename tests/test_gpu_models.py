@@ -8,7 +8,7 @@ import torch
 
 from centernet_amd import rng, synth
 from oracle import models_ref, ops_ref
-from conftest import strided, summary
+from conftest import strided, summary, assert_det_rank_tolerant
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -75,19 +75,85 @@ def test_network_fp32_vs_reference_golden(golden, arch, size, train):
         det = m.decode({"heatmap": raw["heatmap"], "width_height": raw["width_height"], "regression": raw["regression"]})
         got, ref = det.cpu().numpy(), g["det"]
         if arch == "resdcn_18":
-            # this fixture has top-100 scores closer together than the 1e-4 heat-map tolerance: neighbouring ranks may
-            # swap.  Every reference detection must be present (same class, same box, same score), ranks may differ only
-            # between scores that are within 2e-4 of each other.
-            for b in range(ref.shape[0]):
-                for i, r in enumerate(ref[b]):
-                    d = np.abs(got[b][:, :4] - r[:4]).max(1) + 1e3 * (got[b][:, 5] != r[5])
-                    j = int(d.argmin())
-                    cutoff = abs(r[4] - ref[b][-1, 4]) < 2e-4 * r[4]           # may fall off the end of the top-100
-                    assert cutoff or (d[j] < 2e-3 + 1e-3 * np.abs(r[:4]).max() and abs(got[b][j, 4] - r[4]) < 1e-4), (b, i)
-                    assert cutoff or j == i or abs(ref[b][j, 4] - r[4]) < 2e-4 * r[4], (b, i, j)
+            assert_det_rank_tolerant(got, ref)      # top-100 scores closer together than the heat-map tolerance
         else:
             np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-3)
             assert np.array_equal(got[..., 5], ref[..., 5]), "decoded classes identical"
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_hourglass_fp32_vs_reference_golden(golden, train):
+    """2-stack Hourglass-104 + one CenterHead per stack against the reference's own modules (fixture from
+    oracle/gen_golden.py gen_hourglass); the loss averages the stacks (centernet_detection.py:99-123)."""
+    g = golden("hourglass_train.npz" if train else "hourglass_eval.npz")
+    seed, size = int(g["seed"]), int(g["size"])
+    from centernet_amd.centernet_detection import CenterNetDetection
+    m = CenterNetDetection("hourglass", compute_dtype=torch.float32)
+    rng.fill_state_dict(m, seed, var_scale=float(g["var_scale"]))
+    m = m.to(DEV).train(train)
+    x, tgt = synth.ctdet_batch(seed, 2, size, size)
+    xg, tg = x.to(DEV), {k: v.to(DEV) for k, v in tgt.items()}
+    with torch.set_grad_enabled(train):
+        outs = m(xg)
+    assert len(outs) == 2
+    for s_, out in enumerate(outs):
+        for k in ("heatmap", "width_height", "regression"):
+            ref_s = g[f"{k}{s_}_s"]
+            got_s = strided(out[k]).cpu().numpy()
+            # 1e-4 of the map's range (north_star) against the reference's fp32 values.  In train mode the second stack
+            # sits behind ~100 convs with batch statistics over as few as 8 samples (2x2 maps, B=2) and the reference's
+            # OWN fp32 run is ~1e-4 away from exact arithmetic: there the yardstick is the reference run in fp64
+            # (`*_s64`), and the HIP path may be at most 4x as far from it as the reference's fp32 run is.
+            tol = 1e-4
+            if train:
+                ref64 = g[f"{k}{s_}_s64"]
+                ref_noise = np.abs(ref_s - ref64).max() / np.abs(ref64).max()
+                assert np.abs(got_s - ref64).max() < max(1e-4, 4 * ref_noise) * np.abs(ref64).max() + 1e-6, (k, s_, ref_noise)
+                tol = max(1e-4, 5 * ref_noise)
+            assert np.abs(got_s - ref_s).max() < tol * np.abs(ref_s).max() + 1e-6, (k, s_)
+            np.testing.assert_allclose(summary(out[k]), g[f"{k}{s_}_sum"], rtol=tol, atol=tol * float(g[f"{k}{s_}_sum"][1]))
+    raw = {k: v.detach().clone() for k, v in outs[-1].items()}
+    with torch.set_grad_enabled(train):
+        loss, st = m.loss(outs, tg)
+    for k, gk in (("hm_loss", "hm"), ("wh_loss", "wh"), ("off_loss", "off"), ("loss", "loss")):
+        assert float(st[k]) == pytest.approx(float(g[gk]), rel=1e-4), k
+    if train:
+        loss.backward()
+        params = dict(m.named_parameters())
+        for key in g.files:
+            if key.startswith("g:") and key.endswith(":s"):
+                n = key[2:-2]
+                ref = g[key].astype(np.float64)
+                got = strided(params[n].grad, 512).cpu().numpy().astype(np.float64)
+                # yardstick: the reference's gradients in fp64 (`g64:`); its own fp32 run is up to 3.6e-2 (rel. L2) away
+                # from them on the deepest layers (ReLU sign flips behind batch-statistic BN).  Over ALL 600+ parameter
+                # tensors the HIP fp32 path is a uniform 2.2x (median; max 4.6x) as far as the reference's fp32 run
+                # (sequential-K MFMA accumulation vs oneDNN's blocked sums); the 512-entry samples of the fixture
+                # scatter around that, so: 6x the reference's own distance, or 0.1 where that distance is tiny.
+                ref64 = g["g64:" + n + ":s"]
+                ref_noise = np.linalg.norm(ref - ref64) / np.linalg.norm(ref64)
+                mine = np.linalg.norm(got - ref64) / np.linalg.norm(ref64)
+                bound = 6 * ref_noise + 1e-5 if n.startswith("heads") else max(6 * ref_noise, 0.1)
+                assert mine < bound, f"grad {n}: rel-L2 to fp64 {mine:.3e}, reference fp32 {ref_noise:.3e}"
+        sd = m.state_dict()
+        np.testing.assert_allclose(sd["backbone.pre.0.bn.running_mean"].cpu().numpy(), g["bn_running_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sd["backbone.pre.0.bn.running_var"].cpu().numpy(), g["bn_running_var"], rtol=1e-4, atol=1e-6)
+    else:
+        det = m.decode({"heatmap": raw["heatmap"], "width_height": raw["width_height"], "regression": raw["regression"]})
+        assert_det_rank_tolerant(det.cpu().numpy(), g["det"])
+
+
+def test_hourglass_bf16_trains():
+    from centernet_amd.engine import TrainStep
+    from centernet_amd.centernet_detection import CenterNetDetection
+    m = CenterNetDetection("hourglass", compute_dtype=torch.bfloat16)
+    rng.fill_state_dict(m, 96)
+    m = m.to(DEV).train()
+    x, tgt = synth.ctdet_batch(96, 2, 128, 128)
+    batch = (x.to(DEV), {k: v.to(DEV) for k, v in tgt.items()})
+    step = TrainStep(m, lr=2.5e-4, distributed=False)
+    hist = [float(step(batch)) for _ in range(6)]
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
 
 
 @pytest.mark.parametrize("arch,size", [("res_18", 128), ("dla_34", 128)])

@@ -56,6 +56,13 @@ CONVS = [  # N,H,W,Ci,Co,k,s,p,bias,relu
     (1, 9, 9, 256, 2, 1, 1, 0, True, False),
     (2, 4, 4, 512, 256, 3, 1, 1, False, False),
     (1, 24, 24, 448, 128, 1, 1, 0, False, False),
+    (2, 32, 32, 256, 256, 3, 1, 1, False, False),   # Hourglass shapes (384-wide levels, 2x2 / 1x1 maps, strided residuals)
+    (2, 16, 16, 256, 384, 3, 2, 1, False, False),
+    (2, 8, 8, 384, 384, 3, 1, 1, False, False),
+    (2, 2, 2, 384, 512, 3, 2, 1, False, False),
+    (2, 1, 1, 512, 512, 3, 1, 1, False, False),
+    (2, 4, 4, 384, 512, 1, 2, 0, False, False),
+    (2, 32, 32, 128, 256, 3, 2, 1, False, False),
 ]
 
 
@@ -110,7 +117,7 @@ def test_conv_transpose_4x4_s2(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 32, 32, 16, 1), (2, 37, 41, 64, 2), (1, 64, 96, 16, 1)])
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 16, 1), (2, 37, 41, 64, 2), (1, 64, 96, 16, 1), (2, 40, 36, 128, 2)])
 def test_stem_conv(cfg, dt):
     N, H, W, Co, s = cfg
     x = rng.t_normal(3, f"x{cfg}", (N, 3, H, W))
@@ -180,6 +187,31 @@ def test_maxpool(cfg, dt):
     assert torch.equal(to_nchw(y), yr.detach()), "maxpool fwd must be exact"
     y.backward(to_nhwc(gy, dt))
     close(to_nchw(xg.grad), xr.grad, dt, "maxpool bwd (first-max tie rule)")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 4, 4, 256, True), (1, 7, 5, 384, True), (2, 1, 1, 512, True), (2, 6, 9, 64, False)])
+def test_upsample2x_add(cfg, dt):
+    """Hourglass merge: up1 + nn.Upsample(scale_factor=2)(low3) (large_hourglass.py:196-204) and its adjoint."""
+    N, H, W, C, with_a = cfg
+    low = rnd(rng.t_normal(6, f"l{cfg}", (N, C, H, W)), dt)
+    a = rnd(rng.t_normal(6, f"a{cfg}", (N, C, 2 * H, 2 * W)), dt) if with_a else None
+    lr = low.clone().requires_grad_(True)
+    ar = a.clone().requires_grad_(True) if with_a else None
+    up = F.interpolate(lr, scale_factor=2, mode="nearest")
+    yr = up + ar if with_a else up
+    gy = rnd(rng.t_normal(6, f"g{cfg}", tuple(yr.shape)), dt)
+    yr.backward(gy)
+    lg = to_nhwc(low, dt).requires_grad_(True)
+    ag = to_nhwc(a, dt).requires_grad_(True) if with_a else None
+    y = ops().upsample2x_add(ag, lg)
+    close(to_nchw(y), yr, dt, "upsample2x_add fwd")
+    if not with_a:
+        assert torch.equal(to_nchw(y), yr.detach()), "plain nearest up-sampling is a copy"
+    y.backward(to_nhwc(gy, dt))
+    close(to_nchw(lg.grad), lr.grad, dt, "upsample2x_add d(low) = 2x2 sums")
+    if with_a:
+        assert torch.equal(to_nchw(ag.grad), ar.grad), "d(a) is dy itself"
 
 
 @pytest.mark.parametrize("dt", DTYPES)
