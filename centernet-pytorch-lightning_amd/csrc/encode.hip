@@ -82,3 +82,85 @@ extern "C" int cn_encode_ctdet(const float* boxes, const int* cls, const int* no
     CN_LAUNCH_CHECK("cn_encode_ctdet");
     return CN_OK;
 }
+
+// ---- multi_pose targets (sample/multi_pose.py:35-112) ----------------------------------------------------------------------
+// One workgroup per (object k, joint j, image b).  Lane 0 redoes the object's box arithmetic (fp32, like the numpy original),
+// writes keypoints / masks / offsets / indices; all lanes splat the joint's gaussian (draw_msra_gaussian, utils/gaussian.py:
+// 61-83) with the FLOAT sigma = gaussian_radius(ceil h, ceil w) the reference passes:  t = 3 sigma, ul = trunc(c - t),
+// br = trunc(c + t + 1), dropped entirely when the box touches the border, g(i, j) = exp(-((i - x0)^2 + (j - x0)^2) / (2 sigma^2))
+// with x0 = floor(t + 0.5) relative to ul — the peak is one pixel up/left of the keypoint when frac(t) < 0.5, as in the reference.
+// Every slot of the six outputs is written (zeros for empty slots) except the heat map, which the caller zero-fills.
+__global__ __launch_bounds__(256) void encode_multi_pose_kernel(const float* __restrict__ boxes, const float* __restrict__ kps,
+                                                                const int* __restrict__ nobj, float* __restrict__ hm_hp,
+                                                                float* __restrict__ kp_out, unsigned char* __restrict__ kp_mask,
+                                                                float* __restrict__ hp_off, int64_t* __restrict__ hp_ind,
+                                                                unsigned char* __restrict__ hp_mask, int M, int J, int OH, int OW,
+                                                                float down) {
+    const int j = blockIdx.x % J, k = blockIdx.x / J, b = blockIdx.y;
+    __shared__ int s_i[6];          // valid, ulx, uly, nx, ny
+    __shared__ float s_f[2];        // x0, 2 sigma^2
+    if (threadIdx.x == 0) {
+        const int64_t o = (int64_t)b * M + k;
+        float kx = 0.f, ky = 0.f, ox = 0.f, oy = 0.f;
+        int64_t ind = 0;
+        int valid = 0, draw = 0, ulx = 0, uly = 0, nx = 0, ny = 0;
+        float x0 = 0.f, den = 1.f;
+        if (k < nobj[b]) {
+            const float* bb = boxes + o * 4;
+            float bx0 = bb[0] / down, by0 = bb[1] / down, bx1 = (bb[0] + bb[2]) / down, by1 = (bb[1] + bb[3]) / down;
+            bx0 = fminf(fmaxf(bx0, 0.f), (float)(OW - 1)); bx1 = fminf(fmaxf(bx1, 0.f), (float)(OW - 1));
+            by0 = fminf(fmaxf(by0, 0.f), (float)(OH - 1)); by1 = fminf(fmaxf(by1, 0.f), (float)(OH - 1));
+            const float h = by1 - by0, w = bx1 - bx0;
+            const float* pt = kps + (o * J + j) * 3;
+            if (h > 0.f && w > 0.f && pt[2] != 0.f) {
+                const int ctx = (int)((bx0 + bx1) / 2.f), cty = (int)((by0 + by1) / 2.f);
+                const float px = fminf(fmaxf(pt[0] / down, 0.f), (float)(OW - 1)), py = fminf(fmaxf(pt[1] / down, 0.f), (float)(OH - 1));
+                const int ix = (int)px, iy = (int)py;
+                kx = px - (float)ctx; ky = py - (float)cty;
+                ox = px - (float)ix; oy = py - (float)iy;
+                ind = (int64_t)iy * OW + ix;
+                valid = 1;
+                const double sigma = gaussian_radius_d(ceil((double)h), ceil((double)w));
+                const double t = sigma * 3.0;
+                const int ux = (int)((double)ix - t), uy = (int)((double)iy - t);
+                const int rx = (int)((double)ix + t + 1.0), ry = (int)((double)iy + t + 1.0);
+                if (!(rx >= OW || ry >= OH || ux < 0 || uy < 0)) {
+                    draw = 1; ulx = ux; uly = uy; nx = rx - ux; ny = ry - uy;
+                    x0 = (float)floor((2.0 * t + 1.0) / 2.0);
+                    den = (float)(2.0 * sigma * sigma);
+                }
+            }
+        }
+        const int64_t oj = o * J + j;
+        kp_out[oj * 2] = kx; kp_out[oj * 2 + 1] = ky;
+        kp_mask[oj * 2] = kp_mask[oj * 2 + 1] = (unsigned char)valid;
+        hp_off[oj * 2] = ox; hp_off[oj * 2 + 1] = oy;
+        hp_ind[oj] = ind;
+        hp_mask[oj] = (unsigned char)valid;
+        s_i[0] = draw; s_i[1] = ulx; s_i[2] = uly; s_i[3] = nx; s_i[4] = ny;
+        s_f[0] = x0; s_f[1] = den;
+    }
+    __syncthreads();
+    if (!s_i[0]) return;
+    const int ulx = s_i[1], uly = s_i[2], nx = s_i[3], ny = s_i[4];
+    const float x0 = s_f[0], den = s_f[1];
+    int* hm = reinterpret_cast<int*>(hm_hp + ((int64_t)b * J + j) * OH * OW);
+    for (int i = threadIdx.x; i < nx * ny; i += blockDim.x) {
+        const int gy = i / nx, gx = i % nx;
+        const float dx = (float)gx - x0, dy = (float)gy - x0;
+        const float v = expf(-(dx * dx + dy * dy) / den);
+        atomicMax(hm + (int64_t)(uly + gy) * OW + ulx + gx, __float_as_int(v));
+    }
+}
+
+extern "C" int cn_encode_multi_pose(const float* boxes, const float* keypoints, const int* nobj, float* heatmap_keypoints,
+                                    float* kp_out, unsigned char* kp_mask, float* hp_offset, int64_t* hp_indices,
+                                    unsigned char* hp_mask, int B, int M, int J, int OH, int OW, int down_ratio, void* stream) {
+    CN_CHECK_ARG(boxes && keypoints && nobj && heatmap_keypoints && kp_out && kp_mask && hp_offset && hp_indices && hp_mask,
+                 "cn_encode_multi_pose: null pointer");
+    CN_CHECK_ARG(B > 0 && M > 0 && J > 0 && OH > 0 && OW > 0 && down_ratio > 0 && B <= 65535, "cn_encode_multi_pose: bad dims");
+    hipLaunchKernelGGL(encode_multi_pose_kernel, dim3(M * J, B), dim3(256), 0, (hipStream_t)stream, boxes, keypoints, nobj,
+                       heatmap_keypoints, kp_out, kp_mask, hp_offset, hp_indices, hp_mask, M, J, OH, OW, (float)down_ratio);
+    CN_LAUNCH_CHECK("cn_encode_multi_pose");
+    return CN_OK;
+}

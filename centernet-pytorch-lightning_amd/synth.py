@@ -79,6 +79,75 @@ def encode_ctdet(boxes, in_h=512, in_w=512, down=4, num_classes=80, max_objs=128
     return {"heatmap": hm, "regression_mask": msk, "indices": ind, "width_height": wh, "regression": reg}
 
 
+def splat_msra(hm, cx, cy, sigma):
+    """utils/gaussian.py:61-83 (draw_msra_gaussian) as called from sample/multi_pose.py:100 — `sigma` is the FLOAT
+    gaussian_radius (not truncated), the centre is the integer keypoint.  Quirks kept: a gaussian whose 3-sigma box touches
+    the border is dropped entirely (:67-68, with the reference's swapped w/h names); the box corners truncate toward zero;
+    the peak sits at `ul + floor(3 sigma + 0.5)`, which is one pixel left/up of the keypoint when frac(3 sigma) < 0.5."""
+    t = sigma * 3
+    H, W = hm.shape
+    ul = (int(cx - t), int(cy - t))
+    br = (int(cx + t + 1), int(cy + t + 1))
+    if br[0] >= W or br[1] >= H or ul[0] < 0 or ul[1] < 0:
+        return
+    size = 2 * t + 1
+    x = np.arange(0, size, 1, np.float32)
+    y = x[:, None]
+    x0 = y0 = size // 2
+    g = np.exp(-((x - np.float32(x0)) ** 2 + (y - np.float32(y0)) ** 2) / np.float32(2 * sigma ** 2))
+    sub = hm[ul[1]:br[1], ul[0]:br[0]]
+    np.maximum(sub, g[:br[1] - ul[1], :br[0] - ul[0]], out=sub)
+
+
+def encode_multi_pose(anns, in_h=512, in_w=512, down=4, joints=17, max_objs=128):
+    """sample/multi_pose.py:35-112 in numpy.  anns: list of ([x,y,w,h], keypoints [joints*3] as x,y,visibility) in input pixels.
+    Returns the six pose target arrays (the ctdet part of a multi_pose sample is `encode_ctdet(..., num_classes=1)`)."""
+    oh, ow = in_h // down, in_w // down
+    T = {"heatmap_keypoints": np.zeros((joints, oh, ow), np.float32),
+         "keypoints": np.zeros((max_objs, 2 * joints), np.float32),
+         "keypoints_mask": np.zeros((max_objs, 2 * joints), bool),
+         "heatmap_keypoints_offset": np.zeros((max_objs * joints, 2), np.float32),
+         "heatmap_keypoints_indices": np.zeros((max_objs * joints,), np.int64),
+         "heatmap_keypoints_mask": np.zeros((max_objs * joints,), bool)}
+    f32 = np.float32
+    for k, (bb, kps) in enumerate(anns[:max_objs]):
+        box = np.array([bb[0], bb[1], bb[0] + bb[2], bb[1] + bb[3]], f32) / f32(down)
+        box[0::2] = np.clip(box[0::2], 0, ow - 1)
+        box[1::2] = np.clip(box[1::2], 0, oh - 1)
+        ctx, cty = int((box[0] + box[2]) / f32(2)), int((box[1] + box[3]) / f32(2))     # torch.IntTensor([...]): truncation
+        h, w = box[3] - box[1], box[2] - box[0]
+        if not (h > 0 and w > 0):
+            continue
+        sigma = gaussian_radius(math.ceil(h), math.ceil(w))
+        pts = np.array(kps, f32).reshape(joints, 3)
+        for j in range(joints):
+            if pts[j, 2] == 0:
+                continue
+            px = f32(np.clip(pts[j, 0] / f32(down), 0, ow - 1))
+            py = f32(np.clip(pts[j, 1] / f32(down), 0, oh - 1))
+            T["keypoints"][k, 2 * j:2 * j + 2] = (px - f32(ctx), py - f32(cty))
+            T["keypoints_mask"][k, 2 * j:2 * j + 2] = True
+            ix, iy = int(px), int(py)
+            T["heatmap_keypoints_offset"][k * joints + j] = (px - f32(ix), py - f32(iy))
+            T["heatmap_keypoints_indices"][k * joints + j] = iy * ow + ix
+            T["heatmap_keypoints_mask"][k * joints + j] = True
+            splat_msra(T["heatmap_keypoints"][j], ix, iy, sigma)
+    return T
+
+
+def random_pose_anns(seed, img_idx, in_h=512, in_w=512, max_n=8, joints=17):
+    """person boxes + keypoints scattered in and slightly around each box, ~25 % invisible (v = 0)."""
+    anns = []
+    for k, (bb, _) in enumerate(random_boxes(seed, img_idx, in_h, in_w, 1, max_n)):
+        u = rng.uniform(seed, f"pkp{img_idx}_{k}", (joints, 3))
+        kps = []
+        for j in range(joints):
+            kps += [float(np.float32(bb[0] + (1.3 * u[j, 0] - 0.15) * bb[2])), float(np.float32(bb[1] + (1.3 * u[j, 1] - 0.15) * bb[3])),
+                    0.0 if u[j, 2] < 0.25 else (1.0 if u[j, 2] < 0.5 else 2.0)]
+        anns.append(([float(np.float32(v)) for v in bb], kps))
+    return anns
+
+
 def random_boxes(seed, img_idx, in_h=512, in_w=512, num_classes=80, max_n=20):
     n = int(rng.randint(seed, f"nobj{img_idx}", (1,), 1, max_n + 1)[0])
     wh = rng.uniform(seed, f"bwh{img_idx}", (n, 2), 8.0, 256.0)

@@ -213,6 +213,14 @@ int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uint8_t* mask,
  * min_overlap 0.7 (utils/gaussian.py:6-58). */
 int cn_encode_ctdet(const float* boxes, const int* cls, const int* nobj, float* heatmap, unsigned char* mask,
                     int64_t* indices, float* wh, float* reg, int B, int M, int C, int OH, int OW, int down_ratio, void* stream);
+/* Replaces the host loop of MultiPoseSample.__call__ (sample/multi_pose.py:35-112; draw_msra_gaussian utils/gaussian.py:61-83)
+ * for a whole batch.  boxes fp32 [B,M,4] (x,y,w,h, input pixels), keypoints fp32 [B,M,J,3] (x,y,visibility), nobj int32 [B].
+ * Outputs (collated layouts of :103-110): heatmap_keypoints fp32 [B,J,OH,OW] (ZEROED by the caller), keypoints fp32 [B,M,2J],
+ * keypoints_mask u8 [B,M,2J], heatmap_keypoints_offset fp32 [B,M*J,2], heatmap_keypoints_indices int64 [B,M*J],
+ * heatmap_keypoints_mask u8 [B,M*J].  The ctdet part of a multi_pose sample is cn_encode_ctdet with C = 1. */
+int cn_encode_multi_pose(const float* boxes, const float* keypoints, const int* nobj, float* heatmap_keypoints,
+                         float* kp_out, unsigned char* kp_mask, float* hp_offset, int64_t* hp_indices,
+                         unsigned char* hp_mask, int B, int M, int J, int OH, int OW, int down_ratio, void* stream);
 
 /* ---- decode (utils/decode.py, decode/ctdet.py, decode/multi_pose.py) -------------------------- */
 /* keep[b,c,h,w] = heat * (maxpool3x3(heat) == heat)   (utils/decode.py:5-10) */

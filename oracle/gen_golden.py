@@ -30,6 +30,7 @@ from CenterNet.utils.decode import sigmoid_clamped, _nms, _topk, _topk_channel  
 from CenterNet.decode.ctdet import ctdet_decode  # noqa: E402
 from CenterNet.decode.multi_pose import multi_pose_decode  # noqa: E402
 from CenterNet.sample.ctdet import CenterDetectionSample  # noqa: E402
+from CenterNet.sample.multi_pose import MultiPoseSample  # noqa: E402
 
 from centernet_amd import rng, synth  # noqa: E402
 
@@ -97,6 +98,36 @@ def gen_encode():
     assert abs(centers.sum() - ann_c.sum()) < 1e-3
     save("known_answer.npz", n_det=len(det), center_sum=centers.sum(), ann_center_sum=ann_c.sum(),
          det_sorted=det[np.argsort(det[:, 0])])
+
+
+def gen_encode_pose():
+    """SURVEY 8 f-3 (multi_pose): the reference's MultiPoseSample on synthetic person annotations (boxes + 17 keypoints with
+    visibility 0/1/2; some keypoints outside their box, some boxes hanging over the border).
+    sample/multi_pose.py:74 builds `torch.IntTensor([np.float32, np.float32])`, which torch 2.x refuses (TypeError) while
+    the torch 1.10 the reference pins truncates like `int()`; the call below runs with exactly that legacy behaviour
+    restored for the duration (an environment shim: the reference source is untouched)."""
+    legacy = torch.IntTensor
+    torch.IntTensor = lambda seq: torch.tensor([int(v) for v in seq], dtype=torch.int32)
+    try:
+        kw = {}
+        for i, img_idx in enumerate((0, 1, 2, 3)):
+            anns = synth.random_pose_anns(55, img_idx)
+            if i == 1:
+                anns += [([480.0, 470.0, 60.0, 70.0], [500.0, 500.0, 2.0] * 17),        # clipped box, gaussian touching the border
+                         ([-20.0, -10.0, 90.0, 120.0], [3.0, 5.0, 1.0, 40.0, 60.0, 2.0] + [0.0, 0.0, 0.0] * 15),
+                         ([300.0, 300.0, 0.0, 50.0], [310.0, 320.0, 2.0] * 17)]           # zero-width box: skipped
+            target = [{"bbox": list(bb), "keypoints": list(kps)} for bb, kps in anns]
+            _, t = MultiPoseSample()(torch.zeros(3, 512, 512), target)
+            hk = t["heatmap_keypoints"].flatten()
+            kw[f"boxes{i}"] = np.array([bb for bb, _ in anns], np.float64)
+            kw[f"kps{i}"] = np.array([kps for _, kps in anns], np.float64)
+            kw[f"hm_nz_idx{i}"] = torch.nonzero(hk).flatten()
+            kw[f"hm_nz_val{i}"] = hk[hk != 0]
+            for k in ("keypoints", "keypoints_mask", "heatmap_keypoints_offset", "heatmap_keypoints_indices", "heatmap_keypoints_mask"):
+                kw[f"{k}{i}"] = t[k]
+        save("encode_pose_fixture.npz", n=4, **kw)
+    finally:
+        torch.IntTensor = legacy
 
 
 def gen_decode():
@@ -292,6 +323,6 @@ def gen_pose():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode", "decode", "losses", "models", "hourglass", "pose"]
+    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "hourglass", "pose"]
     for w in which:
         globals()["gen_" + w]()

@@ -216,3 +216,42 @@ def test_encode_ctdet_on_device(golden):
     np.testing.assert_allclose(flat[flat != 0].cpu().numpy(), g["heatmap_nz_val"], rtol=3e-7, atol=1e-7)
     np.testing.assert_allclose(one["width_height"].cpu().numpy(), g["width_height"], rtol=1e-6)
     np.testing.assert_allclose(one["regression"].cpu().numpy(), g["regression"], rtol=1e-5, atol=1e-6)
+
+
+def test_encode_multi_pose_on_device(golden):
+    """SURVEY 8 f-3 (multi_pose): cn_encode_multi_pose against the reference's MultiPoseSample outputs (encode_pose_fixture.npz)
+    and, on more annotation sets, against the host restatement that fixture pins: indices / masks / fp32 targets bit-exact,
+    gaussians on the same support and within one ulp of expf."""
+    from centernet_amd import synth
+    from centernet_amd.sample import MultiPoseSample, encode_multi_pose_batch
+    g = golden("encode_pose_fixture.npz")
+    sets = [[(list(b), list(k)) for b, k in zip(g[f"boxes{i}"], g[f"kps{i}"])] for i in range(int(g["n"]))]
+    sets += [synth.random_pose_anns(78, i) for i in range(4)]
+    B, M, J = len(sets), 128, 17
+    boxes = np.zeros((B, M, 4), np.float32); kps = np.zeros((B, M, J, 3), np.float32); cnt = np.zeros((B,), np.int32)
+    for b, anns in enumerate(sets):
+        for k, (bb, kp) in enumerate(anns):
+            boxes[b, k], kps[b, k] = bb, np.array(kp, np.float32).reshape(J, 3)
+        cnt[b] = len(anns)
+    t = encode_multi_pose_batch(torch.from_numpy(boxes).to(DEV), torch.from_numpy(kps).to(DEV), torch.from_numpy(cnt).to(DEV), 512, 512)
+    for b, anns in enumerate(sets):
+        r = synth.encode_multi_pose(anns)
+        for k in ("keypoints", "keypoints_mask", "heatmap_keypoints_offset", "heatmap_keypoints_indices", "heatmap_keypoints_mask"):
+            assert np.array_equal(t[k][b].cpu().numpy(), r[k]), (b, k)
+        hm = t["heatmap_keypoints"][b].cpu().numpy()
+        assert np.array_equal(hm != 0, r["heatmap_keypoints"] != 0), "same support"
+        np.testing.assert_allclose(hm, r["heatmap_keypoints"], rtol=3e-7, atol=1e-7)
+        e = synth.encode_ctdet([(bb, 0) for bb, _ in anns], num_classes=1)
+        assert np.array_equal(t["indices"][b].cpu().numpy(), e["indices"]) and np.array_equal(t["regression_mask"][b].cpu().numpy(), e["regression_mask"])
+        np.testing.assert_allclose(t["heatmap"][b].cpu().numpy(), e["heatmap"], rtol=3e-7, atol=1e-7)
+    for i in range(int(g["n"])):                       # straight against the reference's outputs
+        flat = t["heatmap_keypoints"][i].flatten()
+        assert np.array_equal(torch.nonzero(flat).flatten().cpu().numpy(), g[f"hm_nz_idx{i}"])
+        np.testing.assert_allclose(flat[flat != 0].cpu().numpy(), g[f"hm_nz_val{i}"], rtol=3e-7, atol=1e-7)
+        assert np.array_equal(t["keypoints"][i].cpu().numpy(), g[f"keypoints{i}"])
+        assert np.array_equal(t["heatmap_keypoints_indices"][i].cpu().numpy(), g[f"heatmap_keypoints_indices{i}"])
+    # the reference's transform signature
+    ann = [{"bbox": bb, "keypoints": kp} for bb, kp in sets[1]]
+    _, one = MultiPoseSample()(torch.zeros(3, 512, 512, device=DEV), ann)
+    assert np.array_equal(one["keypoints_mask"].cpu().numpy(), g["keypoints_mask1"])
+    assert np.array_equal(one["heatmap_keypoints_offset"].cpu().numpy(), g["heatmap_keypoints_offset1"])

@@ -171,3 +171,19 @@ def test_hourglass_matches_reference(golden, train):
         o = outs[-1]
         det = ops_ref.ctdet_decode(ops_ref.sigmoid_clamped(o["heatmap"]), o["width_height"], o["regression"])
         assert_det_rank_tolerant(det.detach().numpy(), g["det"])      # random heads: a flat map, top-100 within 1e-6
+
+
+def test_pose_encoder_matches_reference_fixture(golden):
+    """SURVEY 8 f-3 (multi_pose): the numpy restatement of sample/multi_pose.py (synth.encode_multi_pose) is BIT-EXACT against
+    the reference's MultiPoseSample on 4 annotation sets (gaussians dropped at the border, invisible joints, a clipped and a
+    zero-width box)."""
+    g = golden("encode_pose_fixture.npz")
+    for i in range(int(g["n"])):
+        anns = [(list(b), list(k)) for b, k in zip(g[f"boxes{i}"], g[f"kps{i}"])]
+        T = synth.encode_multi_pose(anns)
+        hk = T["heatmap_keypoints"].flatten()
+        nz = np.nonzero(hk)[0]
+        assert np.array_equal(nz, g[f"hm_nz_idx{i}"])
+        assert np.array_equal(hk[nz], g[f"hm_nz_val{i}"])
+        for k in ("keypoints", "keypoints_mask", "heatmap_keypoints_offset", "heatmap_keypoints_indices", "heatmap_keypoints_mask"):
+            assert np.array_equal(T[k], g[f"{k}{i}"]), (i, k)
