@@ -1,12 +1,14 @@
-"""`CenterNetDetection` (reference: CenterNet/centernet_detection.py:28-265) — forward / loss / decode on the HIP path.
-TTA resize, COCO evaluation and the CLI are outside the hot-path scope."""
+"""`CenterNetDetection` (reference: CenterNet/centernet_detection.py:28-265) — forward / loss / decode / test step on the HIP
+path.  COCO evaluation (pycocotools) and the CLI are outside the hot-path scope."""
 import torch
+import torch.nn.functional as F
 
 from .centernet import CenterNet
 from .decode.ctdet import ctdet_decode
 from .models.heads import CenterHead
 from .utils.decode import sigmoid_clamped
 from .utils.losses import FocalLoss, RegL1Loss
+from .utils import post
 
 
 class CenterNetDetection(CenterNet):
@@ -57,5 +59,37 @@ class CenterNetDetection(CenterNet):
         """The decode call of test_step_end (centernet_detection.py:183-187): sigmoid in place, then ctdet_decode."""
         return ctdet_decode(output["heatmap"].sigmoid_(), output["width_height"], reg=output["regression"], K=K)
 
+    @torch.no_grad()
     def test_step(self, batch, batch_idx):
-        raise NotImplementedError("TTA / COCO evaluation are outside the hot-path scope of this build; use `decode`")
+        """centernet_detection.py:132-173 for a BATCH of images in [0, 1] (the reference runs batch size 1): per test scale
+        resize -> zero-pad to `(size | padding) + 1` -> normalise -> (+ mirrored copy) in one launch, forward, and the mirrored
+        head maps folded back (heat map and sizes averaged, offsets from the unflipped pass)."""
+        img, _ = batch
+        B = img.shape[0]
+        image_id = ([self.test_coco_ids[batch_idx * B + i] for i in range(B)] if self.test_coco_ids
+                    else [batch_idx * B + i for i in range(B)])
+        outputs, meta = [], []
+        for scale in self.test_scales:
+            _, _, height, width = img.shape
+            nh, nw = int(height * scale), int(width * scale)
+            pad_y, pad_x = post.tta_pad(nh, self.padding), post.tta_pad(nw, self.padding)
+            x = img if (nh, nw) == (height, width) else F.interpolate(img.float(), size=(nh, nw), mode="bilinear",
+                                                                      align_corners=False)   # VF.resize on tensors (no antialias)
+            x = post.tta_prepare(x, self.mean, self.std, pad_x, pad_y, self.test_flip)
+            out = self(x)[-1]
+            if self.test_flip:
+                out = {"heatmap": post.flip_merge(out["heatmap"]), "width_height": post.flip_merge(out["width_height"]),
+                       "regression": out["regression"][:B].contiguous()}
+            outputs.append(out)
+            meta.append({"scale": [nw / width, nh / height], "padding": [pad_x, pad_y]})
+        return image_id, outputs, meta
+
+    @torch.no_grad()
+    def test_step_end(self, outputs):
+        """centernet_detection.py:173-225 for the batch: decode every scale, then ONE launch maps the boxes back to the
+        image, groups them by class, merges the scales with soft-NMS and keeps the best `test_max_per_image`; one host copy.
+        Returns [(image_id, {class_id: ndarray [n, 5]}), ...] — the reference's per-image result."""
+        image_id, outputs, metas = outputs
+        dets = [self.decode(o) for o in outputs]
+        rows, counts = post.ctdet_merge(dets, metas, self.num_classes, self.down_ratio, self.test_max_per_image)
+        return list(zip(image_id, post.results_by_class(rows, counts, self.num_classes)))

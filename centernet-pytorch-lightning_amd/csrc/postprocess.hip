@@ -1,0 +1,199 @@
+// Test-time augmentation and detection post-processing on the device (soft-NMS of f-4).
+// Reference: CenterNetDetection.test_step / test_step_end (centernet_detection.py:132-225) and utils/nms.py:5-107.  There,
+// every image goes through torchvision pad/normalize/flip on the host side of the step, `.cpu()` per image after decode, a
+// Python loop over 80 classes and numba soft-NMS.  Here: one launch prepares the padded / normalised / mirrored batch, one
+// launch merges the mirrored head maps, and one launch per batch maps the decoded boxes back to image coordinates, groups
+// them by class, runs soft-NMS (multi-scale only) and applies the max-per-image cut — the host receives one tensor per batch.
+#include "common.h"
+#include <math.h>
+
+// out[b] = pad(normalize(img[b])) ; out[B + b] = hflip(out[b]) when flip.  The reference pads with zeros BEFORE normalising
+// (centernet_detection.py:146-151), so the border holds (0 - mean) / std.
+__global__ __launch_bounds__(256) void tta_prepare_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int H, int W,
+                                                          int pad_x, int pad_y, float m0, float m1, float m2, float s0, float s1,
+                                                          float s2, int flip) {
+    const int PH = H + 2 * pad_y, PW = W + 2 * pad_x;
+    const int64_t total = (int64_t)B * 3 * PH * PW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % PW);
+        int64_t r = i / PW;
+        const int y = (int)(r % PH);
+        r /= PH;
+        const int c = (int)(r % 3), b = (int)(r / 3);
+        const int iy = y - pad_y, ix = x - pad_x;
+        const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const float v = in ? img[(((int64_t)b * 3 + c) * H + iy) * W + ix] : 0.f;
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        const float o = (v - mean) / sd;
+        out[i] = o;
+        if (flip) out[((((int64_t)(B + b)) * 3 + c) * PH + y) * PW + (PW - 1 - x)] = o;
+    }
+}
+
+// out[b] = (x[b] + hflip(x[B + b])) / 2 on NCHW fp32 head maps (centernet_detection.py:167-171)
+__global__ __launch_bounds__(256) void flip_merge_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t half, int W) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        out[i] = (x[i] + x[half + i - w + (W - 1 - w)]) / 2.f;
+    }
+}
+
+#define PP_MAXCAND 1024
+#define PP_MAXCLS 256
+
+// utils/nms.py:5-107 verbatim on one class segment (sequential by nature: the array is reordered as it goes).  numba
+// promotes `float32 + 1` to float64, so the overlap arithmetic runs in double and the decayed score is stored as float32.
+__device__ static int soft_nms_segment(float* bx, int N, double sigma, double Nt, double threshold, int method) {
+    const int N0 = N;
+    for (int i = 0; i < N0; ++i) {
+        if (i >= N) break;                                   // (the reference's remaining iterations are no-ops)
+        float maxscore = bx[i * 5 + 4];
+        int maxpos = i;
+        for (int pos = i + 1; pos < N; ++pos)
+            if (maxscore < bx[pos * 5 + 4]) { maxscore = bx[pos * 5 + 4]; maxpos = pos; }
+        for (int q = 0; q < 5; ++q) { const float t = bx[i * 5 + q]; bx[i * 5 + q] = bx[maxpos * 5 + q]; bx[maxpos * 5 + q] = t; }
+        const double tx1 = bx[i * 5], ty1 = bx[i * 5 + 1], tx2 = bx[i * 5 + 2], ty2 = bx[i * 5 + 3];
+        int pos = i + 1;
+        while (pos < N) {
+            const double x1 = bx[pos * 5], y1 = bx[pos * 5 + 1], x2 = bx[pos * 5 + 2], y2 = bx[pos * 5 + 3];
+            const double area = (x2 - x1 + 1) * (y2 - y1 + 1);
+            const double iw = fmin(tx2, x2) - fmax(tx1, x1) + 1;
+            if (iw > 0) {
+                const double ih = fmin(ty2, y2) - fmax(ty1, y1) + 1;
+                if (ih > 0) {
+                    const double ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
+                    const double ov = iw * ih / ua;
+                    double weight;
+                    if (method == 1) weight = ov > Nt ? 1 - ov : 1;
+                    else if (method == 2) weight = exp(-(ov * ov) / sigma);
+                    else weight = ov > Nt ? 0 : 1;
+                    bx[pos * 5 + 4] = (float)(weight * (double)bx[pos * 5 + 4]);
+                    if ((double)bx[pos * 5 + 4] < threshold) {
+                        for (int q = 0; q < 5; ++q) bx[pos * 5 + q] = bx[(N - 1) * 5 + q];
+                        --N;
+                        --pos;
+                    }
+                }
+            }
+            ++pos;
+        }
+    }
+    return N;
+}
+
+// dets [S, B, K, 6] (x1, y1, x2, y2, score, class; output-map coordinates of scale s), meta [S, 4] = pad_x, pad_y, scale_x,
+// scale_y.  One workgroup per image: transform (x down, - pad, / scale in fp32, in that order), group by class (scale-major,
+// rank order inside a scale == np.concatenate of the per-scale class arrays), soft-NMS per class when S > 1, then keep the
+// scores >= the max_per-th largest.  rows [B, S*K, 6] come out class-ascending; counts [B].
+__global__ __launch_bounds__(256) void ctdet_merge_kernel(const float* __restrict__ dets, const float* __restrict__ meta,
+                                                          float* __restrict__ rows, int* __restrict__ counts, int S, int B, int K,
+                                                          int C, float down, int max_per, int nms_method, float nms_nt,
+                                                          float nms_sigma, float nms_thresh) {
+    __shared__ float cand[PP_MAXCAND * 6];
+    __shared__ float seg[PP_MAXCAND * 5];
+    __shared__ int cnt[PP_MAXCLS], off[PP_MAXCLS + 1], keepn[PP_MAXCLS];
+    __shared__ int total_s;
+    const int b = blockIdx.x, tid = threadIdx.x, n = S * K;
+    for (int e = tid; e < n; e += blockDim.x) {
+        const int s = e / K, r = e % K;
+        const float* d = dets + (((int64_t)s * B + b) * K + r) * 6;
+        const float px = meta[s * 4], py = meta[s * 4 + 1], sx = meta[s * 4 + 2], sy = meta[s * 4 + 3];
+        cand[e * 6 + 0] = (d[0] * down - px) / sx;
+        cand[e * 6 + 1] = (d[1] * down - py) / sy;
+        cand[e * 6 + 2] = (d[2] * down - px) / sx;
+        cand[e * 6 + 3] = (d[3] * down - py) / sy;
+        cand[e * 6 + 4] = d[4];
+        cand[e * 6 + 5] = d[5];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        int m = 0;
+        for (int e = 0; e < n; ++e) m += (cand[e * 6 + 5] == (float)c);
+        cnt[c] = m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0;
+        for (int c = 0; c < C; ++c) { off[c] = a; a += cnt[c]; }
+        off[C] = a;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        float* bx = seg + off[c] * 5;
+        int m = 0;
+        for (int e = 0; e < n; ++e)
+            if (cand[e * 6 + 5] == (float)c) {
+                for (int q = 0; q < 5; ++q) bx[m * 5 + q] = cand[e * 6 + q];
+                ++m;
+            }
+        keepn[c] = (S > 1 && m > 0) ? soft_nms_segment(bx, m, (double)nms_sigma, (double)nms_nt, (double)nms_thresh, nms_method) : m;
+    }
+    __syncthreads();
+    if (tid == 0) {                                          // compact the kept prefix of every class segment into cand
+        int a = 0;
+        for (int c = 0; c < C; ++c) {
+            for (int i = 0; i < keepn[c]; ++i, ++a) {
+                for (int q = 0; q < 5; ++q) cand[a * 6 + q] = seg[(off[c] + i) * 5 + q];
+                cand[a * 6 + 5] = (float)c;
+            }
+        }
+        total_s = a;
+    }
+    __syncthreads();
+    const int total = total_s;
+    // keep score >= the max_per-th largest  <=>  fewer than max_per scores are strictly greater (centernet_detection.py:217-223)
+    for (int e = tid; e < total; e += blockDim.x) {
+        int g = 0;
+        if (total > max_per) {
+            const float s = cand[e * 6 + 4];
+            for (int j = 0; j < total; ++j) g += (cand[j * 6 + 4] > s);
+        }
+        seg[e] = (g < max_per) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0;
+        float* out = rows + (int64_t)b * n * 6;
+        for (int e = 0; e < total; ++e)
+            if (seg[e] != 0.f) {
+                for (int q = 0; q < 6; ++q) out[a * 6 + q] = cand[e * 6 + q];
+                ++a;
+            }
+        counts[b] = a;
+        for (int e = a * 6; e < n * 6; ++e) out[e] = 0.f;
+    }
+}
+
+static int pp_grid(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+extern "C" int cn_tta_prepare(const float* img, float* out, int B, int H, int W, int pad_x, int pad_y, float mean0, float mean1,
+                              float mean2, float std0, float std1, float std2, int flip, void* stream) {
+    CN_CHECK_ARG(img && out && B > 0 && H > 0 && W > 0 && pad_x >= 0 && pad_y >= 0, "cn_tta_prepare: bad args");
+    const int64_t total = (int64_t)B * 3 * (H + 2 * pad_y) * (W + 2 * pad_x);
+    hipLaunchKernelGGL(tta_prepare_kernel, dim3(pp_grid(total)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, pad_x, pad_y,
+                       mean0, mean1, mean2, std0, std1, std2, flip);
+    CN_LAUNCH_CHECK("cn_tta_prepare");
+    return CN_OK;
+}
+
+extern "C" int cn_flip_merge(const float* x, float* out, int B, int C, int H, int W, void* stream) {
+    CN_CHECK_ARG(x && out && B > 0 && C > 0 && H > 0 && W > 0, "cn_flip_merge: bad args");
+    const int64_t half = (int64_t)B * C * H * W;
+    hipLaunchKernelGGL(flip_merge_kernel, dim3(pp_grid(half)), dim3(256), 0, (hipStream_t)stream, x, out, half, W);
+    CN_LAUNCH_CHECK("cn_flip_merge");
+    return CN_OK;
+}
+
+extern "C" int cn_ctdet_merge(const float* dets, const float* meta, float* rows, int* counts, int S, int B, int K, int C,
+                              int down_ratio, int max_per_image, int nms_method, float nms_nt, float nms_sigma, float nms_threshold,
+                              void* stream) {
+    CN_CHECK_ARG(dets && meta && rows && counts && S > 0 && B > 0 && K > 0 && C > 0 && max_per_image > 0, "cn_ctdet_merge: bad args");
+    if (S * K > PP_MAXCAND || C > PP_MAXCLS) CN_UNSUPPORTED("cn_ctdet_merge: S*K <= %d and C <= %d (got %d, %d)", PP_MAXCAND, PP_MAXCLS, S * K, C);
+    hipLaunchKernelGGL(ctdet_merge_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dets, meta, rows, counts, S, B, K, C,
+                       (float)down_ratio, max_per_image, nms_method, nms_nt, nms_sigma, nms_threshold);
+    CN_LAUNCH_CHECK("cn_ctdet_merge");
+    return CN_OK;
+}

@@ -222,6 +222,21 @@ int cn_encode_multi_pose(const float* boxes, const float* keypoints, const int* 
                          float* kp_out, unsigned char* kp_mask, float* hp_offset, int64_t* hp_indices,
                          unsigned char* hp_mask, int B, int M, int J, int OH, int OW, int down_ratio, void* stream);
 
+/* ---- test-time augmentation + detection post-processing (centernet_detection.py:132-225, utils/nms.py:5-107) ---------- */
+/* test_step :139-158 for a batch: out[b] = pad(normalize(img[b])) with zero padding BEFORE the normalisation, and, when
+ * flip, out[B+b] = hflip(out[b]).  img fp32 [B,3,H,W] (already resized for scales != 1), out fp32 [B*(1+flip),3,H+2pad_y,W+2pad_x]. */
+int cn_tta_prepare(const float* img, float* out, int B, int H, int W, int pad_x, int pad_y, float mean0, float mean1,
+                   float mean2, float std0, float std1, float std2, int flip, void* stream);
+/* test_step :167-171: out[B,C,H,W] = (x[0:B] + hflip(x[B:2B])) / 2 on NCHW fp32 head maps. */
+int cn_flip_merge(const float* x, float* out, int B, int C, int H, int W, void* stream);
+/* test_step_end :173-225 for a batch: dets fp32 [S,B,K,6] (ctdet_decode output per test scale), meta fp32 [S,4] =
+ * (pad_x, pad_y, scale_x, scale_y).  Boxes * down_ratio - pad, / scale; grouped by class; soft_nms(Nt, method) per class
+ * when S > 1 (utils/nms.py, arithmetic in double as under numba); then only scores >= the max_per_image-th largest stay.
+ * rows fp32 [B,S*K,6] class-ascending (x1,y1,x2,y2,score,class), zero padded; counts int32 [B].  S*K <= 1024, C <= 256. */
+int cn_ctdet_merge(const float* dets, const float* meta, float* rows, int* counts, int S, int B, int K, int C,
+                   int down_ratio, int max_per_image, int nms_method, float nms_nt, float nms_sigma, float nms_threshold,
+                   void* stream);
+
 /* ---- decode (utils/decode.py, decode/ctdet.py, decode/multi_pose.py) -------------------------- */
 /* keep[b,c,h,w] = heat * (maxpool3x3(heat) == heat)   (utils/decode.py:5-10) */
 int cn_nms3x3(const float* heat, float* out, int B, int C, int H, int W, void* stream);

@@ -1,0 +1,99 @@
+"""ORACLE (test infrastructure): CPU restatement of the reference's test-time augmentation and detection post-processing.
+
+Follows CenterNetDetection.test_step / test_step_end (centernet_detection.py:132-225) and utils/nms.py:5-107 (soft_nms).
+PARITY UNPINNED for this file: the LightningModule cannot be imported here (pytorch_lightning / torchvision / pycocotools
+absent) and utils/nms.py needs numba, so no golden vectors exist; the restatement is checked by known-answer tests
+(tests/test_oracle_golden.py) and the HIP path is compared against it.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def tta_pad(size, padding):
+    """centernet_detection.py:143-144."""
+    return ((size | padding) + 1 - size) // 2
+
+
+def tta_prepare(img, mean, std, pad_x, pad_y, flip):
+    """centernet_detection.py:146-154: F.pad (zeros) -> VF.normalize -> cat with VF.hflip.  img fp32 [B,3,H,W]."""
+    x = F.pad(img, (pad_x, pad_x, pad_y, pad_y))
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    x = (x - m) / s
+    return torch.cat([x, x.flip(-1)]) if flip else x
+
+
+def flip_merge(x):
+    """centernet_detection.py:167-171 for B images: rows [B:] are the mirrored passes."""
+    B = x.shape[0] // 2
+    return (x[:B] + x[B:].flip(-1)) / 2
+
+
+def soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """utils/nms.py:5-107, statement by statement.  `boxes` float32 [N,5], modified in place; returns the kept prefix length.
+    numba types `float32 + 1` as float64, so the overlap arithmetic is carried in Python floats (double) here."""
+    N = boxes.shape[0]
+    for i in range(N):
+        maxscore, maxpos = boxes[i, 4], i
+        t = boxes[i].copy()
+        pos = i + 1
+        while pos < N:
+            if maxscore < boxes[pos, 4]:
+                maxscore, maxpos = boxes[pos, 4], pos
+            pos += 1
+        boxes[i] = boxes[maxpos]
+        boxes[maxpos] = t
+        tx1, ty1, tx2, ty2 = (float(v) for v in boxes[i, :4])
+        pos = i + 1
+        while pos < N:
+            x1, y1, x2, y2 = (float(v) for v in boxes[pos, :4])
+            area = (x2 - x1 + 1) * (y2 - y1 + 1)
+            iw = min(tx2, x2) - max(tx1, x1) + 1
+            if iw > 0:
+                ih = min(ty2, y2) - max(ty1, y1) + 1
+                if ih > 0:
+                    ua = float((tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih)
+                    ov = iw * ih / ua
+                    if method == 1:
+                        weight = 1 - ov if ov > Nt else 1
+                    elif method == 2:
+                        weight = np.exp(-(ov * ov) / sigma)
+                    else:
+                        weight = 0 if ov > Nt else 1
+                    boxes[pos, 4] = weight * float(boxes[pos, 4])
+                    if boxes[pos, 4] < threshold:
+                        boxes[pos] = boxes[N - 1]
+                        N -= 1
+                        pos -= 1
+            pos += 1
+    return N
+
+
+def test_step_end(dets, metas, num_classes, down_ratio=4, max_per_image=100, multi_scale=None):
+    """centernet_detection.py:173-225 for ONE image.  dets: list over scales of float32 [K,6] decode outputs; metas as the
+    reference builds them.  Returns {class_id (1-based): ndarray [n,5]}."""
+    multi_scale = len(dets) > 1 if multi_scale is None else multi_scale
+    per_scale = []
+    for det, meta in zip(dets, metas):
+        det = torch.as_tensor(det, dtype=torch.float32).clone()
+        padding = torch.tensor(meta["padding"] + meta["padding"], dtype=torch.float32)
+        scale = torch.tensor(meta["scale"] + meta["scale"], dtype=torch.float32)
+        det[:, :4] *= down_ratio
+        det[:, :4] -= padding
+        det[:, :4] /= scale
+        classes = det[:, -1]
+        per_scale.append({j + 1: det[classes == j, :5].numpy().reshape(-1, 5) for j in range(num_classes)})
+    results = {}
+    for j in range(1, num_classes + 1):
+        results[j] = np.concatenate([d[j] for d in per_scale], axis=0)
+        if multi_scale:
+            n = soft_nms(results[j], Nt=0.5, method=2)
+            results[j] = results[j][:n]
+    scores = np.hstack([results[j][:, 4] for j in range(1, num_classes + 1)])
+    if len(scores) > max_per_image:
+        kth = len(scores) - max_per_image
+        thresh = np.partition(scores, kth)[kth]
+        for j in range(1, num_classes + 1):
+            results[j] = results[j][results[j][:, 4] >= thresh]
+    return results

@@ -1,0 +1,105 @@
+"""GPU: test-time augmentation + detection post-processing (soft-NMS of f-4) through the C ABI against the
+oracle restatement of centernet_detection.py:132-225 / utils/nms.py (oracle/post_ref.py — parity unpinned, see its header)."""
+import numpy as np
+import pytest
+import torch
+
+from centernet_amd import rng, synth
+from oracle import post_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+MEAN, STD = [0.408, 0.447, 0.470], [0.289, 0.274, 0.278]
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 96, 16, 0, True), (1, 50, 38, 7, 13, True), (3, 32, 32, 0, 0, False)])
+def test_tta_prepare_bit_exact(cfg):
+    from centernet_amd.utils import post
+    B, H, W, px, py, flip = cfg
+    img = rng.t_uniform(7, f"img{cfg}", (B, 3, H, W))
+    ref = post_ref.tta_prepare(img, MEAN, STD, px, py, flip)
+    got = post.tta_prepare(img.to(DEV), MEAN, STD, px, py, flip).cpu()
+    assert got.shape == ref.shape and torch.equal(got, ref)
+
+
+def test_flip_merge_bit_exact():
+    from centernet_amd.utils import post
+    x = rng.t_normal(8, "maps", (6, 5, 12, 20))
+    assert torch.equal(post.flip_merge(x.to(DEV)).cpu(), post_ref.flip_merge(x))
+
+
+def _random_dets(seed, S, B, K, C, clustered):
+    """decode-like outputs: scores descending per (scale, image); `clustered` puts boxes of a class on top of each other."""
+    d = np.zeros((S, B, K, 6), np.float32)
+    for s in range(S):
+        for b in range(B):
+            u = rng.uniform(seed, f"d{s}_{b}", (K, 6))
+            cls = np.floor(u[:, 5] * C)
+            if clustered:
+                cx, cy = 20 + 90 * (cls % 5) / 5 + 3 * u[:, 0], 20 + 90 * (cls // 5 % 5) / 5 + 3 * u[:, 1]
+            else:
+                cx, cy = 128 * u[:, 0], 128 * u[:, 1]
+            w, h = 4 + 30 * u[:, 2], 4 + 30 * u[:, 3]
+            d[s, b, :, 0], d[s, b, :, 1], d[s, b, :, 2], d[s, b, :, 3] = cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2
+            d[s, b, :, 4] = np.sort(u[:, 4])[::-1] * (0.2 if clustered and s == 1 else 1.0)
+            d[s, b, :, 5] = cls
+    return d
+
+
+@pytest.mark.parametrize("S,C,clustered", [(1, 80, False), (3, 80, True), (2, 3, True), (5, 80, False)])
+def test_ctdet_merge_matches_restatement(S, C, clustered):
+    """boxes back to image coordinates, class grouping, multi-scale soft-NMS (gaussian, Nt 0.5), max-per-image cut."""
+    from centernet_amd.utils import post
+    B, K = 3, 100
+    d = _random_dets(11 + S, S, B, K, C, clustered)
+    scales = [1.0, 0.75, 1.25, 0.5, 1.5][:S]
+    metas = [{"scale": [int(512 * sc) / 512, int(500 * sc) / 500], "padding": [post_ref.tta_pad(int(512 * sc), 31), post_ref.tta_pad(int(500 * sc), 31)]}
+             for sc in scales]
+    rows, counts = post.ctdet_merge([torch.from_numpy(d[s]).to(DEV) for s in range(S)], metas, C)
+    got = post.results_by_class(rows, counts, C)
+    for b in range(B):
+        ref = post_ref.test_step_end([d[s, b] for s in range(S)], metas, C)
+        assert set(got[b]) == set(ref)
+        n_ref = sum(len(v) for v in ref.values())
+        assert int(counts[b]) == n_ref
+        for j in ref:
+            assert got[b][j].shape == ref[j].shape, (b, j)
+            assert np.array_equal(got[b][j][:, :4], ref[j][:, :4]), "same boxes in the same (soft-NMS selection) order"
+            np.testing.assert_allclose(got[b][j][:, 4], ref[j][:, 4], rtol=2e-7, atol=0)     # exp() in double, stored fp32
+    if S > 1 and clustered:
+        raw = set(np.float32(v) for v in d[:, 0, :, 4].flatten())
+        decayed = sum(int(np.float32(v) not in raw) for r in got[0].values() for v in r[:, 4])
+        assert decayed > 10, "soft-NMS decayed the scores of overlapping boxes"
+
+
+def test_test_step_flip_tta_end_to_end():
+    """CenterNetDetection.test_step + test_step_end on a batch (flip TTA, 2 scales) against the restated pipeline run on the
+    same network: prepared images, merged head maps, and the per-class results."""
+    from centernet_amd.centernet_detection import CenterNetDetection
+    m = CenterNetDetection("res_18", compute_dtype=torch.float32, test_flip=True, test_scales=[1, 0.75])
+    rng.fill_state_dict(m, 98)
+    m = m.to(DEV).eval()
+    img = rng.t_uniform(98, "img", (2, 3, 128, 160)).to(DEV)
+    ids, outs, metas = m.test_step((img, None), 3)
+    assert ids == [6, 7] and len(outs) == 2
+    assert metas[0] == {"scale": [1.0, 1.0], "padding": [16, 16]} and metas[1]["padding"] == [4, 16]
+    # the same pipeline from the restatement's pieces (forward on the device network)
+    for s_, scale in enumerate([1, 0.75]):
+        nh, nw = int(128 * scale), int(160 * scale)
+        x = img.cpu() if scale == 1 else torch.nn.functional.interpolate(img.cpu(), size=(nh, nw), mode="bilinear", align_corners=False)
+        px, py = post_ref.tta_pad(nw, 31), post_ref.tta_pad(nh, 31)
+        xin = post_ref.tta_prepare(x, MEAN, STD, px, py, True)
+        with torch.no_grad():
+            o = m(xin.to(DEV))[-1]
+        hm = post_ref.flip_merge(o["heatmap"].cpu())
+        assert torch.allclose(outs[s_]["heatmap"].cpu(), hm, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(outs[s_]["regression"].cpu(), o["regression"][:2].cpu(), rtol=1e-4, atol=1e-5)
+    dets = [m.decode({k: v.clone() for k, v in o.items()}).cpu().numpy() for o in outs]
+    res = m.test_step_end((ids, outs, metas))
+    assert [r[0] for r in res] == ids
+    for b in range(2):
+        ref = post_ref.test_step_end([d[b] for d in dets], metas, 80)
+        for j in ref:
+            assert res[b][1][j].shape == ref[j].shape
+            np.testing.assert_allclose(res[b][1][j], ref[j], rtol=1e-5, atol=1e-5)
+        assert sum(len(v) for v in res[b][1].values()) >= 100

@@ -187,3 +187,39 @@ def test_pose_encoder_matches_reference_fixture(golden):
         assert np.array_equal(hk[nz], g[f"hm_nz_val{i}"])
         for k in ("keypoints", "keypoints_mask", "heatmap_keypoints_offset", "heatmap_keypoints_indices", "heatmap_keypoints_mask"):
             assert np.array_equal(T[k], g[f"{k}{i}"]), (i, k)
+
+
+def test_soft_nms_restatement_known_answers():
+    """utils/nms.py has no golden here (numba absent): hand-checkable cases of the restatement the HIP kernel is held to."""
+    from oracle import post_ref
+    # identical boxes: the second is decayed by exp(-1^2 / 0.5); a disjoint box is untouched; output sorted by final score
+    b = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 9, 0.8], [100, 100, 109, 109, 0.85]], np.float32)
+    n = post_ref.soft_nms(b, Nt=0.5, method=2)
+    assert n == 3 and np.array_equal(b[:, 4] > 0, [True, True, True])
+    assert b[0, 4] == np.float32(0.9) and b[1, 4] == np.float32(0.85)
+    assert b[2, 4] == pytest.approx(0.8 * np.exp(-2.0), rel=1e-6)
+    # hard NMS (method 0) zeroes an overlapping box, which then falls below the threshold and is dropped
+    b = np.array([[0, 0, 9, 9, 0.9], [1, 1, 10, 10, 0.8], [50, 50, 59, 59, 0.3]], np.float32)
+    n = post_ref.soft_nms(b, Nt=0.3, method=0)
+    assert n == 2 and sorted(b[:n, 4].tolist()) == [pytest.approx(0.3), pytest.approx(0.9)]
+    # IoU of the +1-pixel convention: boxes [0,0,9,9] and [5,0,14,9] overlap 5x10 of 150
+    b = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float32)
+    post_ref.soft_nms(b, Nt=0.5, method=1)
+    assert b[1, 4] == pytest.approx(0.8)             # ov = 1/3 <= Nt: weight 1
+    b = np.array([[0, 0, 9, 9, 0.9], [5, 0, 14, 9, 0.8]], np.float32)
+    post_ref.soft_nms(b, method=2)
+    assert b[1, 4] == pytest.approx(0.8 * np.exp(-(1 / 3) ** 2 / 0.5), rel=1e-6)
+
+
+def test_test_step_end_restatement_single_scale_is_a_regrouping():
+    """Single scale: no NMS, K = 100 = test_max_per_image, so test_step_end only rescales and regroups (centernet_detection.py:189-223)."""
+    from oracle import post_ref
+    det = np.zeros((100, 6), np.float32)
+    det[:, :4] = rng.uniform(3, "boxes", (100, 4)) * 128
+    det[:, 4] = np.sort(rng.uniform(3, "sc", (100,)))[::-1]
+    det[:, 5] = np.floor(rng.uniform(3, "cls", (100,)) * 80)
+    res = post_ref.test_step_end([det], [{"scale": [1.0, 1.0], "padding": [16, 16]}], 80)
+    assert sum(len(v) for v in res.values()) == 100
+    j = int(det[0, 5]) + 1
+    np.testing.assert_allclose(res[j][0, :4], det[0, :4] * 4 - 16, rtol=1e-6)
+    assert post_ref.tta_pad(512, 31) == 16 and post_ref.tta_pad(512, 127) == 64 and post_ref.tta_pad(500, 31) == 6
