@@ -1,11 +1,13 @@
-"""`CenterNetMultiPose` (reference: CenterNet/centernet_multi_pose.py:29-321) — forward / loss / decode on the HIP path."""
+"""`CenterNetMultiPose` (reference: CenterNet/centernet_multi_pose.py:29-321) — forward / loss / decode / test step on the HIP path."""
 import torch
+import torch.nn.functional as F
 
 from .centernet import CenterNet
 from .decode.multi_pose import multi_pose_decode
 from .models.heads import CenterHead
 from .utils.decode import sigmoid_clamped
 from .utils.losses import FocalLoss, RegL1Loss, RegWeightedL1Loss
+from .utils import post
 
 
 class CenterNetMultiPose(CenterNet):
@@ -65,3 +67,51 @@ class CenterNetMultiPose(CenterNet):
         return multi_pose_decode(output["heatmap"].sigmoid_(), output["width_height"], output["keypoints"],
                                  reg=output["regression"], hm_hp=output["heatmap_keypoints"].sigmoid_(),
                                  hp_offset=output["heatmap_keypoints_offset"], K=K)
+
+    def _flip_tables(self, device):
+        """perm / sign vectors of the two pose-aware merges (centernet_multi_pose.py:203-210), cached on the device."""
+        key = str(device)
+        if getattr(self, "_flip_cache", None) is None or self._flip_cache[0] != key:
+            idx = torch.tensor(self.flip_idx, dtype=torch.int32)
+            kp_perm = torch.stack([2 * idx, 2 * idx + 1], 1).flatten()                 # channel 2j+xy <- 2*flip_idx[j]+xy
+            kp_sign = torch.tensor([-1.0, 1.0]).repeat(len(self.flip_idx))             # x components are negated
+            self._flip_cache = (key, kp_perm.to(device), kp_sign.to(device), idx.to(device),
+                                torch.ones(len(self.flip_idx), device=device))
+        return self._flip_cache[1:]
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx):
+        """centernet_multi_pose.py:157-213 for a BATCH of images in [0, 1]: per scale pad / normalise / mirror in one launch,
+        forward, then the mirrored maps folded back — box maps averaged, keypoint maps with the left/right joint swap."""
+        img, _ = batch
+        B = img.shape[0]
+        image_id = ([self.test_coco_ids[batch_idx * B + i] for i in range(B)] if self.test_coco_ids
+                    else [batch_idx * B + i for i in range(B)])
+        outputs, meta = [], []
+        for scale in self.test_scales:
+            _, _, height, width = img.shape
+            nh, nw = int(height * scale), int(width * scale)
+            pad_y, pad_x = post.tta_pad(nh, self.padding), post.tta_pad(nw, self.padding)
+            x = img if (nh, nw) == (height, width) else F.interpolate(img.float(), size=(nh, nw), mode="bilinear", align_corners=False)
+            x = post.tta_prepare(x, self.mean, self.std, pad_x, pad_y, self.test_flip)
+            out = self(x)[-1]
+            if self.test_flip:
+                kp_perm, kp_sign, hm_perm, hm_sign = self._flip_tables(x.device)
+                out = {"heatmap": post.flip_merge(out["heatmap"]), "width_height": post.flip_merge(out["width_height"]),
+                       "regression": out["regression"][:B].contiguous(),
+                       "keypoints": post.flip_merge_perm(out["keypoints"], kp_perm, kp_sign),
+                       "heatmap_keypoints": post.flip_merge_perm(out["heatmap_keypoints"], hm_perm, hm_sign),
+                       "heatmap_keypoints_offset": out["heatmap_keypoints_offset"][:B].contiguous()}
+            outputs.append(out)
+            meta.append({"scale": [nw / width, nh / height], "padding": [pad_x, pad_y]})
+        return image_id, outputs, meta
+
+    @torch.no_grad()
+    def test_step_end(self, outputs):
+        """centernet_multi_pose.py:213-264 for the batch: decode per scale, ONE launch for rescaling / soft_nms_39 / the
+        max-per-image cut, one host copy.  Returns [(image_id, rows as nested lists [n][57]), ...]."""
+        image_id, outputs, metas = outputs
+        dets = [self.decode(o) for o in outputs]
+        rows, counts = post.pose_merge(dets, metas, self.down_ratio, self.test_max_per_image)
+        rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
+        return [(i, rows[b, :counts[b]].tolist()) for b, i in enumerate(image_id)]

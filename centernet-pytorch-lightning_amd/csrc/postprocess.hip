@@ -164,6 +164,125 @@ __global__ __launch_bounds__(256) void ctdet_merge_kernel(const float* __restric
     }
 }
 
+// out[b, c] = (x[b, c] + sign[c] * hflip(x[B + b, perm[c]])) / 2 — the pose-aware merges of centernet_multi_pose.py:200-211:
+// keypoint regression maps swap left/right joints (flip_idx) and negate the x component, keypoint heat maps only swap.
+__global__ __launch_bounds__(256) void flip_merge_perm_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                              const int* __restrict__ perm, const float* __restrict__ sign, int B,
+                                                              int C, int H, int W) {
+    const int64_t half = (int64_t)B * C * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        int64_t r = i / W;
+        const int h = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const float f = x[((((int64_t)(B + b)) * C + perm[c]) * H + h) * W + (W - 1 - w)] * sign[c];
+        out[i] = (x[i] + f) / 2.f;
+    }
+}
+
+#define PP_POSE_MAXROWS 1024
+// utils/nms.py:109-206 (soft_nms_39) on LDS-resident box columns; the keypoint columns 5..38 travel with the boxes through
+// the index list `pay`, columns 39.. (class, keypoint scores) are NOT moved by the reference and stay with their position.
+__device__ static int soft_nms39_lds(float* bx, int* pay, int N, double sigma, double Nt, double threshold, int method) {
+    const int N0 = N;
+    for (int i = 0; i < N0 && i < N; ++i) {
+        float maxscore = bx[i * 5 + 4];
+        int maxpos = i;
+        for (int pos = i + 1; pos < N; ++pos)
+            if (maxscore < bx[pos * 5 + 4]) { maxscore = bx[pos * 5 + 4]; maxpos = pos; }
+        for (int q = 0; q < 5; ++q) { const float t = bx[i * 5 + q]; bx[i * 5 + q] = bx[maxpos * 5 + q]; bx[maxpos * 5 + q] = t; }
+        { const int t = pay[i]; pay[i] = pay[maxpos]; pay[maxpos] = t; }
+        const double tx1 = bx[i * 5], ty1 = bx[i * 5 + 1], tx2 = bx[i * 5 + 2], ty2 = bx[i * 5 + 3];
+        int pos = i + 1;
+        while (pos < N) {
+            const double x1 = bx[pos * 5], y1 = bx[pos * 5 + 1], x2 = bx[pos * 5 + 2], y2 = bx[pos * 5 + 3];
+            const double area = (x2 - x1 + 1) * (y2 - y1 + 1);
+            const double iw = fmin(tx2, x2) - fmax(tx1, x1) + 1;
+            if (iw > 0) {
+                const double ih = fmin(ty2, y2) - fmax(ty1, y1) + 1;
+                if (ih > 0) {
+                    const double ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih;
+                    const double ov = iw * ih / ua;
+                    double weight;
+                    if (method == 1) weight = ov > Nt ? 1 - ov : 1;
+                    else if (method == 2) weight = exp(-(ov * ov) / sigma);
+                    else weight = ov > Nt ? 0 : 1;
+                    bx[pos * 5 + 4] = (float)(weight * (double)bx[pos * 5 + 4]);
+                    if ((double)bx[pos * 5 + 4] < threshold) {
+                        for (int q = 0; q < 5; ++q) bx[pos * 5 + q] = bx[(N - 1) * 5 + q];      // copied (:190-194) ...
+                        { const int t = pay[pos]; pay[pos] = pay[N - 1]; pay[N - 1] = t; }       // ... swapped (:195-198)
+                        --N;
+                        --pos;
+                    }
+                }
+            }
+            ++pos;
+        }
+    }
+    return N;
+}
+
+// dets [S, B, K, D] rows of multi_pose_decode (D = 57: box 4, score, 34 keypoint coords, class, 17 keypoint scores); meta as
+// above.  One workgroup per image: boxes and keypoints to image coordinates, scales concatenated, soft_nms_39 when S > 1,
+// then scores >= the max_per-th largest.  rows [B, S*K, D] zero padded, counts [B].  (centernet_multi_pose.py:213-264)
+__global__ __launch_bounds__(256) void pose_merge_kernel(const float* __restrict__ dets, const float* __restrict__ meta,
+                                                         float* __restrict__ rows, int* __restrict__ counts, int S, int B, int K, int D,
+                                                         float down, int max_per, int nms_method, float nms_nt, float nms_sigma,
+                                                         float nms_thresh) {
+    __shared__ float bx[PP_POSE_MAXROWS * 5];
+    __shared__ int pay[PP_POSE_MAXROWS], dst[PP_POSE_MAXROWS];
+    __shared__ int n_s, kept_s;
+    const int b = blockIdx.x, tid = threadIdx.x, n = S * K;
+    auto src_row = [&](int e) { return dets + (((int64_t)(e / K) * B + b) * K + (e % K)) * D; };
+    for (int e = tid; e < n; e += blockDim.x) {
+        const int s = e / K;
+        const float* d = src_row(e);
+        const float px = meta[s * 4], py = meta[s * 4 + 1], sx = meta[s * 4 + 2], sy = meta[s * 4 + 3];
+        bx[e * 5 + 0] = (d[0] * down - px) / sx;
+        bx[e * 5 + 1] = (d[1] * down - py) / sy;
+        bx[e * 5 + 2] = (d[2] * down - px) / sx;
+        bx[e * 5 + 3] = (d[3] * down - py) / sy;
+        bx[e * 5 + 4] = d[4];
+        pay[e] = e;
+    }
+    __syncthreads();
+    if (tid == 0) n_s = S > 1 ? soft_nms39_lds(bx, pay, n, (double)nms_sigma, (double)nms_nt, (double)nms_thresh, nms_method) : n;
+    __syncthreads();
+    const int total = n_s;
+    for (int e = tid; e < total; e += blockDim.x) {
+        int g = 0;
+        if (total > max_per) {
+            const float sc = bx[e * 5 + 4];
+            for (int j = 0; j < total; ++j) g += (bx[j * 5 + 4] > sc);
+        }
+        dst[e] = g < max_per ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0;
+        for (int e = 0; e < total; ++e) dst[e] = dst[e] ? a++ : -1;
+        kept_s = a;
+        counts[b] = a;
+    }
+    __syncthreads();
+    const int kept = kept_s;
+    float* out = rows + (int64_t)b * n * D;
+    for (int i = tid; i < total * D; i += blockDim.x) {
+        const int e = i / D, q = i % D;
+        if (dst[e] < 0) continue;
+        float v;
+        if (q < 5) v = bx[e * 5 + q];
+        else if (q < 39) {                                   // keypoints travelled with the box: take them from row pay[e]
+            const int o = pay[e], s = o / K;
+            const float pad = (q - 5) & 1 ? meta[s * 4 + 1] : meta[s * 4], sc = (q - 5) & 1 ? meta[s * 4 + 3] : meta[s * 4 + 2];
+            v = (src_row(o)[q] * down - pad) / sc;
+        } else v = src_row(e)[q];                            // class / keypoint scores stay at their position (reference quirk)
+        out[(int64_t)dst[e] * D + q] = v;
+    }
+    for (int i = kept * D + tid; i < n * D; i += blockDim.x) out[i] = 0.f;
+}
+
 static int pp_grid(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -195,5 +314,25 @@ extern "C" int cn_ctdet_merge(const float* dets, const float* meta, float* rows,
     hipLaunchKernelGGL(ctdet_merge_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dets, meta, rows, counts, S, B, K, C,
                        (float)down_ratio, max_per_image, nms_method, nms_nt, nms_sigma, nms_threshold);
     CN_LAUNCH_CHECK("cn_ctdet_merge");
+    return CN_OK;
+}
+
+extern "C" int cn_flip_merge_perm(const float* x, float* out, const int* perm, const float* sign, int B, int C, int H, int W,
+                                  void* stream) {
+    CN_CHECK_ARG(x && out && perm && sign && B > 0 && C > 0 && H > 0 && W > 0, "cn_flip_merge_perm: bad args");
+    hipLaunchKernelGGL(flip_merge_perm_kernel, dim3(pp_grid((int64_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream, x, out, perm,
+                       sign, B, C, H, W);
+    CN_LAUNCH_CHECK("cn_flip_merge_perm");
+    return CN_OK;
+}
+
+extern "C" int cn_pose_merge(const float* dets, const float* meta, float* rows, int* counts, int S, int B, int K, int D,
+                             int down_ratio, int max_per_image, int nms_method, float nms_nt, float nms_sigma, float nms_threshold,
+                             void* stream) {
+    CN_CHECK_ARG(dets && meta && rows && counts && S > 0 && B > 0 && K > 0 && D >= 39 && max_per_image > 0, "cn_pose_merge: bad args");
+    if (S * K > PP_POSE_MAXROWS) CN_UNSUPPORTED("cn_pose_merge: S*K <= %d (got %d)", PP_POSE_MAXROWS, S * K);
+    hipLaunchKernelGGL(pose_merge_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dets, meta, rows, counts, S, B, K, D,
+                       (float)down_ratio, max_per_image, nms_method, nms_nt, nms_sigma, nms_threshold);
+    CN_LAUNCH_CHECK("cn_pose_merge");
     return CN_OK;
 }

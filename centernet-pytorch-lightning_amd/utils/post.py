@@ -34,6 +34,28 @@ def flip_merge(x):
     return out
 
 
+def flip_merge_perm(x, perm, sign):
+    """x fp32 [2B,C,H,W] -> (x[:B] + sign[c] * hflip(x[B:, perm[c]])) / 2 (pose-aware merges, centernet_multi_pose.py:200-211)."""
+    B2, C, H, W = x.shape
+    out = torch.empty((B2 // 2, C, H, W), dtype=torch.float32, device=x.device)
+    call("cn_flip_merge_perm", x.contiguous(), out, perm, sign, B2 // 2, C, H, W)
+    return out
+
+
+def pose_merge(dets, metas, down_ratio=4, max_per_image=20, nms_method=2, nms_nt=0.5, nms_sigma=0.5, nms_threshold=0.001):
+    """dets: list (one per test scale) of multi_pose_decode outputs [B,K,57] -> rows fp32 [B, S*K, 57], counts int32 [B]."""
+    S = len(dets)
+    B, K, D = dets[0].shape
+    d = torch.stack([t.float() for t in dets]).contiguous()
+    meta = torch.tensor([[m["padding"][0], m["padding"][1], m["scale"][0], m["scale"][1]] for m in metas], dtype=torch.float32,
+                        device=d.device)
+    rows = torch.empty((B, S * K, D), dtype=torch.float32, device=d.device)
+    counts = torch.empty((B,), dtype=torch.int32, device=d.device)
+    call("cn_pose_merge", d, meta, rows, counts, S, B, K, D, int(down_ratio), int(max_per_image), int(nms_method), float(nms_nt),
+         float(nms_sigma), float(nms_threshold))
+    return rows, counts
+
+
 def ctdet_merge(dets, metas, num_classes, down_ratio=4, max_per_image=100, nms_method=2, nms_nt=0.5, nms_sigma=0.5,
                 nms_threshold=0.001):
     """dets: list (one per test scale) of ctdet_decode outputs [B,K,6]; metas: list of {"scale": [sx, sy], "padding": [px, py]}.

@@ -236,6 +236,17 @@ int cn_flip_merge(const float* x, float* out, int B, int C, int H, int W, void* 
 int cn_ctdet_merge(const float* dets, const float* meta, float* rows, int* counts, int S, int B, int K, int C,
                    int down_ratio, int max_per_image, int nms_method, float nms_nt, float nms_sigma, float nms_threshold,
                    void* stream);
+/* Pose-aware mirror merge (centernet_multi_pose.py:200-211): out[b,c] = (x[b,c] + sign[c] * hflip(x[B+b, perm[c]])) / 2;
+ * perm int32 [C] and sign fp32 [C] on the device (keypoints: flip_idx per joint, -1 on x components; heat maps: flip_idx, +1). */
+int cn_flip_merge_perm(const float* x, float* out, const int* perm, const float* sign, int B, int C, int H, int W,
+                       void* stream);
+/* CenterNetMultiPose.test_step_end (centernet_multi_pose.py:213-264) for a batch: dets fp32 [S,B,K,D] rows of
+ * multi_pose_decode (D = 57), meta as cn_ctdet_merge.  Boxes (cols 0-3) and keypoints (cols 5-38) to image coordinates,
+ * scales concatenated, soft_nms_39 (utils/nms.py:109-206; it moves columns 0-38 only) when S > 1, scores >= the
+ * max_per_image-th largest kept.  rows fp32 [B,S*K,D] zero padded, counts int32 [B].  S*K <= 1024. */
+int cn_pose_merge(const float* dets, const float* meta, float* rows, int* counts, int S, int B, int K, int D,
+                  int down_ratio, int max_per_image, int nms_method, float nms_nt, float nms_sigma, float nms_threshold,
+                  void* stream);
 
 /* ---- decode (utils/decode.py, decode/ctdet.py, decode/multi_pose.py) -------------------------- */
 /* keep[b,c,h,w] = heat * (maxpool3x3(heat) == heat)   (utils/decode.py:5-10) */

@@ -97,3 +97,92 @@ def test_step_end(dets, metas, num_classes, down_ratio=4, max_per_image=100, mul
         for j in range(1, num_classes + 1):
             results[j] = results[j][results[j][:, 4] >= thresh]
     return results
+
+
+def flip_merge_pose(out, flip_idx):
+    """centernet_multi_pose.py:190-211 for B images (rows [B:] mirrored).  `out`: dict of fp32 NCHW head maps [2B,...]."""
+    B = out["heatmap"].shape[0] // 2
+    r = {"heatmap": flip_merge(out["heatmap"]), "width_height": flip_merge(out["width_height"]), "regression": out["regression"][:B]}
+    kp = out["keypoints"]
+    _, points, height, width = kp.shape
+    fk = kp[B:].flip(-1).reshape(B, points // 2, 2, height, width).clone()
+    fk[:, :, 0, :, :] *= -1
+    fk = fk[:, flip_idx].reshape(B, points, height, width)
+    r["keypoints"] = (kp[:B] + fk) / 2
+    fh = out["heatmap_keypoints"][B:].flip(-1)[:, flip_idx]
+    r["heatmap_keypoints"] = (out["heatmap_keypoints"][:B] + fh) / 2
+    r["heatmap_keypoints_offset"] = out["heatmap_keypoints_offset"][:B]
+    return r
+
+
+def soft_nms_39(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """utils/nms.py:109-206: as soft_nms, but columns 5..38 travel with the box (swap) while columns 39.. stay in place."""
+    N = boxes.shape[0]
+    for i in range(N):
+        maxscore, maxpos = boxes[i, 4], i
+        t = boxes[i, :5].copy()
+        pos = i + 1
+        while pos < N:
+            if maxscore < boxes[pos, 4]:
+                maxscore, maxpos = boxes[pos, 4], pos
+            pos += 1
+        boxes[i, :5] = boxes[maxpos, :5]
+        boxes[maxpos, :5] = t
+        tmp = boxes[i, 5:39].copy()
+        boxes[i, 5:39] = boxes[maxpos, 5:39]
+        boxes[maxpos, 5:39] = tmp
+        tx1, ty1, tx2, ty2 = (float(v) for v in boxes[i, :4])
+        pos = i + 1
+        while pos < N:
+            x1, y1, x2, y2 = (float(v) for v in boxes[pos, :4])
+            area = (x2 - x1 + 1) * (y2 - y1 + 1)
+            iw = min(tx2, x2) - max(tx1, x1) + 1
+            if iw > 0:
+                ih = min(ty2, y2) - max(ty1, y1) + 1
+                if ih > 0:
+                    ua = float((tx2 - tx1 + 1) * (ty2 - ty1 + 1) + area - iw * ih)
+                    ov = iw * ih / ua
+                    if method == 1:
+                        weight = 1 - ov if ov > Nt else 1
+                    elif method == 2:
+                        weight = np.exp(-(ov * ov) / sigma)
+                    else:
+                        weight = 0 if ov > Nt else 1
+                    boxes[pos, 4] = weight * float(boxes[pos, 4])
+                    if boxes[pos, 4] < threshold:
+                        boxes[pos, :5] = boxes[N - 1, :5]
+                        tmp = boxes[pos, 5:39].copy()
+                        boxes[pos, 5:39] = boxes[N - 1, 5:39]
+                        boxes[N - 1, 5:39] = tmp
+                        N -= 1
+                        pos -= 1
+            pos += 1
+    return N
+
+
+def pose_test_step_end(dets, metas, down_ratio=4, max_per_image=20):
+    """centernet_multi_pose.py:213-264 for ONE image; dets: list over scales of float32 [K,57]."""
+    out = []
+    for det, meta in zip(dets, metas):
+        det = torch.as_tensor(det, dtype=torch.float32).clone()
+        padding = torch.tensor(meta["padding"], dtype=torch.float32)
+        scale = torch.tensor(meta["scale"], dtype=torch.float32)
+        det[:, :4] *= down_ratio
+        det[:, :4] -= torch.cat([padding, padding])
+        det[:, :4] /= torch.cat([scale, scale])
+        points = det[:, 5:39].view(-1, 17, 2)
+        points *= down_ratio
+        points -= padding
+        points /= scale
+        det[:, 5:39] = points.view(-1, 34)
+        out.append(det.numpy())
+    results = np.concatenate(out, axis=0)
+    if len(dets) > 1:
+        n = soft_nms_39(results, Nt=0.5, method=2)
+        results = results[:n]
+    scores = results[:, 4]
+    if len(scores) > max_per_image:
+        kth = len(scores) - max_per_image
+        thresh = np.partition(scores, kth)[kth]
+        results = results[results[:, 4] >= thresh]
+    return results

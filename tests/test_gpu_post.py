@@ -103,3 +103,51 @@ def test_test_step_flip_tta_end_to_end():
             assert res[b][1][j].shape == ref[j].shape
             np.testing.assert_allclose(res[b][1][j], ref[j], rtol=1e-5, atol=1e-5)
         assert sum(len(v) for v in res[b][1].values()) >= 100
+
+
+FLIP_IDX = [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]
+
+
+@pytest.mark.parametrize("S", [1, 3])
+def test_pose_merge_matches_restatement(S):
+    """multi_pose rows [K,57]: boxes + keypoints to image coordinates, soft_nms_39 over the scales (columns 0-38 travel,
+    39-56 stay: the reference's behaviour), top-20 cut."""
+    from centernet_amd.utils import post
+    B, K = 2, 100
+    d = np.zeros((S, B, K, 57), np.float32)
+    base = _random_dets(21 + S, S, B, K, 1, True)
+    d[..., :5] = base[..., :5]
+    d[..., 5:39] = rng.uniform(22, f"kps{S}", (S, B, K, 34)) * 128
+    d[..., 40:] = rng.uniform(23, f"hs{S}", (S, B, K, 17))
+    metas = [{"scale": [int(512 * sc) / 512, int(384 * sc) / 384], "padding": [post_ref.tta_pad(int(512 * sc), 31), post_ref.tta_pad(int(384 * sc), 31)]}
+             for sc in [1.0, 0.75, 1.25][:S]]
+    rows, counts = post.pose_merge([torch.from_numpy(d[s]).to(DEV) for s in range(S)], metas)
+    for b in range(B):
+        ref = post_ref.pose_test_step_end([d[s, b] for s in range(S)], metas)
+        got = rows[b, :int(counts[b])].cpu().numpy()
+        assert got.shape == ref.shape and ref.shape[0] >= 20
+        assert np.array_equal(got[:, :4], ref[:, :4]) and np.array_equal(got[:, 5:], ref[:, 5:])
+        np.testing.assert_allclose(got[:, 4], ref[:, 4], rtol=2e-7, atol=0)
+
+
+def test_pose_test_step_flip_end_to_end():
+    """CenterNetMultiPose.test_step (pose-aware flip merge) + test_step_end against the restated pipeline on the same network."""
+    from centernet_amd.centernet_multi_pose import CenterNetMultiPose
+    m = CenterNetMultiPose("res_18", compute_dtype=torch.float32, test_flip=True, test_scales=[1, 1.25])
+    rng.fill_state_dict(m, 99)
+    m = m.to(DEV).eval()
+    img = rng.t_uniform(99, "img", (2, 3, 128, 128)).to(DEV)
+    ids, outs, metas = m.test_step((img, None), 0)
+    x = post_ref.tta_prepare(img.cpu(), MEAN, STD, 16, 16, True)
+    with torch.no_grad():
+        o = {k: v.cpu() for k, v in m(x.to(DEV))[-1].items()}
+    ref = post_ref.flip_merge_pose(o, FLIP_IDX)
+    for k in ref:
+        assert torch.allclose(outs[0][k].cpu(), ref[k], rtol=1e-4, atol=1e-5), k
+    dets = [m.decode({k: v.clone() for k, v in o_.items()}).cpu().numpy() for o_ in outs]
+    res = m.test_step_end((ids, outs, metas))
+    for b in range(2):
+        r = post_ref.pose_test_step_end([d[b] for d in dets], metas)
+        got = np.array(res[b][1], np.float32)
+        assert res[b][0] == ids[b] and got.shape == r.shape
+        np.testing.assert_allclose(got, r, rtol=1e-5, atol=1e-5)
