@@ -128,6 +128,16 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
+// 16-byte load / store through a NATIVE vector type.  `uint4` is a struct (HIP_vector_type): copying one between a global / LDS
+// pointer and an element of a private ARRAY is emitted as llvm.memcpy, which SROA does not promote — the array stays in scratch
+// memory and every reload waits with vmcnt(0) behind all in-flight prefetches (found in the DCN kernels' weight rings).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ static inline uint4 ldg16(const void* p) {
+    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ static inline void st16(void* p, const uint4& v) { *reinterpret_cast<u32x4_t*>(p) = u32x4_t{v.x, v.y, v.z, v.w}; }
+
 // Branch-free guarded 16-byte global load.  A predicated load compiles to an exec-masked branch, after which the
 // compiler can no longer count the loads in flight and falls back to s_waitcnt vmcnt(0) — that serialises every software
 // prefetch behind it.  Here the caller passes an address that is readable either way and the value is masked instead.

@@ -527,12 +527,12 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
 #pragma unroll
         for (int i = 0; i < DYV; ++i) {
             const int v = tid + i * 512;
-            *reinterpret_cast<uint4*>(As + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8) = rdy[i];
+            st16(As + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8, rdy[i]);
         }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int v = tid + i * 512;
-            if (v < DM_HP * (BN / 8)) *reinterpret_cast<uint4*>(Xh + (v / (BN / 8)) * DP + (v % (BN / 8)) * 8) = rx[i];
+            if (v < DM_HP * (BN / 8)) st16(Xh + (v / (BN / 8)) * DP + (v % (BN / 8)) * 8, rx[i]);
         }
 #pragma unroll
         for (int i = 0; i < OV; ++i) {
@@ -544,14 +544,14 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
 #pragma unroll
         for (int i = 0; i < BV; ++i) {
             const int v = tid + i * 512;
-            r[i] = *reinterpret_cast<const uint4*>(g.wd2 + ((int64_t)tap * g.Ci + ci0 + v / (COP / 8)) * COP + (v % (COP / 8)) * 8);
+            r[i] = ldg16(g.wd2 + ((int64_t)tap * g.Ci + ci0 + v / (COP / 8)) * COP + (v % (COP / 8)) * 8);
         }
     };
     auto stage_tap = [&](const uint4 (&r)[BV], int tap, int buf, int th0, int tw0) {   // weight slice + sample geometry -> LDS
 #pragma unroll
         for (int i = 0; i < BV; ++i) {
             const int v = tid + i * 512;
-            *reinterpret_cast<uint4*>(Bs + buf * BN * AP + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8) = r[i];
+            st16(Bs + buf * BN * AP + (v / (COP / 8)) * AP + (v % (COP / 8)) * 8, r[i]);
         }
         if (tid < BM) {
             const int gh = th0 + tid / DX_TW, gw = tw0 + tid % DX_TW;

@@ -271,6 +271,26 @@ def test_dcnv2(cfg, dt):
           scale=float(ref.conv_offset_mask.bias.grad.abs().max()) * sc)
 
 
+def test_dcn_fwd_tile_kernel_matches_gather_kernel():
+    """The LDS-resident forward (dcn_fwd_tile.hip) and the global-gather forward (dcn_fused.hip) on the same inputs: they may
+    differ by one bf16 ulp on a few outputs (fma order of the 4-corner blend).  Separate processes: the switch is read once."""
+    import os, subprocess, sys, tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cfg in (["3", "33", "45", "64", "64", "0.4"], ["2", "19", "37", "128", "128", "3.0"], ["2", "16", "16", "256", "64", "1.0"]):
+        outs = []
+        for env in ({"CN_FORCE_DCN_FWD_TILE": "1"}, {"CN_DISABLE_DCN_FWD_TILE": "1"}):
+            f = tempfile.NamedTemporaryFile(suffix=".pt", delete=False).name
+            r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dcn_fwd_ab.py"), *cfg, f], env=dict(os.environ, **env),
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(f))
+            os.unlink(f)
+        a, b = outs
+        d = (a - b).abs()
+        assert float(b.abs().max()) > 1.0 and float(d.max()) <= 2 ** -6 * float(b.abs().max()), cfg     # <= ~1 bf16 ulp at the top of the range
+        assert float((d > 0).float().mean()) < 2e-3, cfg
+
+
 def test_dcn_zero_init_is_half_conv():
     """Known-answer test 1 of SURVEY Appendix A on the HIP kernel (the state of every DCN at the start of training)."""
     from centernet_amd import nn as hnn
