@@ -1,0 +1,106 @@
+// 1x1 convolution with a 16-wide (padded) contraction — the data gradients of the 2-channel CenterNet heads
+// (width_height / regression / keypoint offsets: dY [P][16] x W^T [16][256] -> dH [P][256], heads.py:9-15 backwards).
+// On the implicit-GEMM kernel these launches are pure overhead: one 16-wide K slice per 128x128 tile, a 64 KB fp32 LDS slab
+// for the epilogue and one workgroup per CU — 502 us for 1.07 GB of traffic (mask read + output write), 17 TFLOP/s.
+// Here it is a streaming VALU kernel (cn_conv1x1_smallk, real contraction length K <= 4 given by the caller): a thread owns 8
+// output channels, keeps their K x 8 weights in registers and per pixel does K x 8 FMAs between one 16-byte mask load and one
+// 16-byte store; 4 pixels are in flight per thread, ~4 long-running workgroups per CU.
+#include "conv_common.h"
+
+template <int KE>
+__device__ static inline void smallk_body(const ConvGeom& g, const uint4 (&wr)[16], int cg, int pr, int ppb, int64_t P) {
+    float w[KE][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t d[8] = {wr[2 * e].x, wr[2 * e].y, wr[2 * e].z, wr[2 * e].w, wr[2 * e + 1].x, wr[2 * e + 1].y, wr[2 * e + 1].z, wr[2 * e + 1].w};
+#pragma unroll
+        for (int k = 0; k < KE; ++k) w[k][e] = __uint_as_float((k & 1) ? (d[k >> 1] & 0xffff0000u) : (d[k >> 1] << 16));
+    }
+    const bf16_t* __restrict__ X = reinterpret_cast<const bf16_t*>(g.x);
+    const bf16_t* __restrict__ R = reinterpret_cast<const bf16_t*>(g.res);
+    bf16_t* __restrict__ Y = reinterpret_cast<bf16_t*>(g.y);
+    const int ch = cg * 8;
+    const bool mask_mode = g.relu == 2;
+    constexpr int U = 4;
+    const int64_t p_begin = (int64_t)blockIdx.x * ppb, p_end = min(P, p_begin + ppb);
+    const int rows = blockDim.x / (g.Co / 8);                   // pixels per pass
+    for (int64_t p0 = p_begin + pr; p0 < p_end; p0 += (int64_t)rows * U) {
+        uint4 xv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                           // branch-free: rows past the end re-read the last row and are not stored
+            const int64_t p = min(p0 + (int64_t)u * rows, p_end - 1);
+            xv[u] = KE > 8 ? ldg16(X + p * g.x_ld) : ldg16(X + p * g.x_ld);
+            rv[u] = R ? ldg16(R + p * g.res_ld + ch) : make_uint4(0, 0, 0, 0);
+        }
+        uint4 xv2[U];
+        if constexpr (KE > 8) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv2[u] = ldg16(X + min(p0 + (int64_t)u * rows, p_end - 1) * g.x_ld + 8);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = p0 + (int64_t)u * rows;
+            const uint32_t dx[8] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w, KE > 8 ? xv2[u].x : 0u, KE > 8 ? xv2[u].y : 0u, KE > 8 ? xv2[u].z : 0u, KE > 8 ? xv2[u].w : 0u};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < KE; ++k) {
+                const float xk = __uint_as_float((k & 1) ? (dx[k >> 1] & 0xffff0000u) : (dx[k >> 1] << 16));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(xk, w[k][e], v[e]);
+            }
+            if (R) {
+                const uint32_t dr[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r = __uint_as_float((e & 1) ? (dr[e >> 1] & 0xffff0000u) : (dr[e >> 1] << 16));
+                    v[e] = mask_mode ? (r > 0.f ? v[e] : 0.f) : v[e] + r;
+                }
+            }
+            if (g.relu == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p < p_end) st16(Y + p * g.y_ld + ch, make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])));
+        }
+    }
+}
+
+template <int KE>
+__global__ __launch_bounds__(256) void conv1x1_smallk_kernel(const ConvGeom g, int ppb, int64_t P) {
+    const int cpg = g.Co / 8;
+    const int cg = threadIdx.x % cpg, pr = threadIdx.x / cpg;
+    const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(g.w);      // [co_pad][16], columns >= K are zero padding
+    uint4 wr[16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        wr[2 * e] = ldg16(Wp + (int64_t)(cg * 8 + e) * 16);
+        wr[2 * e + 1] = make_uint4(0, 0, 0, 0);
+    }
+    if (pr >= 256 / cpg) return;
+    smallk_body<KE>(g, wr, cg, pr, ppb, P);
+}
+
+// y[P][Co] = act(x[P][0..K-1] . wp[Co][0..K-1] (+ residual | masked by residual > 0)); bf16; x pitch x_ld, weights packed with a
+// 16-wide row (cn_pack_weight).  Replaces conv_igemm for the heads' 1x1 data gradients (heads.py:9-15 backwards, K = 1 | 2).
+extern "C" int cn_conv1x1_smallk(const void* x, const void* wp, const void* residual, void* y, int64_t P, int K, int x_ld, int Co,
+                                 int y_ld, int res_ld, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(x && wp && y && P > 0 && K > 0 && Co > 0, "cn_conv1x1_smallk: bad args");
+    if (dtype != CN_BF16 || K > 4 || (Co & 7) || Co < 64 || Co > 2048 || 256 % (Co / 8) != 0 || y_ld != Co || (x_ld & 7) || x_ld < 8 ||
+        (residual && (res_ld & 7)))
+        CN_UNSUPPORTED("cn_conv1x1_smallk: bf16, K <= 4, Co in {64,128,256,512,1024,2048} = y_ld, 16-byte pitches (K=%d Co=%d y_ld=%d x_ld=%d)", K, Co, y_ld, x_ld);
+    ConvGeom g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.w = wp; g.res = residual; g.y = y; g.Co = Co; g.y_ld = y_ld; g.x_ld = x_ld; g.res_ld = res_ld; g.relu = relu;
+    const int rows = 256 / (Co / 8);
+    // ~4 workgroups per CU, each streaming a long run of pixels: the weight prologue (one L2 round trip) is paid once
+    int64_t blocks = (P + rows * 16 - 1) / (rows * 16);
+    if (blocks > 1024) blocks = 1024;
+    const int ppb = (int)(((P + blocks - 1) / blocks + rows * 4 - 1) / (rows * 4)) * rows * 4;
+    blocks = (P + ppb - 1) / ppb;
+    if (K <= 2) hipLaunchKernelGGL(conv1x1_smallk_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, ppb, P);
+    else hipLaunchKernelGGL(conv1x1_smallk_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, ppb, P);
+    CN_LAUNCH_CHECK("cn_conv1x1_smallk");
+    return CN_OK;
+}

@@ -188,6 +188,9 @@ def conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
+_SMALLK_WIDTHS = (64, 128, 256, 512, 1024, 2048)
+
+
 def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None):
     N, H, W, Ci = x.shape
     cp = rup(Co, 16)
@@ -254,7 +257,13 @@ class Conv2dFn(Function):
             wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
             if Cx != Ci:
                 raise RuntimeError("data gradient through a channel-padded conv input is not supported")
-            if ctx.mask_dx:
+            if (KH == 1 and KW == 1 and stride == 1 and pad == 0 and Co <= 4 and x.dtype == torch.bfloat16
+                    and Ci in _SMALLK_WIDTHS and not _os.environ.get("CN_DISABLE_CONV_SMALLK")):
+                # 1- / 2-channel heads: a 16-wide padded contraction is pure overhead on the GEMM kernel -> streaming VALU kernel
+                dx = torch.empty((N, H, W, Ci), dtype=x.dtype, device=x.device)
+                call("cn_conv1x1_smallk", dy, wpd, x if ctx.mask_dx else None, dx, N * H * W, Co, dy.shape[-1], Ci, Ci,
+                     x.shape[-1] if ctx.mask_dx else 0, 2 if ctx.mask_dx else 0, dtype_code(x.dtype))
+            elif ctx.mask_dx:
                 dx = _igemm(dy, wpd, None, x, Ci, KH, KW, stride, pad, True, 2, H, W)
             else:
                 dx = _igemm(dy, wpd, None, None, Ci, KH, KW, stride, pad, True, False, H, W)

@@ -74,6 +74,11 @@ int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, i
 int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                   int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
                   int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype, void* stream);
+/* 1x1 conv with a tiny contraction (K <= 4 real input channels; x pitch x_ld, weights packed with 16-wide rows like
+ * cn_pack_weight): the data gradient of the 1- and 2-channel heads' last conv (heads.py:9-15, backwards).  relu = 2 masks the
+ * result with residual > 0 (fused ReLU backward), relu = 0 with residual adds it.  bf16, y_ld == Co. */
+int cn_conv1x1_smallk(const void* x, const void* wp, const void* residual, void* y, int64_t P, int K, int x_ld, int Co,
+                      int y_ld, int res_ld, int relu, int dtype, void* stream);
 /* which kernel cn_conv2d_fwd dispatches to: BN*1000 + BK = `conv_igemm_kernel<T,BN,BK>`;
  * 3000000 + BN*1000 + CK = the 3x3/s1/p1 halo-tile kernel `conv3x3s1_kernel<T,BN,CK>` */
 int cn_conv2d_variant(int Ci, int Co, int KH, int KW, int stride, int pad, int dtype);

@@ -54,6 +54,8 @@ CONVS = [  # N,H,W,Ci,Co,k,s,p,bias,relu
     (2, 16, 16, 64, 128, 1, 2, 0, False, False),
     (2, 12, 12, 256, 27, 3, 1, 1, True, False),
     (1, 9, 9, 256, 2, 1, 1, 0, True, False),
+    (2, 13, 11, 64, 1, 1, 1, 0, True, False),      # 1- / 2- / 4-channel heads: data gradient on cn_conv1x1_smallk (bf16)
+    (1, 7, 19, 512, 4, 1, 1, 0, False, False),
     (2, 4, 4, 512, 256, 3, 1, 1, False, False),
     (1, 24, 24, 448, 128, 1, 1, 0, False, False),
     (2, 32, 32, 256, 256, 3, 1, 1, False, False),   # Hourglass shapes (384-wide levels, 2x2 / 1x1 maps, strided residuals)
