@@ -288,3 +288,4 @@ bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const f
     }
     return true;
 }
+

@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage: pmc_cmd.sh "<command>" <kernel grep> <counter> [<counter> ...]   (one pass: counters + kernel trace only)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cmd=$1; pat=$2; shift 2
+rm -rf gpurun_out/pmc_x
+timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d gpurun_out/pmc_x -o p -- $cmd > gpurun_out/pmc_x.log 2>&1
+python - <<PY
+import sqlite3,glob
+from collections import defaultdict
+c=sqlite3.connect(glob.glob('gpurun_out/pmc_x/*.db')[0])
+rows=c.execute("select dispatch_id,kernel_name,counter_name,value,end-start from counters_collection where kernel_name like '%$pat%' order by dispatch_id").fetchall()
+d=defaultdict(dict)
+for did,k,cn,v,dur in rows: d[(did,k.split('(')[0][5:60],dur)][cn]=d[(did,k.split('(')[0][5:60],dur)].get(cn,0)+v
+for k,v in list(d.items())[-2:]: print(k, {a:round(b) for a,b in sorted(v.items())})
+PY
