@@ -251,7 +251,9 @@ def main():
         total_images = args.batch * world * args.steps
         roof = None
         tn = "bf16" if dt == torch.bfloat16 else "f32"
-        kname = lambda v: (f"conv3x3s1_kernel<{tn},{(v - 3000000) // 1000},{v % 1000}>" if v >= 3000000
+        waves8 = os.environ.get("CN_CONV3X3_WAVES", "0") in ("0", "8")      # csrc/conv3x3.hip launch3(): 8 waves on the 128x64 tile
+        kname = lambda v: ((f"conv3x3s1_kernel<{tn},128,64,8>" if (v == 3128064 and tn == "bf16" and waves8) else
+                            f"conv3x3s1_kernel<{tn},{(v - 3000000) // 1000},{v % 1000}>") if v >= 3000000
                            else f"conv_igemm_kernel<{tn},{v // 1000},{v % 1000}>")
         if probe:
             by = probe.summary()

@@ -12,8 +12,9 @@
 #define T3_TH 8
 #define T3_TW 16
 
-template <typename T, int BN, int CK>
-__global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
+template <typename T, int BN, int CK, int NW = 4>   // NW waves per workgroup: 4 (64x64 wave tiles) or 8 (32x64: twice the waves per SIMD)
+__global__ __launch_bounds__(NW * 64) void conv3x3s1_kernel(const ConvGeom g) {
+    constexpr int NT = NW * 64;
     constexpr int BM = T3_TH * T3_TW;                  // 128 output pixels
     constexpr int HW_ = T3_TW + 2, HH_ = T3_TH + 2;    // halo tile
     constexpr int HP = HH_ * HW_;                      // 180 halo pixels
@@ -21,20 +22,26 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
     constexpr int PITCH = CK + Mma<T>::PAD;
     constexpr int VPR = CK / VEC;                      // 16-byte vectors per pixel / weight row
     constexpr int A_VECS = HP * VPR;
-    constexpr int A_PASS = (A_VECS + 255) / 256;
+    constexpr int A_PASS = (A_VECS + NT - 1) / NT;
     constexpr int B_VECS = BN * VPR;
-    constexpr int B_PASS = (B_VECS + 255) / 256;
+    constexpr int B_PASS = (B_VECS + NT - 1) / NT;
     constexpr int WGN = (BN >= 64) ? 2 : 1;
-    constexpr int WGM = 4 / WGN;
+    constexpr int WGM = NW / WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NJ = WN / 32;
     constexpr int KSTEPS = CK / Mma<T>::KSTEP;
 
-    constexpr int MAIN_ELEMS = (HP + 2 * BN) * PITCH;
+    // ds_read_b128 is serviced in four fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): an A-fragment read of a
+    // group touches columns {0-3,12-15} of one tile row and {4-11} of the next.  With the pixel pitch of 9 slots (144 B) the two
+    // sets tile all 16 slots exactly when the halo ROW pitch is 0 mod 16 slots; the natural 18 x 9 = 162 = 2 (mod 16) made two
+    // slots collide in every group (every A read cost 2 LDS cycles instead of 1).  Rows are padded to 176 slots.
+    constexpr int RPAD = (sizeof(T) == 2) ? ((16 - (HW_ * PITCH / 8) % 16) % 16) * 8 : 0;
+    constexpr int RP = HW_ * PITCH + RPAD;             // halo row pitch in elements
+    constexpr int MAIN_ELEMS = HH_ * RP + 2 * BN * PITCH;
     constexpr int EPI_ELEMS = (sizeof(T) == 2) ? WGM * 32 * (BN + 4) * 2 : 0;   // fp32 slab of the LDS-staged epilogue
     __shared__ __attribute__((aligned(16))) T lds[MAIN_ELEMS > EPI_ELEMS ? MAIN_ELEMS : EPI_ELEMS];
     T* const As = lds;
-    T* const Bs = lds + HP * PITCH;                    // two buffers of BN rows
+    T* const Bs = lds + HH_ * RP;                      // two buffers of BN rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_w = (g.OW + T3_TW - 1) / T3_TW;
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = wm + i * 32 + (lane & 31);
-        hbase[i] = (m / T3_TW + 1) * HW_ + (m % T3_TW) + 1;
+        hbase[i] = (m / T3_TW + 1) * RP + ((m % T3_TW) + 1) * PITCH;   // element offset of the centre pixel
     }
 
     f32x16_t acc[NJ][MI];
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
 #pragma unroll
         for (int p = 0; p < B_PASS; ++p) {
             // branch-free: rows past the packed matrix re-read its last row (those output channels are never stored)
-            const int v = (B_VECS % 256 == 0) ? tid + p * 256 : min(tid + p * 256, B_VECS - 1);
+            const int v = (B_VECS % NT == 0) ? tid + p * NT : min(tid + p * NT, B_VECS - 1);
             const int row = min(n0 + v / VPR, g.co_pad - 1), col = (v % VPR) * VEC;
             r[p] = *reinterpret_cast<const uint4*>(Wp + (int64_t)row * g.ktot + wofs + col);
         }
@@ -80,14 +87,14 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
     auto bstore = [&](const uint4 (&r)[B_PASS], int buf) {
 #pragma unroll
         for (int p = 0; p < B_PASS; ++p) {
-            const int v = tid + p * 256;
-            if (B_VECS % 256 == 0 || v < B_VECS) lds_store_vec<T, PITCH>(Bs + buf * BN * PITCH, v / VPR, (v % VPR) * VEC, r[p]);
+            const int v = tid + p * NT;
+            if (B_VECS % NT == 0 || v < B_VECS) lds_store_vec<T, PITCH>(Bs + buf * BN * PITCH, v / VPR, (v % VPR) * VEC, r[p]);
         }
     };
     auto aload = [&](int c0) {                         // halo tile of one channel slice: one pass over HBM/L2
 #pragma unroll
         for (int p = 0; p < A_PASS; ++p) {
-            const int v = tid + p * 256;
+            const int v = tid + p * NT;
             const int hp = v / VPR, col = (v % VPR) * VEC;
             const int ih = th0 - 1 + hp / HW_, iw = tw0 - 1 + hp % HW_;
             const bool ok = v < A_VECS && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
@@ -97,8 +104,8 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
     auto astore = [&]() {
 #pragma unroll
         for (int p = 0; p < A_PASS; ++p) {
-            const int v = tid + p * 256;
-            if (v < A_VECS) lds_store_vec<T, PITCH>(As, v / VPR, (v % VPR) * VEC, ra[p]);
+            const int v = tid + p * NT;
+            if (v < A_VECS) lds_store_vec<T, PITCH>(As + ((v / VPR) / HW_) * RP, (v / VPR) % HW_, (v % VPR) * VEC, ra[p]);
         }
     };
 
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
             if (tap + PF < 9) bload(rb[tap % PF], tap + PF, c0);
             else bload(rb[tap % PF], tap + PF - 9, c1);
             if (tap == 4) aload(c1);
-            const int shift = (int)g.dh[0][tap] * HW_ + (int)g.dw[0][tap];
+            const int shift = (int)g.dh[0][tap] * RP + (int)g.dw[0][tap] * PITCH;
             const T* bt = Bs + ((c + tap) & 1) * BN * PITCH;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -128,10 +135,10 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     if constexpr (sizeof(T) == 2) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(As + (hbase[i] + shift) * PITCH + kk * 16 + (lane >> 5) * 8);
+                        const uint4 v = *reinterpret_cast<const uint4*>(As + hbase[i] + shift + kk * 16 + (lane >> 5) * 8);
                         fa[i] = __builtin_bit_cast(bf16x8_t, v);
                     } else {
-                        fa[i] = As[(hbase[i] + shift) * PITCH + kk * 2 + (lane >> 5)];
+                        fa[i] = As[hbase[i] + shift + kk * 2 + (lane >> 5)];
                     }
                 }
 #pragma unroll
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_kernel(const ConvGeom g) {
     }
     if constexpr (sizeof(T) == 2) {
         if (g.epi_tile) {                              // main loop ended on a barrier: the LDS is free
-            conv_epilogue_tile<MI, NJ, WGM, WGN>(g, acc, reinterpret_cast<float*>(lds), n0, tid, [&](int m) -> int64_t {
+            conv_epilogue_tile<MI, NJ, WGM, WGN, NT>(g, acc, reinterpret_cast<float*>(lds), n0, tid, [&](int m) -> int64_t {
                 const int oh = th0 + m / T3_TW, ow = tw0 + m % T3_TW;
                 return (oh < g.OH && ow < g.OW) ? ((int64_t)n * g.OH + oh) * g.OW + ow : -1;
             });
@@ -316,6 +323,13 @@ bool dgrad_s2_c32to16_launch(const ConvGeom& g, hipStream_t st) {
 template <typename T, int BN, int CK>
 static void launch3(const ConvGeom& g, hipStream_t st) {
     dim3 grid(((g.OH + T3_TH - 1) / T3_TH) * ((g.OW + T3_TW - 1) / T3_TW), (g.Co + BN - 1) / BN, g.N);
+    // 8 waves (32x64 wave tiles, 4 waves/SIMD with two workgroups per CU) hide the per-tap LDS/barrier latency better on the
+    // 128-channel tile: 901 vs 850 TFLOP/s; on the 64-channel tile the extra fragment reads cost more than they hide (840 vs 900)
+    static const int nw_env = getenv("CN_CONV3X3_WAVES") ? atoi(getenv("CN_CONV3X3_WAVES")) : 0;
+    if constexpr (sizeof(T) == 2 && CK == 64 && BN >= 64) {
+        const int nw = nw_env ? nw_env : (BN == 128 ? 8 : 4);
+        if (nw == 8) { hipLaunchKernelGGL((conv3x3s1_kernel<T, BN, CK, 8>), grid, dim3(512), 0, st, g); return; }
+    }
     hipLaunchKernelGGL((conv3x3s1_kernel<T, BN, CK>), grid, dim3(256), 0, st, g);
 }
 

@@ -168,10 +168,10 @@ static inline bool conv_epi_tile_ok(const ConvGeom& g, int dtype) {
     return dtype == CN_BF16 && !g.y_f32 && g.res32 == nullptr && (g.Co & 7) == 0 && (g.y_ld & 7) == 0 &&
            (g.res == nullptr || (g.res_ld & 7) == 0) && (((uintptr_t)g.y | (uintptr_t)g.res) & 15) == 0;
 }
-template <int MI, int NJ, int WGM, int WGN, typename PixFn>
+template <int MI, int NJ, int WGM, int WGN, int NT = 256, typename PixFn>
 __device__ static inline void conv_epilogue_tile(const ConvGeom& g, f32x16_t (&acc)[NJ][MI], float* ot, int n0, int tid, PixFn pixel_of) {
     constexpr int BN = WGN * NJ * 32, P = BN + 4, R = WGM * 32, WM = MI * 32;
-    constexpr int CPR = BN / 8, PASSES = (R * CPR + 255) / 256;
+    constexpr int CPR = BN / 8, PASSES = (R * CPR + NT - 1) / NT;
     const int lane = tid & 63, wave = tid >> 6;
     const int wgm = wave / WGN, wgn = wave % WGN;
     bf16_t* __restrict__ Y = reinterpret_cast<bf16_t*>(g.y);
@@ -188,7 +188,7 @@ __device__ static inline void conv_epilogue_tile(const ConvGeom& g, f32x16_t (&a
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int id = tid + p * 256;
+            const int id = tid + p * NT;
             const int rr = id / CPR, c8 = (id % CPR) * 8;
             if (id >= R * CPR) continue;
             const int ch = n0 + c8;
