@@ -99,7 +99,7 @@ __device__ static inline void dw_stage_weights(const float* __restrict__ w, floa
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ res,
                                                            T* __restrict__ y, int N, int H, int W, int CV, int k, int s,
                                                            int p, int OH, int OW) {
     constexpr int V = Vec16<T>::N;
@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__
 #pragma unroll
                 for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], wt[j], acc[j]);
             }
+        }
+        if (res) {                                  // IDAUp: node(up(proj(x)) + layers[i-1]) — the add rides in this store
+            float r[V];
+            Vec16<T>::load(res + i * V, r);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += r[j];
         }
         Vec16<T>::store(y + i * V, acc);
     }
@@ -316,8 +322,8 @@ extern "C" int cn_maxpool_bwd(const void* x, const void* dy, void* dx, int N, in
     return CN_OK;
 }
 
-extern "C" int cn_dwdeconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int k, int stride, int pad,
-                               int OH, int OW, int dtype, void* stream) {
+extern "C" int cn_dwdeconv_fwd(const void* x, const float* w, const void* residual, void* y, int N, int H, int W, int C, int k, int stride,
+                               int pad, int OH, int OW, int dtype, void* stream) {
     CN_CHECK_ARG(x && w && y, "cn_dwdeconv_fwd: null");
     POOL_ARGS_CHECK("cn_dwdeconv_fwd");
     int64_t total = (int64_t)N * OH * OW * (C / V);
@@ -328,7 +334,7 @@ extern "C" int cn_dwdeconv_fwd(const void* x, const float* w, void* y, int N, in
         else (void)hipFuncSetAttribute((const void*)dwdeconv_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes);
     }
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_fwd_kernel<T>, dim3(pool_grid(total) > 2048 ? 2048 : pool_grid(total)), dim3(256),
-                                                   (size_t)C * k * k * sizeof(float), (hipStream_t)stream, (const T*)x, w, (T*)y, N, H, W, C / V, k, stride, pad, OH, OW));
+                                                   (size_t)C * k * k * sizeof(float), (hipStream_t)stream, (const T*)x, w, (const T*)residual, (T*)y, N, H, W, C / V, k, stride, pad, OH, OW));
     CN_LAUNCH_CHECK("cn_dwdeconv_fwd");
     return CN_OK;
 }

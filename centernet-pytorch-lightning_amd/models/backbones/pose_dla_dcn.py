@@ -172,8 +172,8 @@ class IDAUp(nn.Module):
     def forward(self, layers, startp, endp):
         for i in range(startp + 1, endp):
             j = i - startp
-            up = getattr(self, f"up_{j}")(getattr(self, f"proj_{j}")(layers[i]))
-            layers[i] = getattr(self, f"node_{j}")(ops.add(up, layers[i - 1]))
+            merged = getattr(self, f"up_{j}")(getattr(self, f"proj_{j}")(layers[i]), layers[i - 1])    # up(proj(x)) + layers[i-1]
+            layers[i] = getattr(self, f"node_{j}")(merged)
 
 
 class DLAUp(nn.Module):

@@ -143,8 +143,9 @@ class DepthwiseUp(nn.Module):
         g = torch.tensor([1 - abs(i / fc - cc) for i in range(k)])
         self.weight = nn.Parameter(torch.outer(g, g).expand(c, 1, k, k).clone())
 
-    def forward(self, x):
-        return ops.DwDeconvFn.apply(x, self.weight, self.stride, self.padding)
+    def forward(self, x, residual=None):
+        """up(x) (+ residual, fused into the store)"""
+        return ops.DwDeconvFn.apply(x, self.weight, self.stride, self.padding, residual)
 
 
 class DCN(nn.Module):

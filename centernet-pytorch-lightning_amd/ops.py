@@ -456,14 +456,16 @@ class DwDeconvFn(Function):
     """Depthwise ConvTranspose2d(o,o,2f,stride=f,padding=f//2,groups=o,bias=False); weight fp32 [C,1,k,k]."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad):
+    def forward(ctx, x, weight, stride, pad, residual=None):
         N, H, W, C = x.shape
         k = weight.shape[-1]
         OH, OW = (H - 1) * stride - 2 * pad + k, (W - 1) * stride - 2 * pad + k
         y = _empty_like_shape(x, (N, OH, OW, C))
-        call("cn_dwdeconv_fwd", x, weight.detach().contiguous(), y, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        call("cn_dwdeconv_fwd", x, weight.detach().contiguous(), None if residual is None else residual.contiguous(), y, N, H, W, C, k,
+             stride, pad, OH, OW, dtype_code(x.dtype))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, OH, OW)
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
@@ -484,7 +486,7 @@ class DwDeconvFn(Function):
         elif ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight, dtype=torch.float32)
             call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
-        return dx, dw, None, None
+        return dx, dw, None, None, (dy if ctx.has_res else None)
 
 
 class AddFn(Function):

@@ -136,9 +136,10 @@ int cn_maxpool_bwd(const void* x, const void* dy, void* dx, int N, int H, int W,
  * up-sampled operand: dlow[N,H,W,C] = 2x2 block sums of dy[N,2H,2W,C] (the `a` operand's gradient is dy itself). */
 int cn_upsample2x_add(const void* a, const void* low, void* y, int N, int H, int W, int C, int dtype, void* stream);
 int cn_sumpool2x2(const void* dy, void* dlow, int N, int H, int W, int C, int dtype, void* stream);
-/* depthwise ConvTranspose2d(o,o,2f,stride=f,padding=f/2,groups=o) — pose_dla_dcn.py:466-475; w fp32 [C,1,k,k] */
-int cn_dwdeconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int k, int stride, int pad,
-                    int OH, int OW, int dtype, void* stream);
+/* depthwise ConvTranspose2d(o,o,2f,stride=f,padding=f/2,groups=o) — pose_dla_dcn.py:466-475; w fp32 [C,1,k,k].
+ * residual (nullable, [N,OH,OW,C]) is added in the store: IDAUp's `node(up(proj(x)) + layers[i-1])`, pose_dla_dcn.py:483-488. */
+int cn_dwdeconv_fwd(const void* x, const float* w, const void* residual, void* y, int N, int H, int W, int C, int k, int stride,
+                    int pad, int OH, int OW, int dtype, void* stream);
 int cn_dwdeconv_bwd_input(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int k, int stride,
                           int pad, int OH, int OW, int dtype, void* stream);
 int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp32 [C,k,k] */, int N, int H, int W,

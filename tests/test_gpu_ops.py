@@ -217,22 +217,30 @@ def test_upsample2x_add(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 2), (1, 6, 5, 64, 4), (2, 4, 4, 256, 2)])
+@pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 2, False), (1, 6, 5, 64, 4, True), (2, 4, 4, 256, 2, True)])
 def test_depthwise_up(cfg, dt):
-    N, H, W, C, f = cfg
+    """depthwise bilinear up-conv, optionally with IDAUp's merge add fused into its store (pose_dla_dcn.py:483-488)"""
+    N, H, W, C, f, with_res = cfg
     k = 2 * f
     x = rng.t_normal(6, f"x{cfg}", (N, C, H, W))
     w = rng.t_uniform(6, f"w{cfg}", (C, 1, k, k), 0.0, 0.5)
     xr, wr = rnd(x, dt).requires_grad_(True), w.clone().requires_grad_(True)
     yr = F.conv_transpose2d(xr, wr, None, f, f // 2, groups=C)
+    res = rnd(rng.t_normal(6, f"r{cfg}", tuple(yr.shape)), dt) if with_res else None
+    rr = res.clone().requires_grad_(True) if with_res else None
+    if with_res:
+        yr = yr + rr
     gy = rng.t_normal(6, f"g{cfg}", tuple(yr.shape))
     yr.backward(rnd(gy, dt))
     xg, wg = to_nhwc(x, dt).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    y = ops().DwDeconvFn.apply(xg, wg, f, f // 2)
+    rg = to_nhwc(res, dt).requires_grad_(True) if with_res else None
+    y = ops().DwDeconvFn.apply(xg, wg, f, f // 2, rg)
     close(to_nchw(y), yr, dt, "dwdeconv fwd")
     y.backward(to_nhwc(gy, dt))
     close(to_nchw(xg.grad), xr.grad, dt, "dwdeconv dx")
     close(wg.grad, wr.grad, dt, "dwdeconv dw")
+    if with_res:
+        assert torch.equal(to_nchw(rg.grad), rr.grad), "d(residual) is dy itself"
 
 
 @pytest.mark.parametrize("dt", DTYPES)
