@@ -255,3 +255,32 @@ def test_encode_multi_pose_on_device(golden):
     _, one = MultiPoseSample()(torch.zeros(3, 512, 512, device=DEV), ann)
     assert np.array_equal(one["keypoints_mask"].cpu().numpy(), g["keypoints_mask1"])
     assert np.array_equal(one["heatmap_keypoints_offset"].cpu().numpy(), g["heatmap_keypoints_offset1"])
+
+
+def test_empty_inputs_losses_and_encoders():
+    """Images without objects: all-false regression masks give an exactly-zero L1 loss (0 / (0 + 1e-4), utils/losses.py:62)
+    with zero gradients, the focal loss takes its num_pos == 0 branch, and the encoders emit empty targets (nobj = 0)."""
+    from centernet_amd.sample import encode_ctdet_batch, encode_multi_pose_batch
+    from centernet_amd.utils.decode import sigmoid_clamped
+    from centernet_amd.utils.losses import FocalLoss, RegL1Loss, RegWeightedL1Loss
+    B, M = 2, 128
+    t = encode_ctdet_batch(torch.zeros(B, M, 4, device=DEV), torch.zeros(B, M, dtype=torch.int32, device=DEV),
+                           torch.zeros(B, dtype=torch.int32, device=DEV), 512, 512)
+    assert float(t["heatmap"].abs().max()) == 0 and not bool(t["regression_mask"].any()) and int(t["indices"].abs().max()) == 0
+    p = encode_multi_pose_batch(torch.zeros(B, M, 4, device=DEV), torch.zeros(B, M, 17, 3, device=DEV),
+                                torch.zeros(B, dtype=torch.int32, device=DEV), 512, 512)
+    assert float(p["heatmap_keypoints"].abs().max()) == 0 and not bool(p["keypoints_mask"].any()) and not bool(p["heatmap_keypoints_mask"].any())
+    wh = rng.t_normal(61, "wh", (B, 2, 128, 128)).to(DEV).requires_grad_(True)
+    l1 = RegL1Loss()(wh, t["regression_mask"], t["indices"], t["width_height"])
+    l1.backward()
+    assert l1.item() == 0.0 and float(wh.grad.abs().max()) == 0.0
+    kp = rng.t_normal(61, "kp", (B, 34, 128, 128)).to(DEV).requires_grad_(True)
+    lk = RegWeightedL1Loss()(kp, p["keypoints_mask"], t["indices"], p["keypoints"])
+    lk.backward()
+    assert lk.item() == 0.0 and float(kp.grad.abs().max()) == 0.0
+    logits = (rng.t_normal(61, "lg", (B, 80, 128, 128)) - 2.19)
+    lg = logits.to(DEV).requires_grad_(True)
+    hm = FocalLoss()(sigmoid_clamped(lg.clone()), t["heatmap"])
+    ref = ops_ref.focal_loss(ops_ref.sigmoid_clamped(logits.clone()), torch.zeros(B, 80, 128, 128))
+    hm.backward()
+    assert hm.item() == pytest.approx(ref.item(), rel=1e-4) and bool(torch.isfinite(lg.grad).all())
