@@ -4,8 +4,8 @@
 #include "common.h"
 
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
-                                                          int CV, int k, int s, int p, int OH, int OW) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                                          int N, int H, int W, int CV, int k, int s, int p, int OH, int OW) {
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * OH * OW * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -15,8 +15,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         pix /= OW;
         const int oh = (int)(pix % OH), n = (int)(pix / OH);
         float m[V];
+        int am[V];                                   // window position kh*k + kw of the FIRST maximum (ATen's tie rule)
 #pragma unroll
-        for (int j = 0; j < V; ++j) m[j] = -INFINITY;
+        for (int j = 0; j < V; ++j) { m[j] = -INFINITY; am[j] = -1; }
         for (int kh = 0; kh < k; ++kh) {
             const int ih = oh * s - p + kh;
             if ((unsigned)ih >= (unsigned)H) continue;
@@ -26,16 +27,27 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                 float v[V];
                 Vec16<T>::load(x + ((((int64_t)n * H + ih) * W + iw) * CV + cv) * V, v);
 #pragma unroll
-                for (int j = 0; j < V; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                for (int j = 0; j < V; ++j)
+                    if (v[j] > m[j] || am[j] < 0) { m[j] = v[j]; am[j] = kh * k + kw; }
             }
         }
         Vec16<T>::store(y + i * V, m);
+        if (idx) {
+            unsigned char* d = idx + i * V;          // V bytes: 8 (bf16) or 4 (fp32), naturally aligned
+            if constexpr (V == 8) {
+                *reinterpret_cast<uint2*>(d) = make_uint2((am[0] & 255) | (am[1] & 255) << 8 | (am[2] & 255) << 16 | (unsigned)(am[3] & 255) << 24,
+                                                          (am[4] & 255) | (am[5] & 255) << 8 | (am[6] & 255) << 16 | (unsigned)(am[7] & 255) << 24);
+            } else {
+                *reinterpret_cast<uint32_t*>(d) = (am[0] & 255) | (am[1] & 255) << 8 | (am[2] & 255) << 16 | (unsigned)(am[3] & 255) << 24;
+            }
+        }
     }
 }
 
-// gather form: every input element sums dy of the windows whose FIRST maximum (scan order kh, kw) it is.
+// gather form: every input element sums dy of the windows whose recorded arg-max (`idx`, written by the forward) it is — the
+// windows' x values are not re-read (the first version recomputed every arg-max from x: 2.2x the traffic of this one).
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ dy,
                                                           T* __restrict__ dx, int N, int H, int W, int CV, int k, int s,
                                                           int p, int OH, int OW) {
     constexpr int V = Vec16<T>::N;
@@ -59,28 +71,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         if (ow_hi > OW - 1) ow_hi = OW - 1;
         for (int oh = oh_lo; oh <= oh_hi; ++oh)
             for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                float m[V];
-                int am[V];
-#pragma unroll
-                for (int j = 0; j < V; ++j) { m[j] = -INFINITY; am[j] = -1; }
-                for (int kh = 0; kh < k; ++kh) {
-                    const int hh = oh * s - p + kh;
-                    if ((unsigned)hh >= (unsigned)H) continue;
-                    for (int kw = 0; kw < k; ++kw) {
-                        const int ww = ow * s - p + kw;
-                        if ((unsigned)ww >= (unsigned)W) continue;
-                        float v[V];
-                        Vec16<T>::load(x + ((((int64_t)n * H + hh) * W + ww) * CV + cv) * V, v);
-#pragma unroll
-                        for (int j = 0; j < V; ++j)
-                            if (v[j] > m[j] || am[j] < 0) { m[j] = v[j]; am[j] = hh * W + ww; }
-                    }
-                }
+                const int mine = (ih - (oh * s - p)) * k + (iw - (ow * s - p));      // my position inside that window
+                const int64_t o = ((((int64_t)n * OH + oh) * OW + ow) * CV + cv) * V;
+                unsigned int a[2] = {0, 0};
+                if constexpr (V == 8) { const uint2 t = *reinterpret_cast<const uint2*>(idx + o); a[0] = t.x; a[1] = t.y; }
+                else a[0] = *reinterpret_cast<const uint32_t*>(idx + o);
                 float d[V];
-                Vec16<T>::load(dy + ((((int64_t)n * OH + oh) * OW + ow) * CV + cv) * V, d);
+                Vec16<T>::load(dy + o, d);
 #pragma unroll
                 for (int j = 0; j < V; ++j)
-                    if (am[j] == ih * W + iw) g[j] += d[j];
+                    if ((int)((a[j >> 2] >> (8 * (j & 3))) & 255u) == mine) g[j] += d[j];
             }
         Vec16<T>::store(dx + i * V, g);
     }
@@ -299,24 +299,25 @@ static int pool_grid(int64_t total) {
     const int V = dtype == CN_F32 ? 4 : 8;                                                                         \
     CN_CHECK_ARG(C % V == 0, name ": C=%d must be a multiple of %d", C, V)
 
-extern "C" int cn_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, int OH, int OW,
-                              int dtype, void* stream) {
+extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad, int OH,
+                              int OW, int dtype, void* stream) {
     CN_CHECK_ARG(x && y, "cn_maxpool_fwd: null");
     POOL_ARGS_CHECK("cn_maxpool_fwd");
+    CN_CHECK_ARG(k * k <= 255, "cn_maxpool_fwd: window %dx%d does not fit the 8-bit arg-max", k, k);
     int64_t total = (int64_t)N * OH * OW * (C / V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
-                                                   (hipStream_t)stream, (const T*)x, (T*)y, N, H, W, C / V, k, stride, pad, OH, OW));
+                                                   (hipStream_t)stream, (const T*)x, (T*)y, argmax, N, H, W, C / V, k, stride, pad, OH, OW));
     CN_LAUNCH_CHECK("cn_maxpool_fwd");
     return CN_OK;
 }
 
-extern "C" int cn_maxpool_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
+extern "C" int cn_maxpool_bwd(const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
                               int OH, int OW, int dtype, void* stream) {
-    CN_CHECK_ARG(x && dy && dx, "cn_maxpool_bwd: null");
+    CN_CHECK_ARG(argmax && dy && dx, "cn_maxpool_bwd: null");
     POOL_ARGS_CHECK("cn_maxpool_bwd");
     int64_t total = (int64_t)N * H * W * (C / V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
-                                                   (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, N, H, W, C / V, k,
+                                                   (hipStream_t)stream, argmax, (const T*)dy, (T*)dx, N, H, W, C / V, k,
                                                    stride, pad, OH, OW));
     CN_LAUNCH_CHECK("cn_maxpool_bwd");
     return CN_OK;

@@ -437,18 +437,19 @@ class MaxPoolFn(Function):
         N, H, W, C = x.shape
         OH, OW = conv_out(H, k, stride, pad), conv_out(W, k, stride, pad)
         y = _empty_like_shape(x, (N, OH, OW, C))
-        call("cn_maxpool_fwd", x, y, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
-        ctx.save_for_backward(x)
-        ctx.cfg = (k, stride, pad, OH, OW)
+        need = ctx.needs_input_grad[0]
+        idx = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device) if need else None
+        call("cn_maxpool_fwd", x, y, idx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        ctx.save_for_backward(idx)
+        ctx.cfg = (k, stride, pad, OH, OW, (N, H, W, C), x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        k, stride, pad, OH, OW = ctx.cfg
-        N, H, W, C = x.shape
-        dx = torch.empty_like(x)
-        call("cn_maxpool_bwd", x, dy.contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+        (idx,) = ctx.saved_tensors
+        k, stride, pad, OH, OW, (N, H, W, C), dt = ctx.cfg
+        dx = torch.empty((N, H, W, C), dtype=dt, device=dy.device)
+        call("cn_maxpool_bwd", idx, dy.contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(dt))
         return dx, None, None, None
 
 

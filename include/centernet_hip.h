@@ -127,9 +127,11 @@ int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* g
 int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 
 /* ---- pooling / depthwise up-sampling -------------------------------------------------------- */
-int cn_maxpool_fwd(const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad,
+/* F.max_pool2d (msra_resnet.py:113 3x3/s2/p1, pose_dla_dcn.py:219 2x2/s2).  argmax (nullable) u8 [N,OH,OW,C]: window position
+ * kh*k+kw of the FIRST maximum (ATen's tie rule); the backward routes dy through it instead of re-reading x. */
+int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad,
                    int OH, int OW, int dtype, void* stream);
-int cn_maxpool_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
+int cn_maxpool_bwd(const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
                    int OH, int OW, int dtype, void* stream);
 /* Hourglass merge (large_hourglass.py:108-125 MergeUp/make_unpool_layer, :196-204 kp_module.forward):
  * y[N,2H,2W,C] = a + nearest_up2x(low[N,H,W,C]); a == NULL gives plain nn.Upsample(scale_factor=2).  Backward of the
