@@ -184,8 +184,14 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __res
                                                                   float* __restrict__ dw, int N, int H, int W, int CV, int k,
                                                                   int s, int p, int OH, int OW, int64_t chunk) {
     constexpr int V = Vec16<T>::N;
-    const int pair = blockIdx.y * 256 + threadIdx.x;
-    if (pair >= CV * k * k) return;
+    // a workgroup covers NP = min(256, CV*k*k - 256*blockIdx.y) (tap, channel-vector) pairs; when that leaves lanes idle (64 channels x
+    // 16 taps = 128 pairs) the spare lanes take every other group of 4 pixels of the chunk, and the planes meet in LDS before the atomics
+    const int npairs = CV * k * k - blockIdx.y * 256;
+    const int NP = npairs < 256 ? npairs : 256;
+    const int planes = 256 / NP;
+    const int plane = threadIdx.x / NP;
+    const int pair = blockIdx.y * 256 + threadIdx.x % NP;
+    const bool live = plane < planes;
     const int cv = pair % CV, tap = pair / CV;
     const int kh = tap / k, kw = tap - kh * k;
     const int64_t P = (int64_t)N * H * W;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __res
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
-    for (int64_t pb = p0; pb < p1; pb += 4) {
+    for (int64_t pb = p0 + 4 * plane; live && pb < p1; pb += 4 * planes) {
         uint4 ra[4], rb[4];
         bool ok[4];
 #pragma unroll
@@ -225,8 +231,20 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __res
             for (int j = 0; j < V; ++j) acc[j] = fmaf(a[j], b[j], acc[j]);
         }
     }
+    __shared__ float red[256 * 8];
+    if (planes > 1) {
 #pragma unroll
-    for (int j = 0; j < V; ++j) atomicAdd(dw + ((int64_t)(cv * V + j) * k + kh) * k + kw, acc[j]);
+        for (int j = 0; j < V; ++j) red[threadIdx.x * V + j] = acc[j];
+        __syncthreads();
+        if (plane == 0)
+            for (int q = 1; q < planes; ++q)
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += red[(q * NP + threadIdx.x) * V + j];
+    }
+    if (plane == 0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) atomicAdd(dw + ((int64_t)(cv * V + j) * k + kh) * k + kw, acc[j]);
+    }
 }
 
 // ---- nearest-neighbour x2 up-sampling fused with the hourglass merge (large_hourglass.py:108-125, 196-204) ----------------
@@ -362,8 +380,10 @@ extern "C" int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw, 
     CN_CHECK_ARG(x && dy && dw, "cn_dwdeconv_bwd_weight: null");
     POOL_ARGS_CHECK("cn_dwdeconv_bwd_weight");
     int64_t P = (int64_t)N * H * W;
-    int64_t chunk = (P + 511) / 512;
+    const int nchunks = (C / V) * k * k <= 128 ? 1024 : 512;   // spare lanes split a chunk, so the atomics per pixel stay the same
+    int64_t chunk = (P + nchunks - 1) / nchunks;
     if (chunk < 64) chunk = 64;
+    chunk = (chunk + 3) / 4 * 4;
     dim3 grid(cdiv(P, chunk), cdiv((C / V) * k * k, 256));
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_bwd_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (const T*)dy, dw, N, H, W, C / V, k, stride, pad, OH, OW, chunk));
