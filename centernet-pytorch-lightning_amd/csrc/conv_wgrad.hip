@@ -231,12 +231,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
     if (prow < RPB && cv * V < C) {
         const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = r0 + rows_per_blk < P ? r0 + rows_per_blk : P;
         int64_t r = r0 + prow;
-        for (; r + 7 * RPB < r1; r += 8 * RPB) {          // 8 independent 16-byte loads in flight per thread
-            float v[8][V];
+        for (; r + 15 * RPB < r1; r += 16 * RPB) {        // 16 independent 16-byte loads in flight per thread (64 KB per workgroup)
+            uint4 q[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) Vec16<T>::load(dy + (r + u * RPB) * ld + cv * V, v[u]);   // ld is padded to a vector multiple
+            for (int u = 0; u < 16; ++u) q[u] = ldg16(dy + (r + u * RPB) * ld + cv * V);           // ld is padded to a vector multiple
 #pragma unroll
-            for (int j = 0; j < V; ++j) s[j] += ((v[0][j] + v[1][j]) + (v[2][j] + v[3][j])) + ((v[4][j] + v[5][j]) + (v[6][j] + v[7][j]));
+            for (int h = 0; h < 2; ++h) {
+                float v[8][V];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) Vec16<T>::unpack(q[h * 8 + u], v[u]);
+#pragma unroll
+                for (int j = 0; j < V; ++j) s[j] += ((v[0][j] + v[1][j]) + (v[2][j] + v[3][j])) + ((v[4][j] + v[5][j]) + (v[6][j] + v[7][j]));
+            }
         }
         for (; r < r1; r += RPB) {
             float v[V];
@@ -296,8 +302,11 @@ static int launch_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld
     const int CV = (Co + V - 1) / V;
     const int CVB = CV < 256 ? CV : 256;
     const int RPB = 256 / CVB;
-    int64_t nblk = (P + (int64_t)RPB * 16 - 1) / ((int64_t)RPB * 16);
-    if (nblk > 256) nblk = 256;                       // same-address atomics serialise: few workgroups, deep loads
+    int64_t nblk = (P + (int64_t)RPB * 32 - 1) / ((int64_t)RPB * 32);
+    // same-address atomics serialise (~0.2 us each: 256 workgroups spent 50 us in the chain on a 16 MB input): few workgroups,
+    // each with 64 KB of loads in flight
+    static const int cap = getenv("CN_COLSUM_BLOCKS") ? atoi(getenv("CN_COLSUM_BLOCKS")) : 64;
+    if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
     const int64_t rows_per_blk = (P + nblk - 1) / nblk;
     dim3 grid((int)nblk, (CV + CVB - 1) / CVB);
