@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restric
                                                               const float* __restrict__ shift, int64_t nvec, int CV, int relu) {
     constexpr int V = Vec16<T>::N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
+        const int cv = nvec < (1ll << 31) ? (int)((uint32_t)i % (uint32_t)CV) : (int)(i % CV);   // a 64-bit modulo per vector costs more ALU than the vector's FMAs
         float xv[V], rv[V];
         Vec16<T>::load(x + i * V, xv);
         if (res) Vec16<T>::load(res + i * V, rv);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dres, int64_t nvec, int CV, int C, int relu) {
     constexpr int V = Vec16<T>::N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
+        const int cv = nvec < (1ll << 31) ? (int)((uint32_t)i % (uint32_t)CV) : (int)(i % CV);   // a 64-bit modulo per vector costs more ALU than the vector's FMAs
         float gv[V], xv[V], yv[V];
         Vec16<T>::load(dy + i * V, gv);
         Vec16<T>::load(x + i * V, xv);

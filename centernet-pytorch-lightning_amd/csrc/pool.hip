@@ -9,11 +9,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * OH * OW * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        int64_t pix = i / CV;
-        const int ow = (int)(pix % OW);
-        pix /= OW;
-        const int oh = (int)(pix % OH), n = (int)(pix / OH);
+        const uint32_t iu = (uint32_t)i;                       // 32-bit index arithmetic: three 64-bit divisions per vector made these kernels ALU bound
+        const int cv = (int)(iu % (uint32_t)CV);
+        uint32_t pix = iu / (uint32_t)CV;
+        const int ow = (int)(pix % (uint32_t)OW);
+        pix /= (uint32_t)OW;
+        const int oh = (int)(pix % (uint32_t)OH), n = (int)(pix / (uint32_t)OH);
         float m[V];
         int am[V];                                   // window position kh*k + kw of the FIRST maximum (ATen's tie rule)
 #pragma unroll
@@ -53,11 +54,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        int64_t pix = i / CV;
-        const int iw = (int)(pix % W);
-        pix /= W;
-        const int ih = (int)(pix % H), n = (int)(pix / H);
+        const uint32_t iu = (uint32_t)i;                       // 32-bit index arithmetic: three 64-bit divisions per vector made these kernels ALU bound
+        const int cv = (int)(iu % (uint32_t)CV);
+        uint32_t pix = iu / (uint32_t)CV;
+        const int iw = (int)(pix % (uint32_t)W);
+        pix /= (uint32_t)W;
+        const int ih = (int)(pix % (uint32_t)H), n = (int)(pix / (uint32_t)H);
         float g[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) g[j] = 0.f;
@@ -108,11 +110,12 @@ __global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__
     dw_stage_weights(w, wl, C, k * k);
     const int64_t total = (int64_t)N * OH * OW * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        int64_t pix = i / CV;
-        const int ow = (int)(pix % OW);
-        pix /= OW;
-        const int oh = (int)(pix % OH), n = (int)(pix / OH);
+        const uint32_t iu = (uint32_t)i;                       // 32-bit index arithmetic: three 64-bit divisions per vector made these kernels ALU bound
+        const int cv = (int)(iu % (uint32_t)CV);
+        uint32_t pix = iu / (uint32_t)CV;
+        const int ow = (int)(pix % (uint32_t)OW);
+        pix /= (uint32_t)OW;
+        const int oh = (int)(pix % (uint32_t)OH), n = (int)(pix / (uint32_t)OH);
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -150,11 +153,12 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_input_kernel(const T* __rest
     dw_stage_weights(w, wl, C, k * k);
     const int64_t total = (int64_t)N * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        int64_t pix = i / CV;
-        const int iw = (int)(pix % W);
-        pix /= W;
-        const int ih = (int)(pix % H), n = (int)(pix / H);
+        const uint32_t iu = (uint32_t)i;                       // 32-bit index arithmetic: three 64-bit divisions per vector made these kernels ALU bound
+        const int cv = (int)(iu % (uint32_t)CV);
+        uint32_t pix = iu / (uint32_t)CV;
+        const int iw = (int)(pix % (uint32_t)W);
+        pix /= (uint32_t)W;
+        const int ih = (int)(pix % (uint32_t)H), n = (int)(pix / (uint32_t)H);
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -205,9 +209,10 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __res
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t pix = pb + u;
-            const int iw = (int)(pix % W);
-            const int64_t t = pix / W;
-            const int ih = (int)(t % H), n = (int)(t / H);
+            const uint32_t pu = (uint32_t)pix;
+            const int iw = (int)(pu % (uint32_t)W);
+            const uint32_t t = pu / (uint32_t)W;
+            const int ih = (int)(t % (uint32_t)H), n = (int)(t / (uint32_t)H);
             const int oh = ih * s - p + kh, ow = iw * s - p + kw;
             ok[u] = pix < p1 && (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
             ra[u] = ldg16_masked(x, (pix * CV + cv) * 16, ok[u]);
@@ -256,11 +261,12 @@ __global__ __launch_bounds__(256) void upsample2x_add_kernel(const T* __restrict
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        int64_t pix = i / CV;
-        const int w = (int)(pix % W);
-        pix /= W;
-        const int h = (int)(pix % H), n = (int)(pix / H);
+        const uint32_t iu = (uint32_t)i;                       // 32-bit index arithmetic: three 64-bit divisions per vector made these kernels ALU bound
+        const int cv = (int)(iu % (uint32_t)CV);
+        uint32_t pix = iu / (uint32_t)CV;
+        const int w = (int)(pix % (uint32_t)W);
+        pix /= (uint32_t)W;
+        const int h = (int)(pix % (uint32_t)H), n = (int)(pix / (uint32_t)H);
         float lv[V];
         Vec16<T>::load(low + i * V, lv);
 #pragma unroll
@@ -286,11 +292,12 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ d
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = (int)(i % CV);
-        int64_t pix = i / CV;
-        const int w = (int)(pix % W);
-        pix /= W;
-        const int h = (int)(pix % H), n = (int)(pix / H);
+        const uint32_t iu = (uint32_t)i;                       // 32-bit index arithmetic: three 64-bit divisions per vector made these kernels ALU bound
+        const int cv = (int)(iu % (uint32_t)CV);
+        uint32_t pix = iu / (uint32_t)CV;
+        const int w = (int)(pix % (uint32_t)W);
+        pix /= (uint32_t)W;
+        const int h = (int)(pix % (uint32_t)H), n = (int)(pix / (uint32_t)H);
         float acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -315,7 +322,8 @@ static int pool_grid(int64_t total) {
 #define POOL_ARGS_CHECK(name)                                                                                      \
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0 && k > 0 && stride > 0, name ": bad dims"); \
     const int V = dtype == CN_F32 ? 4 : 8;                                                                         \
-    CN_CHECK_ARG(C % V == 0, name ": C=%d must be a multiple of %d", C, V)
+    CN_CHECK_ARG(C % V == 0, name ": C=%d must be a multiple of %d", C, V);                                        \
+    CN_CHECK_ARG((int64_t)N * (H > OH ? H : OH) * (W > OW ? W : OW) * (C / V) < (1ll << 31), name ": more than 2^31 channel vectors (32-bit index arithmetic)")
 
 extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int N, int H, int W, int C, int k, int stride, int pad, int OH,
                               int OW, int dtype, void* stream) {
@@ -396,6 +404,7 @@ extern "C" int cn_upsample2x_add(const void* a, const void* low, void* y, int N,
     const int V = dtype == CN_F32 ? 4 : 8;
     CN_CHECK_ARG(C % V == 0, "cn_upsample2x_add: C=%d must be a multiple of %d", C, V);
     int64_t total = (int64_t)N * H * W * (C / V);
+    CN_CHECK_ARG(total * 4 < (1ll << 31), "cn_upsample2x_add: more than 2^31 channel vectors");
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(upsample2x_add_kernel<T>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)a, (const T*)low, (T*)y, N, H, W, C / V));
     CN_LAUNCH_CHECK("cn_upsample2x_add");
@@ -407,6 +416,7 @@ extern "C" int cn_sumpool2x2(const void* dy, void* dlow, int N, int H, int W, in
     const int V = dtype == CN_F32 ? 4 : 8;
     CN_CHECK_ARG(C % V == 0, "cn_sumpool2x2: C=%d must be a multiple of %d", C, V);
     int64_t total = (int64_t)N * H * W * (C / V);
+    CN_CHECK_ARG(total * 4 < (1ll << 31), "cn_sumpool2x2: more than 2^31 channel vectors");
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(sumpool2x2_kernel<T>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)dy, (T*)dlow, N, H, W, C / V));
     CN_LAUNCH_CHECK("cn_sumpool2x2");
