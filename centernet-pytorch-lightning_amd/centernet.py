@@ -47,6 +47,16 @@ class CenterNet(_Base):
         self.backbone = create_model(arch, compute_dtype=compute_dtype)
         self.down_ratio = 4
 
+    @staticmethod
+    def _sigmoid_focal(criterion, x, target):
+        """`y = sigmoid_clamped(x); loss = criterion(y, target)` (centernet_detection.py:103-106); one autograd node with a
+        single-pass backward when the criterion is this package's FocalLoss."""
+        if hasattr(criterion, "on_logits"):
+            return criterion.on_logits(x, target)
+        from .utils.decode import sigmoid_clamped
+        y = sigmoid_clamped(x)
+        return y, criterion(y, target)
+
     @property
     def compute_dtype(self):
         return self.backbone.compute_dtype

@@ -44,8 +44,8 @@ class CenterNetDetection(CenterNet):
         hm_loss, wh_loss, off_loss = 0, 0, 0
         num_stacks = len(outputs)
         for output in outputs:
-            output["heatmap"] = sigmoid_clamped(output["heatmap"])
-            hm_loss = hm_loss + self.criterion(output["heatmap"], target["heatmap"])
+            output["heatmap"], hm = self._sigmoid_focal(self.criterion, output["heatmap"], target["heatmap"])
+            hm_loss = hm_loss + hm
             wh_loss = wh_loss + self.criterion_width_height(output["width_height"], target["regression_mask"],
                                                             target["indices"], target["width_height"])
             off_loss = off_loss + self.criterion_regression(output["regression"], target["regression_mask"],

@@ -42,16 +42,17 @@ class CenterNetMultiPose(CenterNet):
         hm_loss = wh_loss = off_loss = kp_loss = hm_kp_loss = hm_offset_loss = 0
         num_stacks = len(outputs)
         for output in outputs:
-            output["heatmap"] = sigmoid_clamped(output["heatmap"])
-            output["heatmap_keypoints"] = sigmoid_clamped(output["heatmap_keypoints"])
-            hm_loss = hm_loss + self.criterion(output["heatmap"], target["heatmap"])
+            output["heatmap"], hm = self._sigmoid_focal(self.criterion, output["heatmap"], target["heatmap"])
+            output["heatmap_keypoints"], hm_kp = self._sigmoid_focal(self.criterion_heatmap_keypoints, output["heatmap_keypoints"],
+                                                                     target["heatmap_keypoints"])
+            hm_loss = hm_loss + hm
             wh_loss = wh_loss + self.criterion_width_height(output["width_height"], target["regression_mask"],
                                                             target["indices"], target["width_height"])
             off_loss = off_loss + self.criterion_regression(output["regression"], target["regression_mask"],
                                                             target["indices"], target["regression"])
             kp_loss = kp_loss + self.criterion_keypoints(output["keypoints"], target["keypoints_mask"], target["indices"],
                                                          target["keypoints"])
-            hm_kp_loss = hm_kp_loss + self.criterion_heatmap_keypoints(output["heatmap_keypoints"], target["heatmap_keypoints"])
+            hm_kp_loss = hm_kp_loss + hm_kp
             hm_offset_loss = hm_offset_loss + self.criterion_regression(
                 output["heatmap_keypoints_offset"], target["heatmap_keypoints_mask"], target["heatmap_keypoints_indices"],
                 target["heatmap_keypoints_offset"])

@@ -119,6 +119,34 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
     }
 }
 
+// d loss / d logits in ONE pass: focal backward on p = clamp(s) times the sigmoid/clamp backward s(1-s)[lo <= s <= 1-lo]
+// (utils/losses.py:14-39 through utils/decode.py:43-45).  The two-kernel form writes and re-reads d loss / d p (2 x 335 MB at C3).
+__global__ __launch_bounds__(256) void sigmoid_focal_bwd_kernel(const float* __restrict__ s, const float* __restrict__ gt,
+                                                                const float* __restrict__ out4, const float* __restrict__ gout,
+                                                                float* __restrict__ dz, int64_t n, int64_t HW, int C, int gtB,
+                                                                int gtC, int same, float lo) {
+    const float np = out4[3], hi = 1.f - lo;
+    const float scale = -gout[0] / (np == 0.f ? 1.f : np);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float sv = s[i];
+        const float g = gt[same ? i : gt_index(i, HW, C, gtB, gtC)];
+        float d = 0.f;
+        if (sv >= lo && sv <= hi) {                    // outside, the clamp blocks the gradient (and p == the clamp bound)
+            const float p = sv;
+            if (g == 1.f) {
+                const float q = 1.f - p;
+                d = q * q / p - 2.f * q * logf(p);
+            } else if (g < 1.f) {
+                const float w = 1.f - g;
+                const float w2 = w * w;
+                d = (w2 * w2) * (2.f * p * logf(1.f - p) - p * p / (1.f - p));
+            }
+            d = (d * scale) * p * (1.f - p);           // same association as the two kernels: (d * scale), then * p * (1 - p)
+        }
+        dz[i] = d;
+    }
+}
+
 static int focal_grid(int64_t n) {
     int64_t g = (n + 256 * 8 - 1) / (256 * 8);
     return (int)(g > FOCAL_MAX_BLOCKS ? FOCAL_MAX_BLOCKS : (g < 1 ? 1 : g));
@@ -148,6 +176,18 @@ extern "C" int cn_focal_bwd(const float* pred, const float* gt, const float* out
     hipLaunchKernelGGL(focal_bwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, pred, gt, out4,
                        gout, dpred, n, HW, C, gtB, gtC, (int)(gtB == B && gtC == C));
     CN_LAUNCH_CHECK("cn_focal_bwd");
+    return CN_OK;
+}
+
+extern "C" int cn_sigmoid_focal_bwd(const float* x_sig, const float* gt, const float* out4, const float* gout, float* dz, int B, int C,
+                                    int64_t HW, int gtB, int gtC, float lo, void* stream) {
+    CN_CHECK_ARG(x_sig && gt && out4 && gout && dz && B > 0 && C > 0 && HW > 0, "cn_sigmoid_focal_bwd: bad args");
+    CN_CHECK_ARG((gtB == B || gtB == 1) && (gtC == C || gtC == 1), "cn_sigmoid_focal_bwd: gt does not broadcast");
+    const int64_t n = (int64_t)B * C * HW;
+    int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(sigmoid_focal_bwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, x_sig, gt, out4,
+                       gout, dz, n, HW, C, gtB, gtC, (int)(gtB == B && gtC == C), lo);
+    CN_LAUNCH_CHECK("cn_sigmoid_focal_bwd");
     return CN_OK;
 }
 

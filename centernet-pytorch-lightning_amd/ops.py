@@ -753,6 +753,44 @@ class FocalLossFn(Function):
         return dpred, None
 
 
+class SigmoidFocalFn(Function):
+    """sigmoid_clamped (utils/decode.py:43-45) + FocalLoss (utils/losses.py:14-39) as ONE autograd node: the forward runs the
+    same two kernels (x becomes sigmoid(x) in place, y the clamped copy, the loss is computed on y), the backward is a single pass
+    instead of focal-backward -> 335 MB of d loss / d p -> sigmoid/clamp-backward."""
+
+    @staticmethod
+    def forward(ctx, x, gt, lo):
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        y = torch.empty_like(x)
+        call("cn_sigmoid_clamp_fwd", x, y, x.numel(), float(lo))
+        gt = gt.contiguous().float()
+        B, C = x.shape[:2]
+        HW = x[0, 0].numel()
+        out = torch.empty(4, dtype=torch.float32, device=x.device)
+        n = _hip.query("cn_focal_workspace_bytes", x.numel())
+        ws = _hip.workspace(n, x.device, "focal")
+        call("cn_focal_fwd", y, gt, out, B, C, HW, gt.shape[0], gt.shape[1], ws, n)
+        ctx.mark_dirty(x)
+        ctx.mark_non_differentiable(y)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, gt, out)
+        ctx.lo = float(lo)
+        return x, y, out[0]
+
+    @staticmethod
+    def backward(ctx, dx_unused, dy_unused, g):
+        s, gt, out = ctx.saved_tensors
+        if dx_unused is not None:
+            raise RuntimeError("gradient through the in-place sigmoid alias is not supported")
+        if g is None:
+            return None, None, None
+        B, C = s.shape[:2]
+        dz = torch.empty_like(s)
+        call("cn_sigmoid_focal_bwd", s, gt, out, g.contiguous().float().reshape(1), dz, B, C, s[0, 0].numel(), gt.shape[0], gt.shape[1],
+             ctx.lo)
+        return dz, None, None
+
+
 class GatherL1Fn(Function):
     """utils/losses.py:53-63 / 81-91: masked L1 between rows gathered at `ind` and the targets."""
 

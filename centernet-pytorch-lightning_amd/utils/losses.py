@@ -1,4 +1,5 @@
 """Loss modules with the reference's names (CenterNet/utils/losses.py) on the HIP loss kernels (csrc/loss.hip)."""
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -16,6 +17,16 @@ class FocalLoss(nn.Module):
 
     def forward(self, out, target):
         return self.neg_loss(out, target)
+
+    def on_logits(self, x, target, clamp=1e-4):
+        """`y = sigmoid_clamped(x); loss = self(y, target)` (centernet_detection.py:103-106) as one autograd node with a
+        single-pass backward.  Returns (y, loss); x holds sigmoid(x) afterwards, exactly as after sigmoid_clamped."""
+        if self.neg_loss is not _neg_loss or not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
+            from .decode import sigmoid_clamped
+            y = sigmoid_clamped(x, clamp)
+            return y, self(y, target)
+        _, y, loss = ops.SigmoidFocalFn.apply(x, target, clamp)
+        return y, loss
 
 
 class RegL1Loss(nn.Module):

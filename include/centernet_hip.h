@@ -205,6 +205,10 @@ int cn_focal_fwd(const float* pred, const float* gt, float* out4, int B, int C, 
 /* dpred = gout[0] * dloss/dpred, using out4 from the forward */
 int cn_focal_bwd(const float* pred, const float* gt, const float* out4, const float* gout, float* dpred,
                  int B, int C, int64_t HW, int gtB, int gtC, void* stream);
+/* cn_focal_bwd followed by cn_sigmoid_clamp_bwd in one pass (the training path always chains them: centernet_detection.py:103-106):
+ * x_sig = sigmoid(logits) as left in place by cn_sigmoid_clamp_fwd, out4 / gout as for cn_focal_bwd, dz = d loss / d logits. */
+int cn_sigmoid_focal_bwd(const float* x_sig, const float* gt, const float* out4, const float* gout, float* dz, int B, int C,
+                         int64_t HW, int gtB, int gtC, float lo, void* stream);
 /* masked gather-L1 (utils/losses.py:53-63, 81-91): feat NCHW fp32 [B,C,HW]; ind int64 [B,N]; mask uint8 [B,N]
  * (mask_has_c == 0) or [B,N,C]; target fp32 [B,N,C].  out[0] = loss, out[1] = sum|.|, out[2] = sum(mask). */
 int cn_gather_l1_fwd(const float* feat, const int64_t* ind, const uint8_t* mask, const float* target, float* out3,

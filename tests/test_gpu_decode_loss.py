@@ -284,3 +284,26 @@ def test_empty_inputs_losses_and_encoders():
     ref = ops_ref.focal_loss(ops_ref.sigmoid_clamped(logits.clone()), torch.zeros(B, 80, 128, 128))
     hm.backward()
     assert hm.item() == pytest.approx(ref.item(), rel=1e-4) and bool(torch.isfinite(lg.grad).all())
+
+
+def test_fused_sigmoid_focal_matches_two_step():
+    """FocalLoss.on_logits (one autograd node, single-pass backward) == sigmoid_clamped followed by FocalLoss: same clamped map,
+    same in-place sigmoid, same loss, same d loss / d logits (incl. saturated logits where the clamp blocks the gradient)."""
+    from centernet_amd.utils.decode import sigmoid_clamped
+    from centernet_amd.utils.losses import FocalLoss
+    _, tgt = synth.ctdet_batch(62, 2)
+    gt = tgt["heatmap"].to(DEV)
+    logits = rng.t_normal(62, "lg", (2, 80, 128, 128)) * 6.0 - 2.19          # |z| up to ~30: both clamp bounds are hit
+    a = logits.to(DEV).requires_grad_(True)
+    xa = a.clone()
+    ya = sigmoid_clamped(xa)
+    la = FocalLoss()(ya, gt)
+    (3.0 * la).backward()
+    b = logits.to(DEV).requires_grad_(True)
+    xb = b.clone()
+    yb, lb = FocalLoss().on_logits(xb, gt)
+    (3.0 * lb).backward()
+    assert torch.equal(ya, yb) and torch.equal(xa, xb), "clamped copy and in-place sigmoid"
+    assert la.item() == lb.item()
+    assert float((yb == 1e-4).float().mean()) > 0.01 and float((yb == 1 - 1e-4).float().mean()) > 1e-4
+    assert torch.equal(a.grad, b.grad), "single-pass backward is bit-identical to the two kernels"
