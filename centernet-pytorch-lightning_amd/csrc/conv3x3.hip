@@ -261,15 +261,22 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvGeom g) {
 // = 1 KB contiguous each — and issues the 1 + 2 + 2 + 4 MFMAs of the four output parity classes (taps whose offset divides
 // the stride; the zero-stuffed positions are never touched).  D[ci = 4*(lane>>4)+r][px]: 8-byte stores, the even and the
 // odd column of a pair land next to each other.
+template <int KC, int NB>      // dy channels = 32*KC, dx channels = 16*NB  (1,1: DLA level1; 2,2: level2's 32 <- 64)
 __global__ __launch_bounds__(256) void dgrad_s2_c32to16_kernel(const ConvGeom g) {
+    constexpr int CO = 32 * KC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, kc = lane >> 4;
     const bf16_t* __restrict__ DY = reinterpret_cast<const bf16_t*>(g.x);
     const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(g.w);
     bf16_t* __restrict__ DX = reinterpret_cast<bf16_t*>(g.y);
-    bf16x8_t wa[9];                                        // [ci = px][co = 8*kc..+7] of weight tap t = kh*3 + kw
+    bf16x8_t wa[NB][KC][9];                                // [ci = 16*nb + px][co = 32*k + 8*kc..+7] of weight tap t = kh*3 + kw
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wa[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Wp + (int64_t)px * g.ktot + t * 32 + 8 * kc));
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                wa[nb][k][t] = __builtin_bit_cast(bf16x8_t, ldg16(Wp + (int64_t)(16 * nb + px) * g.ktot + t * CO + 32 * k + 8 * kc));
     const int segs = (g.W + 15) / 16;                      // 16 dy columns -> 32 dx columns
     const int64_t strips = (int64_t)g.N * g.H * segs;      // one strip = one dy row r of one image -> dx rows 2r, 2r+1
 #pragma unroll 1
@@ -278,45 +285,53 @@ __global__ __launch_bounds__(256) void dgrad_s2_c32to16_kernel(const ConvGeom g)
         const int64_t row = sidx / segs;                   // n * H + r
         const int r = (int)(row % g.H);
         const int c0 = seg * 16 + px;                      // dy column of this lane at shift 0
-        uint4 b[2][2];
+        bf16x8_t b[2][2][KC];
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int dw = 0; dw < 2; ++dw) {
                 const bool ok = r + dh < g.H && c0 + dw < g.W;
-                b[dh][dw] = ldg16_masked(DY, (((row + dh) * g.W + c0 + dw) * g.x_ld + 8 * kc) * 2, ok);
+#pragma unroll
+                for (int k = 0; k < KC; ++k)
+                    b[dh][dw][k] = __builtin_bit_cast(bf16x8_t, ldg16_masked(DY, (((row + dh) * g.W + c0 + dw) * g.x_ld + 32 * k + 8 * kc) * 2, ok));
             }
-        const bf16x8_t b00 = __builtin_bit_cast(bf16x8_t, b[0][0]), b01 = __builtin_bit_cast(bf16x8_t, b[0][1]);
-        const bf16x8_t b10 = __builtin_bit_cast(bf16x8_t, b[1][0]), b11 = __builtin_bit_cast(bf16x8_t, b[1][1]);
-        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-        // dx[2r + ph][2c + pw] = sum over taps (kh, kw) with ph + 1 - kh, pw + 1 - kw even of W[kh][kw]^T dy[r + (ph+1-kh)/2][c + (pw+1-kw)/2]
-        f32x4_t ee = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[4], b00, z, 0, 0, 0);                 // (1,1)
-        f32x4_t eo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[3], b01, z, 0, 0, 0);                 // (1,0): dw = 1
-        eo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[5], b00, eo, 0, 0, 0);                        // (1,2): dw = 0
-        f32x4_t oe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1], b10, z, 0, 0, 0);                 // (0,1): dh = 1
-        oe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[7], b00, oe, 0, 0, 0);                        // (2,1): dh = 0
-        f32x4_t oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0], b11, z, 0, 0, 0);                 // (0,0)
-        oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[2], b10, oo, 0, 0, 0);                        // (0,2)
-        oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[6], b01, oo, 0, 0, 0);                        // (2,0)
-        oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[8], b00, oo, 0, 0, 0);                        // (2,2)
         const int64_t n = (row - r) / g.H;
-        auto put = [&](const f32x4_t& v, int ph, int pw) {
-            const int oh = 2 * r + ph, ow = 2 * c0 + pw;
-            if (oh < g.OH && ow < g.OW)
-                *reinterpret_cast<uint2*>(DX + ((n * g.OH + oh) * g.OW + ow) * g.y_ld + 4 * kc) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
-        };
-        put(ee, 0, 0); put(eo, 0, 1); put(oe, 1, 0); put(oo, 1, 1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4_t ee = {0.f, 0.f, 0.f, 0.f}, eo = ee, oe = ee, oo = ee;
+            // dx[2r + ph][2c + pw] = sum over taps (kh, kw) with ph + 1 - kh, pw + 1 - kw even of W[kh][kw]^T dy[r + (ph+1-kh)/2][c + (pw+1-kw)/2]
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                ee = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][4], b[0][0][k], ee, 0, 0, 0);                 // (1,1)
+                eo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][3], b[0][1][k], eo, 0, 0, 0);                 // (1,0): dw = 1
+                eo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][5], b[0][0][k], eo, 0, 0, 0);                 // (1,2): dw = 0
+                oe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][1], b[1][0][k], oe, 0, 0, 0);                 // (0,1): dh = 1
+                oe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][7], b[0][0][k], oe, 0, 0, 0);                 // (2,1): dh = 0
+                oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][0], b[1][1][k], oo, 0, 0, 0);                 // (0,0)
+                oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][2], b[1][0][k], oo, 0, 0, 0);                 // (0,2)
+                oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][6], b[0][1][k], oo, 0, 0, 0);                 // (2,0)
+                oo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][k][8], b[0][0][k], oo, 0, 0, 0);                 // (2,2)
+            }
+            auto put = [&](const f32x4_t& v, int ph, int pw) {
+                const int oh = 2 * r + ph, ow = 2 * c0 + pw;
+                if (oh < g.OH && ow < g.OW)
+                    *reinterpret_cast<uint2*>(DX + ((n * g.OH + oh) * g.OW + ow) * g.y_ld + 16 * nb + 4 * kc) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+            };
+            put(ee, 0, 0); put(eo, 0, 1); put(oe, 1, 0); put(oo, 1, 1);
+        }
     }
 }
 
-// caller guarantees: bf16, transposed 3x3 / stride 2 / pad 1, 32 -> 16 channels, OH = 2H, OW = 2W, no bias / residual / ReLU
+// caller guarantees: bf16, transposed 3x3 / stride 2 / pad 1, (32 -> 16) or (64 -> 32) channels, OH = 2H, OW = 2W, no bias / residual / ReLU
 bool dgrad_s2_c32to16_launch(const ConvGeom& g, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_CONV_C16") != nullptr;
-    if (disabled || (g.x_ld & 7) || g.y_ld != 16) return false;
+    if (disabled || (g.x_ld & 7) || g.y_ld != g.Co) return false;
     const int64_t strips = (int64_t)g.N * g.H * ((g.W + 15) / 16);
     int64_t blocks = (strips + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dgrad_s2_c32to16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (g.Ci == 32 && g.Co == 16) hipLaunchKernelGGL((dgrad_s2_c32to16_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else if (g.Ci == 64 && g.Co == 32) hipLaunchKernelGGL((dgrad_s2_c32to16_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else return false;
     return true;
 }
 

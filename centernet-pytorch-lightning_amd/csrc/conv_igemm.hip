@@ -453,7 +453,7 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     int ncls = build_geom(g, KH, KW, stride, pad, transposed);
     if (ncls < 0) CN_UNSUPPORTED("cn_conv2d_fwd: kernel %dx%d stride %d not supported", KH, KW, stride);
     if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);
-    if (transposed && dtype == CN_BF16 && out_dtype == dtype && KH == 3 && KW == 3 && stride == 2 && pad == 1 && Ci == 32 && Co == 16 &&
+    if (transposed && dtype == CN_BF16 && out_dtype == dtype && KH == 3 && KW == 3 && stride == 2 && pad == 1 && ((Ci == 32 && Co == 16) || (Ci == 64 && Co == 32)) &&
         OH == 2 * H && OW == 2 * W && !bias && !residual && !relu && dgrad_s2_c32to16_launch(g, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_conv2d_fwd(dgrad s2 32->16)");
         return CN_OK;

@@ -48,7 +48,8 @@ CONVS = [  # N,H,W,Ci,Co,k,s,p,bias,relu
     (1, 33, 129, 16, 16, 3, 1, 1, False, False),
     (2, 17, 19, 32, 48, 3, 1, 1, True, True),
     (1, 16, 16, 64, 128, 3, 2, 1, False, False),
-    (2, 38, 70, 16, 32, 3, 2, 1, False, False),     # level1 shape: its data gradient runs on dgrad_s2_c32to16_kernel
+    (2, 38, 70, 16, 32, 3, 2, 1, False, False),     # level1 shape: its data gradient runs on dgrad_s2_c32to16_kernel<1,1>
+    (2, 21, 37, 32, 64, 3, 2, 1, False, False),     # level2 shape: dgrad_s2_c32to16_kernel<2,2> (odd sizes: ragged strips)
     (1, 15, 13, 64, 64, 3, 2, 1, False, False),
     (2, 8, 8, 128, 256, 1, 1, 0, False, False),
     (2, 16, 16, 64, 128, 1, 2, 0, False, False),
