@@ -257,9 +257,11 @@ class Conv2dFn(Function):
             wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
             if Cx != Ci:
                 raise RuntimeError("data gradient through a channel-padded conv input is not supported")
-            if (KH == 1 and KW == 1 and stride == 1 and pad == 0 and Co <= 4 and x.dtype == torch.bfloat16
-                    and Ci in _SMALLK_WIDTHS and not _os.environ.get("CN_DISABLE_CONV_SMALLK")):
-                # 1- / 2-channel heads: a 16-wide padded contraction is pure overhead on the GEMM kernel -> streaming VALU kernel
+            small = Co <= 4 and Ci in _SMALLK_WIDTHS                     # 1- / 2-channel heads -> streaming VALU kernel
+            mid = 4 < Co <= 96 and Ci == 256 and dy.shape[-1] <= 96      # class / keypoint heads -> streaming MFMA kernel
+            if (KH == 1 and KW == 1 and stride == 1 and pad == 0 and (small or mid) and x.dtype == torch.bfloat16
+                    and not _os.environ.get("CN_DISABLE_CONV_SMALLK")):
+                # a short contraction with a 256-wide output is epilogue / overhead bound on the GEMM kernel
                 dx = torch.empty((N, H, W, Ci), dtype=x.dtype, device=x.device)
                 call("cn_conv1x1_smallk", dy, wpd, x if ctx.mask_dx else None, dx, N * H * W, Co, dy.shape[-1], Ci, Ci,
                      x.shape[-1] if ctx.mask_dx else 0, 2 if ctx.mask_dx else 0, dtype_code(x.dtype))

@@ -348,12 +348,15 @@ def test_adam_matches_torch():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-def test_head_conv_fused_relu_backward(dt):
+@pytest.mark.parametrize("sizes", [(64, 32, 5), (64, 256, 2), (64, 256, 80), (32, 256, 17), (32, 256, 34)])
+def test_head_conv_fused_relu_backward(dt, sizes):
     """heads.py:4-25: conv3x3+ReLU -> conv1x1; the hidden ReLU's backward runs as the mask mode (relu=2) of the 1x1
-    conv's data-gradient epilogue.  Reference: plain torch autograd on the same (rounded) operands."""
+    conv's data-gradient epilogue (GEMM kernel; 256-wide hidden layers in bf16: the VALU stream for 1-/2-channel heads, the MFMA
+    stream for 17 .. 96 channels).  Reference: plain torch autograd on the same (rounded) operands."""
     from centernet_amd.models.heads import HeadConv
     torch.manual_seed(0)
-    N, H, W, Cin, Cmid, Cout = 2, 9, 11, 64, 32, 5
+    N, H, W = 2, 9, 11
+    Cin, Cmid, Cout = sizes
     head = HeadConv(Cout, Cin, Cmid).to(DEV)
     x = rng.t_normal(21, "hx", (N, Cin, H, W))
     with torch.no_grad():
