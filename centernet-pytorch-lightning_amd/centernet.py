@@ -88,21 +88,24 @@ class CenterNet(_Base):
     def loss(self, outputs, target):
         return 0, {}
 
-    def training_step(self, batch, batch_idx):
+    def _loss_and_log(self, batch, stage):
+        """forward + loss + the reference's log keys (`<stage>_loss`, `<stage>/<term>`; validation logs per epoch, synced)."""
         img, target = batch
-        loss, loss_stats = self.loss(self(img), target)
-        self.log("train_loss", loss, on_epoch=True)
-        for key, value in loss_stats.items():
-            self.log(f"train/{key}", value)
-        return loss
+        loss, terms = self.loss(self(img), target)
+        per_epoch = {"on_epoch": True, "sync_dist": True} if stage == "val" else {}
+        self.log(f"{stage}_loss", loss, **{"on_epoch": True, **per_epoch})
+        for term, value in terms.items():
+            self.log(f"{stage}/{term}", value, **per_epoch)
+        return loss, terms
+
+    def training_step(self, batch, batch_idx):
+        """centernet.py:70-80."""
+        return self._loss_and_log(batch, "train")[0]
 
     def validation_step(self, batch, batch_idx):
-        img, target = batch
-        loss, loss_stats = self.loss(self(img), target)
-        self.log("val_loss", loss, on_epoch=True, sync_dist=True)
-        for name, value in loss_stats.items():
-            self.log(f"val/{name}", value, on_epoch=True, sync_dist=True)
-        return {"loss": loss, "loss_stats": loss_stats}
+        """centernet.py:82-92."""
+        loss, terms = self._loss_and_log(batch, "val")
+        return {"loss": loss, "loss_stats": terms}
 
     def configure_optimizers(self):
         """centernet.py:94-105: Adam(lr) + MultiStepLR(milestones) stepped per epoch.  The optimizer is this package's

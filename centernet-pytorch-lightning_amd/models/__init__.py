@@ -1,24 +1,32 @@
-"""Backbone plugin registry — same surface as CenterNet/models/__init__.py:6-19."""
+"""Backbone plug-in point (surface of CenterNet/models/__init__.py:6-19: `_model_factory`, `create_model`).
+
+An architecture string is `<family>[_<depth>]`; the family picks a factory, the depth is passed through as `num_layers`.
+Every factory returns a module that maps the NCHW fp32 image to a list of NHWC activation maps (one per stack) with
+`.out_channels` channels at stride 4 — what `heads.CenterHead` consumes.
+"""
 import torch
 
-from .backbones.msra_resnet import get_pose_net
-from .backbones.pose_dla_dcn import get_pose_net as get_dla_dcn
-from .backbones.resnet_dcn import get_pose_net as get_pose_net_dcn
-from .backbones.large_hourglass import get_large_hourglass_net
+from .backbones import large_hourglass, msra_resnet, pose_dla_dcn, resnet_dcn
+
+_model_factory = {}
 
 
+def _register(family, factory):
+    _model_factory[family] = factory
 
-_model_factory = {
-    "res": get_pose_net,          # ResNet + deconv
-    "dla": get_dla_dcn,           # DLA-34 + DCNv2
-    "resdcn": get_pose_net_dcn,   # ResNet + DCNv2 / deconv up path
-    "hourglass": get_large_hourglass_net,   # 2-stack Hourglass-104
-}
+
+_register("res", msra_resnet.get_pose_net)                          # ResNet trunk + 3 full deconvs
+_register("resdcn", resnet_dcn.get_pose_net)                        # ResNet trunk + (DCNv2, depthwise-free deconv) x 3
+_register("dla", pose_dla_dcn.get_pose_net)                         # DLA-34 + DCNv2 up-path
+_register("hourglass", large_hourglass.get_large_hourglass_net)     # 2-stack Hourglass-104
+
+
+def _split_arch(arch):
+    family, _, depth = arch.partition("_")
+    return family, (int(depth) if depth else 0)
 
 
 def create_model(arch, compute_dtype=torch.bfloat16, **kwargs):
-    """`"res_18"` -> ("res", 18) -> factory(num_layers=18).  Backbones take the NCHW fp32 image and return a list
-    of NHWC activation maps with `.out_channels` channels at stride 4 (consumed by heads.CenterHead)."""
-    num_layers = int(arch[arch.find("_") + 1:]) if "_" in arch else 0
-    family = arch[: arch.find("_")] if "_" in arch else arch
-    return _model_factory[family](num_layers=num_layers, compute_dtype=compute_dtype, **kwargs)
+    """`"res_18"` -> family "res", num_layers 18.  Unknown families raise KeyError like the reference's dict lookup."""
+    family, depth = _split_arch(arch)
+    return _model_factory[family](num_layers=depth, compute_dtype=compute_dtype, **kwargs)

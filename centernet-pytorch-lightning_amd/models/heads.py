@@ -1,49 +1,63 @@
-"""Task heads (reference: CenterNet/models/heads.py).  Each head: 3x3 conv(+bias, ReLU fused in the GEMM
-epilogue) -> 1x1 conv(+bias); outputs leave the NHWC engine as public NCHW fp32 maps [B, C, H/4, W/4]."""
+"""Task heads on the NHWC conv engine (surface of CenterNet/models/heads.py: `HeadConv`, `CenterHead`, checkpoint keys
+`<head>.fc.0.*` / `<head>.fc.2.*`).
+
+A head is conv3x3(+bias) -> ReLU -> conv1x1(+bias).  Here the ReLU lives in the first conv's GEMM epilogue and its backward
+mask in the second conv's data-gradient epilogue (`defer_relu_bwd` / `mask_dx`), so a head is two forward launches and
+the hidden activation is never re-read just to be masked; the result leaves the engine as a public NCHW fp32 map
+[B, C, H/4, W/4] (`ops.ToNCHWFn`).
+"""
 import torch.nn as nn
 
 from .. import nn as hnn
 from .. import ops
 
+PRIOR_LOGIT = -2.19          # sigmoid^-1(0.1): bias of every `heatmap*` head's last conv (heads.py:45-50)
+
+
+def _init_like_reference(name, head):
+    """heads.py:45-50 / 19-25: heat-map heads only get the prior bias (their weights keep the framework default);
+    every other head is N(0, 0.001) with zero biases."""
+    hidden, out = head.fc[0], head.fc[2]
+    if name.startswith("heatmap"):
+        out.bias.data.fill_(PRIOR_LOGIT)
+        return
+    for conv in (hidden, out):
+        nn.init.normal_(conv.weight, std=0.001)
+        nn.init.zeros_(conv.bias)
+
 
 class HeadConv(nn.Module):
-    """heads.py:4-25."""
+    """heads.py:4-25.  `fc` keeps the reference's Sequential indices (slot 1 is where its nn.ReLU sits)."""
 
     def __init__(self, out_channels, intermediate_channel, head_conv):
         super().__init__()
         self.out_channels = out_channels
-        self.fc = nn.Sequential(hnn.Conv2d(intermediate_channel, head_conv, 3, 1, 1, bias=True), nn.Identity(),
-                                hnn.Conv2d(head_conv, out_channels, 1, 1, 0, bias=True))
+        hidden = hnn.Conv2d(intermediate_channel, head_conv, 3, stride=1, padding=1, bias=True)
+        out = hnn.Conv2d(head_conv, out_channels, 1, stride=1, padding=0, bias=True)
+        self.fc = nn.Sequential(hidden, nn.Identity(), out)
 
     def forward(self, x):
-        # the hidden ReLU's backward mask is applied in the 1x1 conv's data-gradient epilogue (no separate relu_bwd pass)
-        y = self.fc[2](self.fc[0](x, relu=True, defer_relu_bwd=True), mask_dx=True)
+        h = self.fc[0](x, relu=True, defer_relu_bwd=True)      # ReLU in the epilogue; its backward is owed to ...
+        y = self.fc[2](h, mask_dx=True)                        # ... this conv's data-gradient epilogue
         return ops.ToNCHWFn.apply(y, self.out_channels)
 
     def fill_fc_weights(self):
-        for m in self.modules():
-            if isinstance(m, hnn.Conv2d):
-                nn.init.normal_(m.weight, std=0.001)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
+        _init_like_reference("", self)
 
 
 class CenterHead(nn.Module):
-    """heads.py:28-50: dict of heads in declaration order; `heatmap*` heads get a -2.19 final bias."""
+    """heads.py:28-50: one `HeadConv` per entry of `heads` (declaration order is the output order)."""
 
     def __init__(self, heads, intermediate_channel, head_conv):
         super().__init__()
         self.heads = heads
-        for name, out_channel in heads.items():
-            setattr(self, name, HeadConv(out_channel, intermediate_channel, head_conv))
+        for name, channels in heads.items():
+            self.add_module(name, HeadConv(channels, intermediate_channel, head_conv))
         self.init_weights()
 
     def forward(self, x):
-        return {name: getattr(self, name)(x) for name in self.heads.keys()}
+        return {name: self._modules[name](x) for name in self.heads}
 
     def init_weights(self):
-        for name in self.heads.keys():
-            if name.startswith("heatmap"):
-                getattr(self, name).fc[-1].bias.data.fill_(-2.19)
-            else:
-                getattr(self, name).fill_fc_weights()
+        for name in self.heads:
+            _init_like_reference(name, self._modules[name])
