@@ -232,6 +232,7 @@ class TrainStep:
 
     def _begin_packs(self):
         """one launch packs every weight operand of the step (recorded during the first step)"""
+        SideGrads.fwd_order = 0
         if not self.opt.flat_p.is_cuda:
             return
         PackArena.current = self._packs

@@ -148,6 +148,29 @@ class SideGrads:
         return on
 
     thin = 1536
+    fwd_order = 0         # convs seen in this step's forward pass (TrainStep resets it): the first few are the LAST of backward
+    TAIL_LAYERS = 3
+
+    @classmethod
+    def next_order(cls):
+        cls.fwd_order += 1
+        return cls.fwd_order - 1
+
+    @classmethod
+    def wide_if_tail(cls, fn, order):
+        """Weight gradients of the network's first layers are produced when the data-gradient chain is (all but) finished:
+        nothing is left to share the GPU with, so they get a full-width grid instead of the background-shaped one (the
+        last millisecond of a step was three thin kernels running one after the other on an otherwise idle GPU)."""
+        if order >= cls.TAIL_LAYERS or cls.thin >= 1536 or _os.environ.get("CN_THIN_TAIL"):
+            return fn
+
+        def wide():
+            call("cn_set_wgrad_parallelism", 1536)
+            try:
+                fn()
+            finally:
+                call("cn_set_wgrad_parallelism", cls.thin)
+        return wide
 
     @classmethod
     def usable(cls, *params):
@@ -181,15 +204,7 @@ class SideGrads:
     @classmethod
     def join(cls):
         if cls.stream is not None:
-            # whatever is still pending was produced by the LAST backward op (the stem's weight gradient): the data-gradient
-            # chain is finished, nothing is left to protect, so this tail runs with a full-width grid (it ended the step alone:
-            # 0.58 ms at 128 workgroups)
-            if cls.pending and cls.thin < 1536 and not _os.environ.get("CN_THIN_TAIL"):
-                call("cn_set_wgrad_parallelism", 1536)
-                cls._flush()
-                call("cn_set_wgrad_parallelism", cls.thin)
-            else:
-                cls._flush()
+            cls._flush()
         if cls.active and cls.stream is not None:
             torch.cuda.current_stream().wait_stream(cls.stream)
         cls.active = False
@@ -242,6 +257,7 @@ class Conv2dFn(Function):
         ctx.cfg = (stride, pad, relu and not defer_relu_bwd, bias is not None)
         ctx.mask_dx = mask_dx
         ctx.bias_ref = bias
+        ctx.order = SideGrads.next_order()
         return y
 
     @staticmethod
@@ -260,7 +276,7 @@ class Conv2dFn(Function):
             def side_work(x=x, dy=dy, bias=ctx.bias_ref):
                 dwp, _ = _wgrad(x, dy, Co, KH, KW, stride, pad, False, db_into=bias.grad if has_bias else None)
                 unpack_wgrad(dwp, Co, Ci, KH, KW, into=weight.grad)
-            SideGrads.submit(side_work, x, dy)
+            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), x, dy)
         elif ctx.needs_input_grad[1]:
             dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, has_bias and ctx.needs_input_grad[2])
             dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
@@ -345,6 +361,7 @@ class StemConvFn(Function):
              dtype_code(dtype))
         ctx.save_for_backward(img, weight)
         ctx.cfg = (stride, pad)
+        ctx.order = SideGrads.next_order()
         return y
 
     @staticmethod
@@ -358,7 +375,7 @@ class StemConvFn(Function):
             def side_work(img=img, dy=dy):  # the kernel accumulates with atomics: deposit straight into weight.grad
                 call("cn_stem_conv_wgrad", img, dy, weight.grad, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2],
                      dtype_code(dy.dtype))
-            SideGrads.submit(side_work, img, dy)
+            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy)
             return None, None, None, None, None
         dw = torch.zeros_like(weight, dtype=torch.float32)
         call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))

@@ -17,3 +17,7 @@ for n, s, e, q in seg[:-1]:
 print("step span ms:", (rows[i1][2] - rows[i0][2]) / 1e6)
 for q, (e, n) in sorted(last.items(), key=lambda kv: kv[1][0]):
     print(f"queue {q}: last kernel ends {(t_adam - e) / 1e3:8.1f} us before adam starts; busy {busy[q] / 1e6:6.2f} ms; last = {n[:60]}")
+
+print("last kernels before the optimizer:")
+for n, s_, e, q in seg[-9:-1]:
+    print(f"  q{q} start {-(t_adam - s_) / 1e3:9.1f} us  dur {(e - s_) / 1e3:8.1f} us  {n[:70]}")
