@@ -158,10 +158,9 @@ class GradSync:
         """Non-overlapped variant (used between the two captured graphs): every bucket, then wait."""
         if not self.exchange:
             return
-        works = [dist.all_reduce(self.opt.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for s, e, _ in self.buckets]
-        for w in works:
-            w.wait()
+        # nothing to overlap with between the two graphs: ONE collective over the whole flat gradient (79 MB for DLA-34) pays
+        # the ring latency once instead of once per bucket
+        dist.all_reduce(self.opt.flat_g, op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_state(self, module):
         """DDP init: parameters (flat) + buffers from rank 0."""

@@ -103,7 +103,7 @@ def test_flat_adam_cpu_matches_torch_adam():
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
 
 
-def _ddp_worker(rank, world, port, out):
+def _ddp_worker(rank, world, port, out, between_graphs=False):
     import torch.distributed as dist
     from centernet_amd.engine import FlatAdam, GradSync
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -113,7 +113,7 @@ def _ddp_worker(rank, world, port, out):
     dead = torch.nn.Linear(3, 3)                        # never used: no gradient, like the reference's dead DLA projections
     params = list(net.parameters()) + list(dead.parameters())
     opt = FlatAdam(params, lr=1e-2)
-    sync = GradSync(opt, bucket_bytes=256)
+    sync = GradSync(opt, bucket_bytes=256, hooks=not between_graphs)      # graph mode: no hooks, one collective after backward
     sync.broadcast_state(net)
     assert len(sync.buckets) > 2
     for it in range(3):
@@ -121,19 +121,24 @@ def _ddp_worker(rank, world, port, out):
         x = torch.randn(4, 16, generator=g)
         opt.zero_grad()
         loss = net(x).square().mean()
-        sync.begin(); loss.backward(); sync.finish()
+        if between_graphs:
+            loss.backward(); sync.allreduce_all()
+        else:
+            sync.begin(); loss.backward(); sync.finish()
         opt.step()
     out[rank] = opt.flat_p.clone()
     dist.destroy_process_group()
 
 
-def test_gradient_buckets_over_gloo_world2():
-    """N>1 path on CPU: ranks end bit-identical, and equal to one process that averages the two gradients itself."""
+@pytest.mark.parametrize("between_graphs", [False, True])
+def test_gradient_buckets_over_gloo_world2(between_graphs):
+    """N>1 path on CPU: ranks end bit-identical, and equal to one process that averages the two gradients itself — with the
+    backward-overlapped buckets of eager mode and with the single collective graph mode runs between its two hipGraphs."""
     from centernet_amd.engine import FlatAdam
-    port = 29000 + os.getpid() % 2000
+    port = 29000 + os.getpid() % 2000 + (7 if between_graphs else 0)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, port, out, between_graphs), nprocs=2, join=True)
     assert torch.equal(out[0], out[1])
     torch.manual_seed(100)
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 8))
