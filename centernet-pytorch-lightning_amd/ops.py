@@ -165,7 +165,7 @@ class SideGrads:
             return fn
 
         def wide():
-            call("cn_set_wgrad_parallelism", 1536)
+            call("cn_set_wgrad_parallelism", int(_os.environ.get("CN_TAIL_BLOCKS", 1536)))
             try:
                 fn()
             finally:
