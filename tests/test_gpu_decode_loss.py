@@ -307,3 +307,25 @@ def test_fused_sigmoid_focal_matches_two_step():
     assert la.item() == lb.item()
     assert float((yb == 1e-4).float().mean()) > 0.01 and float((yb == 1 - 1e-4).float().mean()) > 1e-4
     assert torch.equal(a.grad, b.grad), "single-pass backward is bit-identical to the two kernels"
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_ctdet_decode_fuzz_bit_exact(seed):
+    """Random map sizes (both NMS code paths: rows that divide the 1024-thread strip layout and rows that do not), class
+    counts, K and heat statistics (smooth, quantised = many ties / plateaus, sparse): indices, classes and boxes bit-exact
+    against the oracle's ctdet_decode with the (score desc, index asc) tie rule."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    u = rng.uniform(900 + seed, "cfg", (8,))
+    B = 1 + int(u[0] * 3)
+    C = [1, 2, 5, 17, 80][int(u[1] * 5)]
+    H, W = [(128, 128), (64, 64), (32, 64), (48, 40), (17, 23), (96, 128), (128, 32), (8, 8)][int(u[2] * 8)]
+    K = min([1, 7, 40, 100][int(u[3] * 4)], H * W)
+    z = rng.t_normal(900 + seed, "heat", (B, C, H, W))
+    kind = int(u[4] * 3)
+    heat = torch.sigmoid(z * 0.5 - 2.19) if kind == 0 else (torch.sigmoid(z) * 16).round() / 16 if kind == 1 else torch.where(z > 1.5, torch.sigmoid(z), torch.zeros_like(z))
+    wh = rng.t_uniform(900 + seed, "wh", (B, 2, H, W), 1, 30)
+    reg = rng.t_uniform(900 + seed, "reg", (B, 2, H, W)) if u[5] > 0.3 else None
+    det, inds, clses = ctdet_decode(heat.to(DEV), wh.to(DEV), None if reg is None else reg.to(DEV), K=K, return_aux=True)
+    rdet, rinds, rcls = ops_ref.ctdet_decode(heat, wh, reg, K=K, return_aux=True)
+    assert torch.equal(inds.cpu(), rinds) and torch.equal(clses.cpu(), rcls), (B, C, H, W, K, kind)
+    assert torch.equal(det.cpu(), rdet), (B, C, H, W, K, kind)
