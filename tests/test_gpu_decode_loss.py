@@ -329,3 +329,24 @@ def test_ctdet_decode_fuzz_bit_exact(seed):
     rdet, rinds, rcls = ops_ref.ctdet_decode(heat, wh, reg, K=K, return_aux=True)
     assert torch.equal(inds.cpu(), rinds) and torch.equal(clses.cpu(), rcls), (B, C, H, W, K, kind)
     assert torch.equal(det.cpu(), rdet), (B, C, H, W, K, kind)
+
+
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_multi_pose_decode_fuzz(seed):
+    """Random map sizes / K / offset options against the oracle's multi_pose_decode (continuous inputs: no ties)."""
+    from centernet_amd.decode.multi_pose import multi_pose_decode
+    u = rng.uniform(950 + seed, "cfg", (6,))
+    B = 1 + int(u[0] * 2)
+    H, W = [(128, 128), (64, 96), (40, 48), (32, 32)][int(u[1] * 4)]
+    K = [20, 50, 100][int(u[2] * 3)]
+    heat = torch.sigmoid(rng.t_normal(950 + seed, "heat", (B, 1, H, W)))
+    hm_hp = torch.sigmoid(rng.t_normal(950 + seed, "hmhp", (B, 17, H, W)) * 0.7 - 1.0)
+    wh = rng.t_uniform(950 + seed, "wh", (B, 2, H, W), 4.0, 0.4 * min(H, W))
+    kps = rng.t_normal(950 + seed, "kps", (B, 34, H, W), 0, 5.0)
+    reg = rng.t_uniform(950 + seed, "reg", (B, 2, H, W)) if u[3] > 0.4 else None
+    hpo = rng.t_uniform(950 + seed, "hpo", (B, 2, H, W)) if u[4] > 0.4 else None
+    d = lambda t: None if t is None else t.to(DEV)
+    det = multi_pose_decode(d(heat), d(wh), d(kps), reg=d(reg), hm_hp=d(hm_hp), hp_offset=d(hpo), K=K).cpu()
+    ref = ops_ref.multi_pose_decode(heat, wh, kps, reg=reg, hm_hp=hm_hp, hp_offset=hpo, K=K)
+    assert det.shape == ref.shape == (B, K, 57)
+    np.testing.assert_array_equal(det.numpy(), ref.numpy())
