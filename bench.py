@@ -269,7 +269,7 @@ def main():
                     "all_igemm": {"achieved": round(allf / allt / 1e12, 2), "ms_per_step": round(allt / args.probe_steps * 1e3, 3),
                                   "variants": {kname(k): {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.probe_steps * 1e3, 3), "launches_per_step": v[2] // args.probe_steps}
                                                for k, v in sorted(by.items())}}}
-        line = {"metric": "images/sec (train step + decode) DLA-34 512x512 bs=64 at 1/2/4/8 MI355X",
+        line = {"metric": "images/sec (train step + decode) DLA-34 512\u00d7512 bs=64 at 1/2/4/8 MI355X",
                 "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
