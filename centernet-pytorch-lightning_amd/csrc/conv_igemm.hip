@@ -604,7 +604,14 @@ extern "C" int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, in
     return CN_OK;
 }
 
-#define PACK_CHUNK 2048
+// One launch packs every weight operand of a step (table: w, wp, A, B, taps, mode, rows_pad, inner_pad, first_block per entry).
+// A thread owns one (row, inner) PAIR and walks its taps: the fp32 source w[a][b][0..taps-1] is one contiguous run per pair and
+// the lanes of a wave write consecutive bf16 elements for every tap.  (The first version was output-element driven: every
+// lane read with a stride of `taps` floats, 9x over-fetch from L2, and divided 64-bit indices twice per element: 266 us.)
+// Items per entry: modes 0/1 rows_pad * inner_pad; mode 2 (rows = tap*B + b) B * inner_pad pairs + the zero rows of the padding.
+__device__ static inline int64_t pack_items(int A, int B, int taps, int mode, int rows_pad, int inner_pad) {
+    return (mode == 2 ? (int64_t)(B + rows_pad - taps * B) : (int64_t)rows_pad) * (inner_pad / 8);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const int64_t* __restrict__ tab, int n) {
     int lo = 0, hi = n - 1;                                 // last record whose first_block <= blockIdx.x
@@ -615,29 +622,37 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const int64_t* _
     const int64_t* e = tab + lo * 10;
     const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
     T* __restrict__ wp = reinterpret_cast<T*>(e[1]);
-    const int A = (int)e[2], B = (int)e[3], taps = (int)e[4], mode = (int)e[5], rows_pad = (int)e[6], inner_pad = (int)e[7];
-    const int ktot = mode == 2 ? inner_pad : taps * inner_pad;
-    // 32-bit index arithmetic on purpose: the first version divided 64-bit element indices twice per element and was ALU bound
-    // (266 us for 200 MB); a packed matrix has < 2^31 elements
-    const int total = rows_pad * ktot;
-    const int base = (int)((int64_t)blockIdx.x - e[8]) * PACK_CHUNK;
+    const int A = (int)e[2], B = (int)e[3], taps = (int)e[4], mode = (int)e[5], rows_pad = (int)e[6], ip = (int)e[7];
+    const int ipv = ip / 8;                                 // inner_pad is a multiple of 16: a thread packs 8 inner elements
+    const int i = (int)((int64_t)blockIdx.x - e[8]) * 256 + threadIdx.x;
+    if ((int64_t)i >= pack_items(A, B, taps, mode, rows_pad, ip)) return;
+    const int r = (int)((unsigned)i / (unsigned)ipv), c0 = (i - r * ipv) * 8;
+    auto put8 = [&](T* dst, const float (&v)[8]) {
+        if constexpr (sizeof(T) == 2) st16(dst, make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])));
+        else {
 #pragma unroll
-    for (int j = 0; j < PACK_CHUNK / 256; ++j) {
-        const int i = base + j * 256 + threadIdx.x;
-        if (i >= total) break;
-        const int r = (int)((unsigned)i / (unsigned)ktot), k = i - r * ktot;
-        int a = -1, b = -1, t = 0;
-        if (mode == 2) {
-            t = r / B; b = r - t * B; a = k;
-            if (t >= taps) b = -1;
-        } else {
-            t = (int)((unsigned)k / (unsigned)inner_pad);
-            const int c = k - t * inner_pad;
-            if (mode == 1) { a = r; b = c; } else { a = c; b = r; }
+            for (int j = 0; j < 8; ++j) dst[j] = v[j];
         }
-        float v = 0.f;
-        if (a >= 0 && a < A && b >= 0 && b < B) v = w[((int64_t)a * B + b) * taps + t];
-        Elem<T>::st(wp + i, v);
+    };
+    if (mode == 2 && r >= B) {                              // padding rows of the (tap, b)-major matrix
+        const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        put8(wp + (int64_t)taps * B * ip + (int64_t)(r - B) * ip + c0, z);
+        return;
+    }
+    // source element of inner index c0 + j: modes 0 / 2: a = c0 + j, b = r; mode 1: a = r, b = c0 + j
+    int64_t src[8];
+    bool ok[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int a = mode == 1 ? r : c0 + j, bb = mode == 1 ? c0 + j : r;
+        ok[j] = a < A && bb < B;
+        src[j] = ok[j] ? ((int64_t)a * B + bb) * taps : 0;
+    }
+    for (int t = 0; t < taps; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float x = w[src[j] + t]; v[j] = ok[j] ? x : 0.f; }
+        put8(mode == 2 ? wp + ((int64_t)t * B + r) * ip + c0 : wp + (int64_t)r * taps * ip + (int64_t)t * ip + c0, v);
     }
 }
 

@@ -93,7 +93,8 @@ class PackArena:
             wp = torch.empty((rows_pad, cols), dtype=self.dtype, device=w.device)
             self.slots[k] = wp
             rows.append([w.data_ptr(), wp.data_ptr(), A, B, KH * KW, mode, rows_pad, inner_pad, blk, 0])
-            blk += (rows_pad * cols + 2047) // 2048
+            items = ((B + rows_pad - KH * KW * B) if mode == 2 else rows_pad) * (inner_pad // 8)   # see pack_weight_batch_kernel
+            blk += (items + 255) // 256
         self.table = torch.tensor(rows, dtype=torch.int64).to(reqs[0][1].device)
         self.n_blocks = blk
 
