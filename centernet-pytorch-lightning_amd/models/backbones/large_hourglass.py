@@ -56,8 +56,11 @@ class Residual(nn.Module):
             self.skip = nn.Sequential()
 
     def forward(self, x):
-        idt = x if len(self.skip) == 0 else hnn.conv_bn_act(self.skip[0], self.skip[1], x, None, False)
-        y = hnn.conv_bn_act(self.conv1, self.bn1, x)
+        if len(self.skip) == 0:
+            y, idt = hnn.conv_bn_act_skip(self.conv1, self.bn1, x)
+        else:
+            idt = hnn.conv_bn_act(self.skip[0], self.skip[1], x, None, False)
+            y = hnn.conv_bn_act(self.conv1, self.bn1, x)
         return hnn.conv_bn_act(self.conv2, self.bn2, y, idt, True)
 
 

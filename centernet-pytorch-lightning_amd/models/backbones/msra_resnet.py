@@ -23,8 +23,11 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else hnn.conv_bn_act(self.downsample[0], self.downsample[1], x, None, False)
-        y = hnn.conv_bn_act(self.conv1, self.bn1, x)
+        if self.downsample is None:
+            y, idt = hnn.conv_bn_act_skip(self.conv1, self.bn1, x)
+        else:
+            idt = hnn.conv_bn_act(self.downsample[0], self.downsample[1], x, None, False)
+            y = hnn.conv_bn_act(self.conv1, self.bn1, x)
         return hnn.conv_bn_act(self.conv2, self.bn2, y, idt, True)
 
 

@@ -30,9 +30,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x, residual=None):
-        if residual is None:
-            residual = x
-        y = hnn.conv_bn_act(self.conv1, self.bn1, x)
+        if residual is None:            # identity block: the skip gradient joins conv1's data gradient in that kernel's epilogue
+            y, residual = hnn.conv_bn_act_skip(self.conv1, self.bn1, x)
+        else:
+            y = hnn.conv_bn_act(self.conv1, self.bn1, x)
         return hnn.conv_bn_act(self.conv2, self.bn2, y, residual, True)
 
 

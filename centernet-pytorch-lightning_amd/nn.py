@@ -36,6 +36,13 @@ class Conv2d(nn.Module):
             return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu, mask_dx, defer_relu_bwd)
         return self.infer(x, None, None, None, relu)
 
+    def with_skip(self, x):
+        """-> (conv(x), x) for a residual connection around this conv: the skip path's gradient is added in the epilogue of this
+        conv's data-gradient kernel (training; otherwise just the pair)."""
+        if torch.is_grad_enabled() and x.requires_grad and self.stride == 1:
+            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, False, False, False, True)
+        return self.forward(x), x
+
     def infer(self, x, scale, shift, residual, relu, out_dtype=None):
         """No-grad path: y = act(conv(x)*scale + shift + residual); packed (folded) weights are cached."""
         key = (x.dtype, self.weight._version, None if scale is None else (scale.data_ptr(), scale._version))
@@ -83,6 +90,14 @@ class BatchNorm2d(nn.BatchNorm2d):
             return ops.batch_norm_act(x, self, residual, relu)
         s, b = self.folded()
         return ops.scale_shift_act(x, s, b, residual, relu)
+
+
+def conv_bn_act_skip(conv, bn, x):
+    """(ReLU(BN(conv(x))), x) — the first half of a residual block whose identity path is its own input."""
+    if bn.training and torch.is_grad_enabled() and x.requires_grad and conv.stride == 1:
+        c, skip = conv.with_skip(x)
+        return bn(c, None, True), skip
+    return conv_bn_act(conv, bn, x), x
 
 
 def conv_bn_act(conv, bn, x, residual=None, relu=True):

@@ -245,9 +245,12 @@ class Conv2dFn(Function):
     """nn.Conv2d (+bias, +ReLU) on NHWC.  weight fp32 [Co,Ci,KH,KW]; x channels = rup(Ci,16) (zero padded)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, mask_dx=False, defer_relu_bwd=False):
+    def forward(ctx, x, weight, bias, stride, pad, relu, mask_dx=False, defer_relu_bwd=False, passthrough=False):
         """mask_dx: x is the output of a fused-ReLU producer that was built with defer_relu_bwd=True; this layer's data
-        gradient is then masked by (x > 0) in its own epilogue (relu mode 2) and the producer skips its cn_relu_bwd pass."""
+        gradient is then masked by (x > 0) in its own epilogue (relu mode 2) and the producer skips its cn_relu_bwd pass.
+        passthrough: also return x itself (for a residual connection around this conv): the gradient of that second use
+        then arrives in THIS backward and is added in the data-gradient kernel's epilogue instead of by a separate
+        element-wise pass of the autograd engine."""
         Co, Ci, KH, KW = weight.shape
         N, H, W, Cx = x.shape
         assert Cx == rup(Ci, 16), f"conv input has {Cx} channels, weight expects {Ci}"
@@ -259,10 +262,13 @@ class Conv2dFn(Function):
         ctx.mask_dx = mask_dx
         ctx.bias_ref = bias
         ctx.order = SideGrads.next_order()
+        ctx.passthrough = passthrough
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, weight, y = ctx.saved_tensors
         stride, pad, relu, has_bias = ctx.cfg
         Co, Ci, KH, KW = weight.shape
@@ -296,8 +302,15 @@ class Conv2dFn(Function):
             elif ctx.mask_dx:
                 dx = _igemm(dy, wpd, None, x, Ci, KH, KW, stride, pad, True, 2, H, W)
             else:
-                dx = _igemm(dy, wpd, None, None, Ci, KH, KW, stride, pad, True, False, H, W)
-        return dx, dw, db, None, None, None, None, None
+                skip = dskip.contiguous() if (dskip is not None and dskip.dtype == x.dtype and dskip.shape == x.shape) else None
+                dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
+                if skip is not None:
+                    dskip = None                                  # folded into the epilogue
+            if dskip is not None:
+                dx = dx + dskip
+        elif dskip is not None:
+            dx = dskip
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(Function):
@@ -852,8 +865,8 @@ class GatherL1Fn(Function):
 
 
 # ------------------------------------------------------------------------------------------------ functional aliases
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, defer_relu_bwd=False):
-    return Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd)
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, defer_relu_bwd=False, passthrough=False):
+    return Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd, passthrough)
 
 
 def conv_transpose2d(x, weight, stride=2, pad=1):
