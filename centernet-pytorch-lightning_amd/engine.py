@@ -214,6 +214,7 @@ class TrainStep:
         if self.sync is not None:
             self.sync.broadcast_state(model)
         self._g1 = self._g2 = None
+        self._inflight = None
         self._bns = [m for m in model.modules() if hasattr(m, "_pending")]
 
     def _fork_post_forward(self):
@@ -327,7 +328,23 @@ class TrainStep:
         self._g2.replay()
         for m in self._bns:
             m._pending += 1
+        self._throttle()
         return self._loss
+
+    MAX_STEPS_AHEAD = 3
+
+    def _throttle(self):
+        """A host that never synchronises can enqueue replays hundreds of steps ahead of the GPU (each one ~1 150 kernel nodes):
+        300 un-synchronised steps drove the HIP runtime into a 7x slowdown and finally a GPU memory fault.  The host therefore
+        waits for the step that was launched MAX_STEPS_AHEAD steps ago — never for the one it has just enqueued."""
+        if self._inflight is None:
+            from collections import deque
+            self._inflight = deque()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._inflight.append(ev)
+        if len(self._inflight) > self.MAX_STEPS_AHEAD:
+            self._inflight.popleft().synchronize()
 
 
 class Trainer:

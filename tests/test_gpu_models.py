@@ -304,3 +304,31 @@ def test_rccl_exchange_next_to_graphs(tmp_path):
     assert all(np.isfinite(res["eager"])) and all(np.isfinite(res["graph"]))
     assert res["graph"][0] == pytest.approx(res["eager"][2], rel=5e-3)     # 2 warm-up steps precede the capture
     assert res["eager"][3] < res["eager"][0]
+
+
+def test_graph_replay_host_never_runs_far_ahead():
+    """Regression: 300 un-synchronised hipGraph steps (2 replays of ~1 150 nodes each) drove the HIP runtime into a 7x slowdown
+    and finally a GPU memory fault.  TrainStep throttles the host to MAX_STEPS_AHEAD steps; a long un-synchronised run must
+    complete, keep its pace and leave every parameter finite."""
+    import time
+    from centernet_amd.engine import TrainStep
+    m = _model("res_18", 92, torch.bfloat16).train()
+    x, tgt = synth.ctdet_batch(92, 4, 128, 128)
+    batch = (x.to(DEV), {k: v.to(DEV) for k, v in tgt.items()})
+    step = TrainStep(m, lr=1e-4, distributed=False, graph=True)
+    for _ in range(3):
+        step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        step(batch)
+    torch.cuda.synchronize()
+    t40 = time.perf_counter() - t0
+    assert len(step._inflight) <= step.MAX_STEPS_AHEAD
+    t0 = time.perf_counter()
+    for _ in range(400):
+        loss = step(batch)
+    torch.cuda.synchronize()
+    t400 = time.perf_counter() - t0
+    assert t400 < 10 * t40 * 1.5, (t40, t400)
+    assert np.isfinite(float(loss)) and all(bool(torch.isfinite(p).all()) for p in m.parameters())
