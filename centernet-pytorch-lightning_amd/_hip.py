@@ -88,10 +88,17 @@ def _arg(a):
     return a
 
 
+TRACE = False      # debugging aid: name every call on stderr before it is issued (with HIP_LAUNCH_BLOCKING=1 the last line is the culprit)
+
+
 def call(name, *args):
     """Invoke cn_<name>; tensors become device pointers; the current torch stream is appended."""
     L = lib()
     fn = getattr(L, name)
+    if TRACE:
+        import sys
+        sys.stderr.write("CALL " + name + " " + " ".join(str(tuple(a.shape)) if isinstance(a, torch.Tensor) else str(a) for a in args) + "\n")
+        sys.stderr.flush()
     rc = fn(*[_arg(a) for a in args], stream_ptr())
     if rc != 0:
         raise RuntimeError(f"{name} failed (status {rc}): {L.cn_last_error().decode()}")

@@ -38,7 +38,11 @@ __device__ static void block_topk(const uint32_t* keys, int L, int K, TkShared& 
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = tid; i < 256; i += nthr) sh.hist[i] = 0;
         __syncthreads();
-        const uint32_t prefix = sh.prefix, mask = sh.mask;
+        // sh.need is read HERE, a barrier away from where the crossing thread rewrites it below.  (It used to be read in that
+        // same phase: a wave that ran late saw the already-reduced count, found a second "crossing" bin and overwrote
+        // prefix / need — a wrong threshold, more than K survivors, sel_* overrun in LDS and garbage indices.  It only ever
+        // happened with the decode running next to another stream's kernels: 1 in ~10^6 maps.)
+        const uint32_t prefix = sh.prefix, mask = sh.mask, need = sh.need;
         for (int i0 = 0; i0 < L; i0 += nthr) {
             const int i = i0 + tid;
             const bool ok = i < L && ((keys[i] & mask) == prefix);
@@ -77,7 +81,6 @@ __device__ static void block_topk(const uint32_t* keys, int L, int K, TkShared& 
         __syncthreads();
         if (tid < 256) {
             for (int w = 0; w < (tid >> 6); ++w) incl += sh.wsum[w];
-            const uint32_t need = sh.need;
             if (incl >= need && incl - h < need) {      // exactly one thread: the crossing bin
                 sh.need = need - (incl - h);            // how many are still needed inside that bin
                 sh.prefix = prefix | ((uint32_t)(255 - tid) << shift);
@@ -125,7 +128,7 @@ __device__ static void block_topk(const uint32_t* keys, int L, int K, TkShared& 
         const uint32_t k = keys[i];
         if (k > thr) {
             const uint32_t s = atomicAdd(&sh.cnt_g, 1u);
-            sh.sel_key[s] = k; sh.sel_idx[s] = i;
+            if (s < (uint32_t)K) { sh.sel_key[s] = k; sh.sel_idx[s] = i; }      // always true for a consistent threshold
         } else if (k == thr && (uint32_t)i <= idx_thr) {
             const uint32_t s = n_gt + atomicAdd(&sh.cnt_e, 1u);
             if (s < (uint32_t)K) { sh.sel_key[s] = k; sh.sel_idx[s] = i; }

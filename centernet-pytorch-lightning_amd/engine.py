@@ -303,7 +303,10 @@ class TrainStep:
 
     def __call__(self, batch, batch_idx=0):
         if not self.graph:
-            return self._eager(batch, batch_idx)
+            loss = self._eager(batch, batch_idx)
+            if self.opt.flat_p.is_cuda:
+                self._throttle()
+            return loss
         if self._g1 is None:
             try:
                 self._capture(batch)

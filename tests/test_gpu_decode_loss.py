@@ -350,3 +350,35 @@ def test_multi_pose_decode_fuzz(seed):
     ref = ops_ref.multi_pose_decode(heat, wh, kps, reg=reg, hm_hp=hm_hp, hp_offset=hpo, K=K)
     assert det.shape == ref.shape == (B, K, 57)
     np.testing.assert_array_equal(det.numpy(), ref.numpy())
+
+
+def test_decode_is_stable_next_to_other_streams():
+    """Regression for a read/write race on the radix select's shared `need` counter: a late wave saw the already-reduced count,
+    picked a second pivot bin and overran the survivor list (garbage indices -> GPU memory fault in the gather).  It needed the
+    decode to share the GPU with another stream's kernels (about one map in 10^6), exactly what TrainStep's post_forward does.
+    Here: 300 full-size decodes on a side stream while the main stream runs conv + BN forward/backward; every result must be
+    bit-identical (a stress test: the original fault needed ~4e5 maps under a real backward pass; tools/long_run.py reproduces that)."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    B, C, H, W = 64, 80, 128, 128
+    heat = torch.clamp(torch.sigmoid(rng.t_normal(70, "heat", (B, C, H, W)) * 2.0 - 6.0), 1e-4, 1 - 1e-4).to(DEV)
+    wh = rng.t_uniform(70, "wh", (B, 2, H, W), 1, 30).to(DEV)
+    reg = rng.t_uniform(70, "reg", (B, 2, H, W)).to(DEV)
+    ref = ctdet_decode(heat, wh, reg)
+    torch.cuda.synchronize()
+    from centernet_amd import nn as hnn
+    conv = hnn.Conv2d(64, 64, 3, 1, 1).to(DEV)
+    bnm = hnn.BatchNorm2d(64).to(DEV).train()
+    xin = torch.randn(32, 128, 128, 64, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    side = torch.cuda.Stream()
+    bad = torch.zeros((), dtype=torch.int32, device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    for it in range(300):
+        with torch.cuda.stream(side):
+            det = ctdet_decode(heat, wh, reg)
+            bad += (det != ref).any().int()
+        y = bnm(conv(xin), None, True)         # main-stream work shaped like the backward pass the decode overlaps in a
+        y.backward(y.detach())                 # TrainStep: LDS-heavy conv / weight-gradient kernels and streaming BN passes
+        xin.grad = None
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert int(bad) == 0

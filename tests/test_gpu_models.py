@@ -332,3 +332,18 @@ def test_graph_replay_host_never_runs_far_ahead():
     t400 = time.perf_counter() - t0
     assert t400 < 10 * t40 * 1.5, (t40, t400)
     assert np.isfinite(float(loss)) and all(bool(torch.isfinite(p).all()) for p in m.parameters())
+
+
+def test_training_next_to_overlapped_decode_survives(tmp_path):
+    """The scenario that exposed the top-K race (see test_decode_is_stable_next_to_other_streams): eager DLA-34 training at the
+    bench's size with ctdet_decode forked onto its own stream after every forward pass and a garbage collection per step — it
+    used to die of a GPU memory fault after 60-180 steps.  Runs in a subprocess with a timeout: a GPU fault must fail this
+    test, not hang the session."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "long_run.py"), "--steps", "120", "--no-graph", "--decode",
+                        "--gc", "every", "--every", "40"], env=dict(os.environ, CN_NO_SIDE="1"), capture_output=True, text=True,
+                       timeout=240)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
+    last = [l for l in r.stdout.splitlines() if l.startswith("step 120:")]
+    assert last and "params finite True" in last[0], r.stdout[-800:]
