@@ -334,12 +334,13 @@ class TrainStep:
         self._throttle()
         return self._loss
 
-    MAX_STEPS_AHEAD = 3
+    MAX_STEPS_AHEAD = int(os.environ.get("CN_MAX_STEPS_AHEAD", 3))
 
     def _throttle(self):
-        """A host that never synchronises can enqueue replays hundreds of steps ahead of the GPU (each one ~1 150 kernel nodes):
-        300 un-synchronised steps drove the HIP runtime into a 7x slowdown and finally a GPU memory fault.  The host therefore
-        waits for the step that was launched MAX_STEPS_AHEAD steps ago — never for the one it has just enqueued."""
+        """Bound the host's run-ahead: a caller that never synchronises would otherwise enqueue replays hundreds of steps ahead
+        of the GPU (each one ~1 150 kernel nodes plus their events).  The host waits for the step that was launched
+        MAX_STEPS_AHEAD steps ago — never for the one it has just enqueued, so the GPU queue stays full.  (CN_MAX_STEPS_AHEAD
+        overrides it; unbounded run-ahead was measured to work too — the fault first blamed on it was the top-K race.)"""
         if self._inflight is None:
             from collections import deque
             self._inflight = deque()

@@ -307,9 +307,8 @@ def test_rccl_exchange_next_to_graphs(tmp_path):
 
 
 def test_graph_replay_host_never_runs_far_ahead():
-    """Regression: 300 un-synchronised hipGraph steps (2 replays of ~1 150 nodes each) drove the HIP runtime into a 7x slowdown
-    and finally a GPU memory fault.  TrainStep throttles the host to MAX_STEPS_AHEAD steps; a long un-synchronised run must
-    complete, keep its pace and leave every parameter finite."""
+    """TrainStep bounds the host's run-ahead to MAX_STEPS_AHEAD graph-replayed steps; a long un-synchronised run completes,
+    keeps its pace and leaves every parameter finite."""
     import time
     from centernet_amd.engine import TrainStep
     m = _model("res_18", 92, torch.bfloat16).train()
