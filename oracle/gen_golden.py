@@ -322,7 +322,41 @@ def gen_pose():
     save("pose_decode.npz", seed=seed, B=B, K=K, det=det, det_nooff=det2)
 
 
+def gen_soft_nms():
+    """utils/nms.py run from the reference's own source.  numba is absent here, so `jit` is shimmed to the identity decorator
+    and the functions run as plain Python.  numba types `float32 + 1` as float64; to keep the same arithmetic the boxes are
+    handed over in float64 STORAGE holding float32-representable values (the only difference left: the decayed score is not
+    rounded to float32 between passes, < 1e-6 relative)."""
+    import importlib
+    import types
+    if "numba" not in sys.modules:
+        shim = types.ModuleType("numba")
+        shim.jit = lambda *a, **k: (lambda f: f)
+        sys.modules["numba"] = shim
+    ref = importlib.import_module("CenterNet.utils.nms")
+    kw = {}
+    cases = [("gauss", dict(Nt=0.5, method=2), 5, 60), ("linear", dict(Nt=0.5, method=1), 5, 60),
+             ("hard", dict(Nt=0.3, method=0), 5, 60), ("gauss39", dict(Nt=0.5, method=2), 57, 40)]
+    for i, (name, args, cols, n) in enumerate(cases):
+        g = np.random.default_rng(900 + i)
+        c = g.uniform(20, 200, (n, 2))
+        wh = g.uniform(10, 80, (n, 2))
+        b = np.zeros((n, cols), np.float32)
+        b[:, 0:2], b[:, 2:4] = c - wh / 2, c + wh / 2
+        b[:, 4] = g.uniform(0.002, 0.9, n)
+        b[n // 2:, :4] = b[:n - n // 2, :4] + g.uniform(-3, 3, (n - n // 2, 4))       # near-duplicates, as two scales give
+        if cols > 5:
+            b[:, 5:] = g.uniform(0, 256, (n, cols - 5))
+        kw[name + "_in"] = b.copy()
+        w = b.astype(np.float64)
+        keep = (ref.soft_nms_39 if cols > 5 else ref.soft_nms)(w, **args)
+        assert list(keep) == list(range(len(keep)))
+        kw[name + "_out"] = w
+        kw[name + "_n"] = len(keep)
+    save("soft_nms.npz", **kw)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "hourglass", "pose"]
+    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "hourglass", "pose", "soft_nms"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,5 +1,6 @@
 """GPU: test-time augmentation + detection post-processing (soft-NMS of f-4) through the C ABI against the
-oracle restatement of centernet_detection.py:132-225 / utils/nms.py (oracle/post_ref.py — parity unpinned, see its header)."""
+oracle restatement of centernet_detection.py:132-225 / utils/nms.py (oracle/post_ref.py — soft-NMS pinned by
+tests/golden/soft_nms.npz, the test-step glue unpinned: see its header)."""
 import numpy as np
 import pytest
 import torch
@@ -151,3 +152,39 @@ def test_pose_test_step_flip_end_to_end():
         got = np.array(res[b][1], np.float32)
         assert res[b][0] == ids[b] and got.shape == r.shape
         np.testing.assert_allclose(got, r, rtol=1e-5, atol=1e-5)
+
+
+IDENT = {"scale": [1.0, 1.0], "padding": [0, 0]}
+
+
+@pytest.mark.parametrize("name,method,nt", [("gauss", 2, 0.5), ("linear", 1, 0.5), ("hard", 0, 0.3)])
+def test_soft_nms_kernel_matches_reference_source_run(golden, name, method, nt):
+    """The HIP soft-NMS held to tests/golden/soft_nms.npz directly (utils/nms.py:5-107 run from the reference's source, see
+    oracle/gen_golden.py:gen_soft_nms): the golden boxes as two scales of one class with an identity transform."""
+    from centernet_amd.utils import post
+    g = golden("soft_nms.npz")
+    b, ref, n = g[name + "_in"], g[name + "_out"], int(g[name + "_n"])
+    K = len(b) // 2
+    d = np.zeros((2, 1, K, 6), np.float32)
+    d[0, 0, :, :5], d[1, 0, :, :5] = b[:K], b[K:]
+    rows, counts = post.ctdet_merge([torch.from_numpy(d[s]).to(DEV) for s in range(2)], [IDENT, IDENT], 1, down_ratio=1,
+                                    max_per_image=2 * K, nms_method=method, nms_nt=nt)
+    got = rows[0, :int(counts[0])].cpu().numpy()
+    assert int(counts[0]) == n and n < 2 * K
+    assert np.array_equal(got[:, :4], ref[:n, :4].astype(np.float32)) and not got[:, 5].any()
+    np.testing.assert_allclose(got[:, 4], ref[:n, 4], rtol=1e-6, atol=1e-7)
+
+
+def test_soft_nms_39_kernel_matches_reference_source_run(golden):
+    """utils/nms.py:109-206 (columns 5-38 travel with the box, 39-56 stay in place) against the same golden file."""
+    from centernet_amd.utils import post
+    g = golden("soft_nms.npz")
+    b, ref, n = g["gauss39_in"], g["gauss39_out"], int(g["gauss39_n"])
+    K = len(b) // 2
+    d = np.stack([b[:K], b[K:]])[:, None]
+    rows, counts = post.pose_merge([torch.from_numpy(d[s].copy()).to(DEV) for s in range(2)], [IDENT, IDENT], down_ratio=1,
+                                   max_per_image=2 * K)
+    got = rows[0, :int(counts[0])].cpu().numpy()
+    assert int(counts[0]) == n and n < 2 * K
+    assert np.array_equal(got[:, :4], ref[:n, :4].astype(np.float32)) and np.array_equal(got[:, 5:], ref[:n, 5:].astype(np.float32))
+    np.testing.assert_allclose(got[:, 4], ref[:n, 4], rtol=1e-6, atol=1e-7)

@@ -211,6 +211,25 @@ def test_soft_nms_restatement_known_answers():
     assert b[1, 4] == pytest.approx(0.8 * np.exp(-(1 / 3) ** 2 / 0.5), rel=1e-6)
 
 
+NMS_CASES = [("gauss", dict(Nt=0.5, method=2)), ("linear", dict(Nt=0.5, method=1)), ("hard", dict(Nt=0.3, method=0)),
+             ("gauss39", dict(Nt=0.5, method=2))]
+
+
+@pytest.mark.parametrize("name,args", NMS_CASES)
+def test_soft_nms_restatement_matches_reference_source_run(golden, name, args):
+    """tests/golden/soft_nms.npz: utils/nms.py:5-206 executed from the reference's own source with `numba.jit` shimmed to the
+    identity (oracle/gen_golden.py:gen_soft_nms).  The whole array is compared, the discarded tail included: boxes and
+    travelling columns exactly (they are only moved), scores to 1e-6 (float32 storage vs the shim run's float64)."""
+    from oracle import post_ref
+    g = golden("soft_nms.npz")
+    b = g[name + "_in"].copy()
+    n = (post_ref.soft_nms_39 if b.shape[1] > 5 else post_ref.soft_nms)(b, **args)
+    ref = g[name + "_out"]
+    assert n == int(g[name + "_n"]) and n < len(b)
+    assert np.array_equal(b[:, :4], ref[:, :4].astype(np.float32)) and np.array_equal(b[:, 5:], ref[:, 5:].astype(np.float32))
+    np.testing.assert_allclose(b[:, 4], ref[:, 4], rtol=1e-6, atol=1e-7)
+
+
 def test_test_step_end_restatement_single_scale_is_a_regrouping():
     """Single scale: no NMS, K = 100 = test_max_per_image, so test_step_end only rescales and regroups (centernet_detection.py:189-223)."""
     from oracle import post_ref
