@@ -220,3 +220,30 @@ def pose_batch(seed, batch, in_h=512, in_w=512, start=0, joints=17, max_objs=128
                 T["heatmap_keypoints_mask"][b, k * joints + j] = True
                 splat_umich(T["heatmap_keypoints"][b, j], ix, iy, rad)
     return imgs, {k: torch.from_numpy(v) for k, v in T.items()}
+
+
+def tta_head_maps(seed, channels, sizes):
+    """Seeded raw head maps for the test scales: {name: [1, C, H, W]} per scale; the heat-map logits are biased so that the
+    decode sees a few hundred separated peaks."""
+    outs = []
+    for i, (h, w) in enumerate(sizes):
+        o = {}
+        for name, (c, kind) in channels.items():
+            if kind == "logit":
+                o[name] = rng.t_normal(seed, f"{name}{i}", (1, c, h, w)) * 2.0 - 2.0
+            elif kind == "size":
+                o[name] = rng.t_uniform(seed, f"{name}{i}", (1, c, h, w), 2.0, 12.0)
+            elif kind == "kps":
+                o[name] = rng.t_normal(seed, f"{name}{i}", (1, c, h, w), 0, 4.0)
+            else:
+                o[name] = rng.t_uniform(seed, f"{name}{i}", (1, c, h, w))
+        outs.append(o)
+    return outs
+
+
+DET_MAPS = {"heatmap": (3, "logit"), "width_height": (2, "size"), "regression": (2, "off")}
+POSE_MAPS = {"heatmap": (1, "logit"), "width_height": (2, "size"), "regression": (2, "off"), "keypoints": (34, "kps"),
+             "heatmap_keypoints": (17, "logit"), "heatmap_keypoints_offset": (2, "off")}
+# 128x128 image at scales 1 and 0.75: padded to (size | 31) + 1 = 160 / 128 -> 40x40 and 32x32 maps
+TTA_SIZES = [(40, 40), (32, 32)]
+TTA_METAS = [{"scale": [1.0, 1.0], "padding": [16, 16]}, {"scale": [0.75, 0.75], "padding": [16, 16]}]

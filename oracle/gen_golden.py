@@ -327,13 +327,7 @@ def gen_soft_nms():
     and the functions run as plain Python.  numba types `float32 + 1` as float64; to keep the same arithmetic the boxes are
     handed over in float64 STORAGE holding float32-representable values (the only difference left: the decayed score is not
     rounded to float32 between passes, < 1e-6 relative)."""
-    import importlib
-    import types
-    if "numba" not in sys.modules:
-        shim = types.ModuleType("numba")
-        shim.jit = lambda *a, **k: (lambda f: f)
-        sys.modules["numba"] = shim
-    ref = importlib.import_module("CenterNet.utils.nms")
+    ref = _ref_nms_module()
     kw = {}
     cases = [("gauss", dict(Nt=0.5, method=2), 5, 60), ("linear", dict(Nt=0.5, method=1), 5, 60),
              ("hard", dict(Nt=0.3, method=0), 5, 60), ("gauss39", dict(Nt=0.5, method=2), 57, 40)]
@@ -356,7 +350,79 @@ def gen_soft_nms():
     save("soft_nms.npz", **kw)
 
 
+def _ref_nms_module():
+    import importlib
+    import types
+    if "numba" not in sys.modules:
+        shim = types.ModuleType("numba")
+        shim.jit = lambda *a, **k: (lambda f: f)
+        sys.modules["numba"] = shim
+    return importlib.import_module("CenterNet.utils.nms")
+
+
+def _ref_method(path, cls, name, ns):
+    """Compile ONE method of a reference class straight from its source file and return it as a function living in `ns`.
+    The LightningModule files cannot be imported here (pytorch_lightning, torchvision, imgaug, pycocotools, cv2 absent and
+    transforms/sample.py needs `collections.Callable`), but test_step_end itself only touches torch, numpy, the decode and
+    soft-NMS — so its body is executed as it stands in /root/reference, with those names supplied."""
+    import ast
+    tree = ast.parse(open(path).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for f in node.body:
+                if isinstance(f, ast.FunctionDef) and f.name == name:
+                    exec(compile(ast.Module(body=[f], type_ignores=[]), path, "exec"), ns)
+                    return ns[name]
+    raise KeyError((cls, name))
+
+
+def _as_numba(fn):
+    """Call a shimmed soft-NMS the way numba would run it on a float32 array: arithmetic in double (float64 working copy),
+    results stored back to float32."""
+    def run(boxes, **kw):
+        w = boxes.astype(np.float64)
+        keep = fn(w, **kw)
+        boxes[:] = w
+        return keep
+    return run
+
+
+def gen_test_step_end():
+    """centernet_detection.py:175-225 and centernet_multi_pose.py:215-264 executed from the reference's source (see
+    _ref_method) on seeded head maps of two test scales, plus the single-scale variant (no NMS, straight cut)."""
+    import types
+    nms = _ref_nms_module()
+    kw = {}
+    seed = 77
+    while True:
+        outs = synth.tta_head_maps(seed, synth.DET_MAPS, synth.TTA_SIZES)
+        if all(tie_free(o["heatmap"].sigmoid(), 100) for o in outs):
+            break
+        seed += 1000
+    fn = _ref_method(f"{refshim.REF}/CenterNet/centernet_detection.py", "CenterNetDetection", "test_step_end",
+                     {"torch": torch, "np": np, "ctdet_decode": ctdet_decode, "soft_nms": _as_numba(nms.soft_nms)})
+    for tag, S in (("ms", 2), ("ss", 1)):
+        me = types.SimpleNamespace(down_ratio=4, num_classes=3, test_scales=[1, 0.75][:S], test_max_per_image=100)
+        _, res = fn(me, (5, [{k: v.clone() for k, v in o.items()} for o in outs[:S]], synth.TTA_METAS[:S]))
+        kw[f"det_{tag}_rows"] = np.concatenate([np.concatenate([res[j], np.full((len(res[j]), 1), j, np.float32)], 1) for j in sorted(res)])
+    kw["det_seed"] = seed
+    seed = 78
+    while True:
+        outs = synth.tta_head_maps(seed, synth.POSE_MAPS, synth.TTA_SIZES)
+        if all(tie_free(o["heatmap"].sigmoid(), 100) and tie_free(o["heatmap_keypoints"].sigmoid(), 100) for o in outs):
+            break
+        seed += 1000
+    fn = _ref_method(f"{refshim.REF}/CenterNet/centernet_multi_pose.py", "CenterNetMultiPose", "test_step_end",
+                     {"torch": torch, "np": np, "multi_pose_decode": multi_pose_decode, "soft_nms_39": _as_numba(nms.soft_nms_39)})
+    for tag, S in (("ms", 2), ("ss", 1)):
+        me = types.SimpleNamespace(down_ratio=4, test_scales=[1, 0.75][:S], test_max_per_image=20)
+        _, res = fn(me, (5, [{k: v.clone() for k, v in o.items()} for o in outs[:S]], synth.TTA_METAS[:S]))
+        kw[f"pose_{tag}_rows"] = np.asarray(res, np.float32)
+    kw["pose_seed"] = seed
+    save("test_step_end.npz", **kw)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "hourglass", "pose", "soft_nms"]
+    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "hourglass", "pose", "soft_nms", "test_step_end"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,11 +1,13 @@
 """ORACLE (test infrastructure): CPU restatement of the reference's test-time augmentation and detection post-processing.
 
 Follows CenterNetDetection.test_step / test_step_end (centernet_detection.py:132-225) and utils/nms.py:5-107 (soft_nms).
-soft_nms / soft_nms_39 are PINNED: tests/golden/soft_nms.npz holds the outputs of utils/nms.py run from the reference's own
-source (numba is absent, so `jit` is shimmed to the identity and the boxes are given float64 storage to keep numba's typing;
-oracle/gen_golden.py:gen_soft_nms), and tests/test_oracle_golden.py + tests/test_gpu_post.py hold this file and the HIP kernels
-to it.  PARITY UNPINNED for the rest (tta_prepare, flip_merge*, *test_step_end): the LightningModules cannot be imported here
-(pytorch_lightning / torchvision / pycocotools absent), so those are checked by known-answer tests only.
+PINNED: soft_nms / soft_nms_39 (tests/golden/soft_nms.npz: utils/nms.py run from the reference's own source; numba is absent, so
+`jit` is shimmed to the identity and the boxes get float64 storage to keep numba's typing) and test_step_end /
+pose_test_step_end (tests/golden/test_step_end.npz: the reference's method bodies compiled from their source files and run on
+seeded two-scale head maps) — see oracle/gen_golden.py:gen_soft_nms / gen_test_step_end; tests/test_oracle_golden.py and
+tests/test_gpu_post.py hold this file and the HIP path to both.
+PARITY UNPINNED: tta_prepare and flip_merge* (the test_step halves, centernet_detection.py:132-173) — they need
+torchvision.transforms.functional (resize / normalize / hflip), which is absent; checked by known-answer tests only.
 """
 import numpy as np
 import torch

@@ -1,6 +1,6 @@
 """GPU: test-time augmentation + detection post-processing (soft-NMS of f-4) through the C ABI against the
-oracle restatement of centernet_detection.py:132-225 / utils/nms.py (oracle/post_ref.py — soft-NMS pinned by
-tests/golden/soft_nms.npz, the test-step glue unpinned: see its header)."""
+oracle restatement of centernet_detection.py:132-225 / utils/nms.py (oracle/post_ref.py — soft-NMS and
+test_step_end pinned by tests/golden/{soft_nms,test_step_end}.npz, the test_step half unpinned: see its header)."""
 import numpy as np
 import pytest
 import torch
@@ -188,3 +188,28 @@ def test_soft_nms_39_kernel_matches_reference_source_run(golden):
     assert int(counts[0]) == n and n < 2 * K
     assert np.array_equal(got[:, :4], ref[:n, :4].astype(np.float32)) and np.array_equal(got[:, 5:], ref[:n, 5:].astype(np.float32))
     np.testing.assert_allclose(got[:, 4], ref[:n, 4], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag,S", [("ms", 2), ("ss", 1)])
+def test_test_step_end_matches_reference_source_run(golden, tag, S):
+    """CenterNetDetection.test_step_end / CenterNetMultiPose.test_step_end (decode + merge kernels through the C ABI) against
+    tests/golden/test_step_end.npz — the reference's own method bodies (centernet_detection.py:175-225,
+    centernet_multi_pose.py:215-264) run from source on the same seeded two-scale head maps."""
+    from centernet_amd.centernet_detection import CenterNetDetection
+    from centernet_amd.centernet_multi_pose import CenterNetMultiPose
+    g = golden("test_step_end.npz")
+    m = CenterNetDetection("res_18", num_classes=3, test_scales=[1, 0.75][:S], compute_dtype=torch.float32)
+    outs = [{k: v.to(DEV) for k, v in o.items()} for o in synth.tta_head_maps(int(g["det_seed"]), synth.DET_MAPS, synth.TTA_SIZES)[:S]]
+    (iid, res), = m.test_step_end(([5], outs, synth.TTA_METAS[:S]))
+    rows = np.concatenate([np.concatenate([res[j], np.full((len(res[j]), 1), j, np.float32)], 1) for j in sorted(res)])
+    ref = g[f"det_{tag}_rows"]
+    assert iid == 5 and rows.shape == ref.shape and np.array_equal(rows[:, 5], ref[:, 5])
+    np.testing.assert_allclose(rows[:, :4], ref[:, :4], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 4], ref[:, 4], rtol=1e-6, atol=1e-7)
+    m = CenterNetMultiPose("res_18", test_scales=[1, 0.75][:S], compute_dtype=torch.float32)
+    outs = [{k: v.to(DEV) for k, v in o.items()} for o in synth.tta_head_maps(int(g["pose_seed"]), synth.POSE_MAPS, synth.TTA_SIZES)[:S]]
+    (iid, res), = m.test_step_end(([5], outs, synth.TTA_METAS[:S]))
+    rows, ref = np.asarray(res, np.float32), g[f"pose_{tag}_rows"]
+    assert rows.shape == ref.shape
+    np.testing.assert_allclose(np.delete(rows, 4, 1), np.delete(ref, 4, 1), rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 4], ref[:, 4], rtol=1e-6, atol=1e-7)

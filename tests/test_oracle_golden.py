@@ -230,6 +230,32 @@ def test_soft_nms_restatement_matches_reference_source_run(golden, name, args):
     np.testing.assert_allclose(b[:, 4], ref[:, 4], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("tag,S", [("ms", 2), ("ss", 1)])
+def test_test_step_end_restatement_matches_reference_source_run(golden, tag, S):
+    """tests/golden/test_step_end.npz: the reference's own test_step_end bodies (centernet_detection.py:175-225,
+    centernet_multi_pose.py:215-264) executed from source on seeded head maps of two test scales
+    (oracle/gen_golden.py:gen_test_step_end).  Same rows, same order; scores to 1e-6 (soft-NMS decay)."""
+    from oracle import post_ref
+    g = golden("test_step_end.npz")
+    outs = synth.tta_head_maps(int(g["det_seed"]), synth.DET_MAPS, synth.TTA_SIZES)[:S]
+    dets = [ops_ref.ctdet_decode(o["heatmap"].sigmoid(), o["width_height"], reg=o["regression"])[0].numpy() for o in outs]
+    res = post_ref.test_step_end(dets, synth.TTA_METAS[:S], 3)
+    rows = np.concatenate([np.concatenate([res[j], np.full((len(res[j]), 1), j, np.float32)], 1) for j in sorted(res)])
+    ref = g[f"det_{tag}_rows"]
+    assert rows.shape == ref.shape and np.array_equal(rows[:, 5], ref[:, 5])
+    np.testing.assert_allclose(rows[:, :4], ref[:, :4], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 4], ref[:, 4], rtol=1e-6, atol=1e-7)
+    outs = synth.tta_head_maps(int(g["pose_seed"]), synth.POSE_MAPS, synth.TTA_SIZES)[:S]
+    dets = [ops_ref.multi_pose_decode(o["heatmap"].sigmoid(), o["width_height"], o["keypoints"], reg=o["regression"],
+                                      hm_hp=o["heatmap_keypoints"].sigmoid(), hp_offset=o["heatmap_keypoints_offset"])[0].numpy()
+            for o in outs]
+    rows = post_ref.pose_test_step_end(dets, synth.TTA_METAS[:S])
+    ref = g[f"pose_{tag}_rows"]
+    assert rows.shape == ref.shape
+    np.testing.assert_allclose(np.delete(rows, 4, 1), np.delete(ref, 4, 1), rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(rows[:, 4], ref[:, 4], rtol=1e-6, atol=1e-7)
+
+
 def test_test_step_end_restatement_single_scale_is_a_regrouping():
     """Single scale: no NMS, K = 100 = test_max_per_image, so test_step_end only rescales and regroups (centernet_detection.py:189-223)."""
     from oracle import post_ref
