@@ -185,6 +185,40 @@ def init_distributed():
     return rank, local, world
 
 
+class HostFeed:
+    """Pinned host batches -> HBM one step ahead, on a copy stream of its own (what the reference leaves to Lightning's
+    `batch.to(device)`, on the launch stream).  `put(batch)` starts the host->device copy of the NEXT batch while the current
+    step computes; `get()` makes the launch stream wait for that copy only.  Batches are `(image, {name: tensor})`; tensors
+    that are already on the device pass through."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self._q = []
+
+    def _to_dev(self, t):
+        if t.device == self.device:
+            return t
+        assert t.is_pinned(), "HostFeed wants pinned host memory (pageable copies serialise with the launch stream)"
+        return t.to(self.device, non_blocking=True)
+
+    def put(self, batch):
+        x, tgt = batch
+        with torch.cuda.stream(self.stream):
+            dev = (self._to_dev(x), {k: self._to_dev(v) for k, v in tgt.items()})
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._q.append((dev, ev))
+
+    def get(self):
+        dev, ev = self._q.pop(0)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        for t in (dev[0], *dev[1].values()):
+            t.record_stream(cur)              # allocated on the copy stream, consumed on the launch stream
+        return dev
+
+
 class TrainStep:
     """forward + loss + backward (+ gradient exchange) + Adam, i.e. what Lightning's loop does around
     `CenterNet.training_step` (centernet.py:70-80).
@@ -268,7 +302,8 @@ class TrainStep:
 
     def _capture(self, batch):
         x, tgt = batch
-        self._sx, self._st = x.clone(), {k: v.clone() for k, v in tgt.items()}
+        dev = self.opt.flat_p.device           # the static batch lives in HBM; later batches may arrive in (pinned) host memory
+        self._sx, self._st = x.to(dev, copy=True), {k: v.to(dev, copy=True) for k, v in tgt.items()}
         static = (self._sx, self._st)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -333,6 +333,40 @@ def test_graph_replay_host_never_runs_far_ahead():
     assert np.isfinite(float(loss)) and all(bool(torch.isfinite(p).all()) for p in m.parameters())
 
 
+def test_host_feed_prefetch_trains_like_resident_batches():
+    """HostFeed: pinned host batches copied one step ahead on the copy stream give the same losses, step by step, as the same
+    batches resident in HBM (different batch every step, so a late or reordered copy would show)."""
+    from centernet_amd.engine import TrainStep, HostFeed
+    batches = [synth.ctdet_batch(300 + i, 4, 128, 128) for i in range(6)]
+    losses = []
+    for fed in (False, True):
+        m = _model("res_18", 93, torch.float32).train()
+        step = TrainStep(m, lr=1e-6, distributed=False, graph=True)     # tiny steps: each loss is a fingerprint of its batch
+        out = []
+        if fed:
+            feed = HostFeed("cuda:0")
+            host = [(x.pin_memory(), {k: v.pin_memory() for k, v in t.items()}) for x, t in batches]
+            feed.put(host[0])
+            for i in range(len(host)):
+                b = feed.get()
+                if i + 1 < len(host):
+                    feed.put(host[i + 1])
+                out.append(step(b).clone())
+            assert not feed._q
+        else:
+            for x, t in batches:
+                out.append(step((x.to(DEV), {k: v.to(DEV) for k, v in t.items()})).clone())
+        losses.append(torch.stack(out).cpu())
+    # weight gradients are accumulated with fp32 atomics: two runs agree to rounding, not bit for bit
+    assert torch.allclose(losses[0], losses[1], rtol=1e-3), losses
+    assert (losses[0][1:] - losses[0][:-1]).abs().min() > 0.01 * losses[0].mean(), losses[0]    # a swapped batch would show
+    feed = HostFeed("cuda:0")                  # and the bytes themselves, two copies in flight
+    feed.put(host[3]); feed.put(host[4])
+    for i in (3, 4):
+        x, t = feed.get()
+        assert torch.equal(x.cpu(), host[i][0]) and all(torch.equal(t[k].cpu(), host[i][1][k]) for k in t)
+
+
 def test_training_next_to_overlapped_decode_survives(tmp_path):
     """The scenario that exposed the top-K race (see test_decode_is_stable_next_to_other_streams): eager DLA-34 training at the
     bench's size with ctdet_decode forked onto its own stream after every forward pass and a garbage collection per step — it
