@@ -87,7 +87,9 @@ class Tree(nn.Module):
         if self.level_root:
             children.append(bottom)
         if self.levels == 1:
-            x1 = self.tree1(x, residual)
+            # stride-1, same-width tree: the residual IS x, so let the block take its own skip path (the skip gradient then
+            # joins conv1's data gradient in that kernel's epilogue instead of in an element-wise pass of the autograd engine)
+            x1 = self.tree1(x, None if residual is x else residual)
             return self.root(self.tree2(x1), x1, *children)
         x1 = self.tree1(x)
         children.append(x1)
