@@ -303,10 +303,15 @@ def main():
                 "cpu_baseline": None}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a pipe: push it out now so that
+    # the JSON line is the LAST line of stdout, whatever the reader keys on
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
