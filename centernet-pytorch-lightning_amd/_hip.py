@@ -110,13 +110,18 @@ def query(name, *args):
 
 
 _ws = {}
+_ws_retired = []     # outgrown buffers stay allocated: a captured hipGraph (or a kernel still queued) may hold their address
 
 
 def workspace(nbytes, device, tag="ws"):
-    """Persistent per-device scratch buffer (stream-ordered reuse on the current stream)."""
-    key = (tag, torch.device(device).index)
+    """Persistent scratch buffer per (tag, device, stream): reuse is stream-ordered, so a buffer is never shared between two
+    streams (the decode of `TrainStep.post_forward` runs on its own stream next to backward).  When a larger size is asked for,
+    the old buffer is retired, not freed — hipGraphs captured earlier keep replaying into it."""
+    key = (tag, torch.device(device).index, torch.cuda.current_stream().cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf

@@ -80,6 +80,13 @@ class CenterNet(_Base):
                 continue
             name = ".".join([mapping[strip(k).split(".")[0]], "fc"] + parts[2:]).replace("conv.", "")
             heads[("0." if self.num_stacks == 1 else "") + name] = v
+        if self.arch == "hourglass":
+            # centernet.py:55-61: the original hourglass heads are `<head>.<stack>.<layer>`; here `<stack>.<head>.fc.<layer>`,
+            # and the second conv sits in slot 2 of `fc` (slot 1 is the ReLU)
+            def restack(k):
+                p = k.split(".")
+                return ".".join(p[2:3] + p[:2] + p[3:]).replace("fc.1", "fc.2")
+            heads = {restack(k): v for k, v in heads.items()}
         self.heads.load_state_dict(heads, strict=strict)
 
     def forward(self, x):
@@ -119,7 +126,7 @@ class CenterNet(_Base):
     @staticmethod
     def add_model_specific_args(parent_parser):
         parser = ArgumentParser(parents=[parent_parser], add_help=False)
-        parser.add_argument("--arch", default="dla_34", help="backbone architecture: res_18 | res_101 | dla_34")
+        parser.add_argument("--arch", default="dla_34", help="backbone architecture: res_18 | res_101 | resdcn_18 | resdcn_101 | dla_34 | hourglass")
         parser.add_argument("--learning_rate", type=float, default=25e-5)
         parser.add_argument("--learning_rate_milestones", default="90, 120")
         return parser

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
-from .ops import SideGrads, PackArena
+from .ops import SideGrads, PackArena, WeightsEpoch
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -23,7 +23,10 @@ class FlatAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         params = [p for p in params if p.requires_grad]
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # the remaining keys are torch.optim.Adam's defaults (what the reference runs with): carried in the param group so that
+        # a checkpoint of this optimizer loads into torch.optim.Adam unchanged
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                                      capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False))
         self.params = params
         dev = params[0].device
         offs, n = [], 0
@@ -59,6 +62,7 @@ class FlatAdam(torch.optim.Optimizer):
         """Host half of a step (never captured in a graph): mirror t, upload the learning rate only when it changed."""
         g = self.param_groups[0]
         self.t += 1
+        WeightsEpoch.bump()             # the parameters are about to change through raw pointers: eval-mode caches expire
         if self._lr_dev != float(g["lr"]):
             self._lr_dev = float(g["lr"])
             self.hyper[0:1].fill_(self._lr_dev)
@@ -68,6 +72,52 @@ class FlatAdam(torch.optim.Optimizer):
         """restore the step counter (checkpoint resume): host mirror + device copy"""
         self.t = int(t)
         self.hyper[3:4].copy_(torch.tensor([self.t], dtype=torch.int32).view(torch.float32))
+
+    def state_dict(self):
+        """torch.optim.Adam's checkpoint format (`state[i] = {step, exp_avg, exp_avg_sq}` per parameter, `param_groups`), so a
+        checkpoint written under this optimizer resumes under torch.optim.Adam (the reference's, centernet.py:94-95) and back.
+        The moments are copies of the views into the flat buffers."""
+        state = {}
+        if self.t > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.t)),
+                            "exp_avg": self.flat_m[o:o + n].view_as(p).clone(),
+                            "exp_avg_sq": self.flat_v[o:o + n].view_as(p).clone()}
+        groups = [{**{k: v for k, v in g.items() if k != "params"}, "params": list(range(len(self.params)))}
+                  for g in self.param_groups]
+        return {"state": state, "param_groups": groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        """Inverse of `state_dict` (also accepts a torch.optim.Adam checkpoint of the same parameter list): moments into the
+        flat buffers, step counter to the host mirror and the device copy, lr / betas / eps from the param group."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FlatAdam.load_state_dict: expected one param group with "
+                             f"{len(self.params)} parameters, got {[len(g['params']) for g in groups]}")
+        if groups[0].get("weight_decay", 0) or groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            raise NotImplementedError("FlatAdam implements torch.optim.Adam's defaults only (no weight decay / amsgrad / maximize)")
+        for k, v in groups[0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        self.flat_m.zero_()
+        self.flat_v.zero_()
+        t = 0
+        ids = groups[0]["params"]
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            st = sd["state"].get(ids[i], sd["state"].get(str(ids[i])))
+            if st is None:
+                continue
+            n = p.numel()
+            self.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            t = max(t, int(float(st["step"])))
+        if self.flat_p.is_cuda:
+            self.set_step(t)
+        else:
+            self.t = t
+        self._lr_dev = None              # re-upload the learning rate on the next step
 
     @torch.no_grad()
     def launch(self):
@@ -87,6 +137,7 @@ class FlatAdam(torch.optim.Optimizer):
             self.launch()
         else:  # host logic tests (gloo / CPU): same arithmetic with torch ops
             self.t += 1
+            WeightsEpoch.bump()
             gr = self.flat_g * self.grad_scale
             self.flat_m.mul_(b1).add_(gr, alpha=1 - b1)
             self.flat_v.mul_(b2).addcmul_(gr, gr, value=1 - b2)
@@ -307,10 +358,28 @@ class TrainStep:
         static = (self._sx, self._st)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        # the two warm-up steps below are real steps on the first batch; one step per batch is the contract (and what eager mode
+        # does), so the optimizer state, the parameters and the BN buffers are put back before the capture
+        torch.cuda.synchronize()
+        opt = self.opt
+        snap = [t.clone() for t in (opt.flat_p, opt.flat_m, opt.flat_v, opt.hyper)]
+        bufs = [b for b in self.model.buffers()]
+        snap_b = [b.clone() for b in bufs]
+        t0, pend = opt.t, [m._pending for m in self._bns]
         with torch.cuda.stream(side):            # warm-up off the capture stream: workspaces, lazy attributes, allocator
             for _ in range(2):
                 self._eager(static)
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for dst, src in zip((opt.flat_p, opt.flat_m, opt.flat_v, opt.hyper), snap):
+                dst.copy_(src)
+            for dst, src in zip(bufs, snap_b):
+                dst.copy_(src)
+        opt.t = t0
+        for m, n in zip(self._bns, pend):
+            m._pending = n
+        WeightsEpoch.bump()
         torch.cuda.synchronize()
         if os.environ.get("CN_FAIL_CAPTURE"):
             raise RuntimeError("CN_FAIL_CAPTURE set (test hook for the eager fallback)")
@@ -397,6 +466,9 @@ class Trainer:
         dev = next(model.parameters()).device
         to = lambda b: (b[0].to(dev), {k: v.to(dev) for k, v in b[1].items()})
         history = []
+        # centernet.py:94-105: MultiStepLR(milestones, gamma 0.1) stepped once per epoch, on the optimizer that actually steps
+        milestones = [int(m) for m in (getattr(model, "learning_rate_milestones", None) or [])]
+        sched = torch.optim.lr_scheduler.MultiStepLR(step.opt, milestones=milestones) if milestones else None
         for _ in range(self.max_epochs):
             model.train()
             for i, batch in enumerate(train_loader):
@@ -410,4 +482,6 @@ class Trainer:
                         if self.limit_val_batches is not None and i >= self.limit_val_batches:
                             break
                         model.validation_step(to(batch), i)
+            if sched is not None:
+                sched.step()
         return history

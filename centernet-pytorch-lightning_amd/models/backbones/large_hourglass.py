@@ -103,6 +103,7 @@ class HourglassNet(nn.Module):
                  modules=(2, 2, 2, 2, 2, 4), cnv_dim=256, pre_dim=128):
         super().__init__()
         self.nstack, self.out_channels, self.compute_dtype = num_stacks, cnv_dim, compute_dtype
+        self.nchw_out = False                 # True: return the reference's NCHW fp32 maps instead of NHWC handles
         dims, modules = list(dims), list(modules)
         cur = dims[0]
         self.pre = nn.Sequential(StemConvolution(pre_dim, compute_dtype), Residual(3, pre_dim, cur, stride=2))
@@ -122,7 +123,7 @@ class HourglassNet(nn.Module):
                 a = hnn.conv_bn_act(self.inters_[i][0], self.inters_[i][1], inter, None, False)
                 inter = hnn.conv_bn_act(self.cnvs_[i][0], self.cnvs_[i][1], cnv, a, True)
                 inter = self.inters[i](inter)
-        return outs
+        return ops.emit_maps(outs, self.out_channels, self.nchw_out)
 
 
 def get_large_hourglass_net(num_layers=0, compute_dtype=torch.bfloat16, **kwargs):

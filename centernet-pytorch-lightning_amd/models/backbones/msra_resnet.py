@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from ... import nn as hnn
+from ... import ops
 
 
 class BasicBlock(nn.Module):
@@ -62,6 +63,7 @@ class PoseResNet(nn.Module):
     def __init__(self, block, layers, compute_dtype=torch.bfloat16, **kwargs):
         super().__init__()
         self.compute_dtype = compute_dtype
+        self.nchw_out = False                 # True: return the reference's NCHW fp32 maps instead of NHWC handles
         self.inplanes = 64
         self.out_channels = 256
         self.deconv_with_bias = False
@@ -94,7 +96,7 @@ class PoseResNet(nn.Module):
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         for i in range(0, 9, 3):
             x = self.deconv_layers[i + 1](self.deconv_layers[i](x))
-        return [x]
+        return ops.emit_maps([x], self.out_channels, self.nchw_out)
 
     def init_weights(self, num_layers, pretrained=True):
         """msra_resnet.py:209-246 minus the ImageNet download (no network): deconv N(0, 0.001), BN 1/0."""

@@ -212,6 +212,7 @@ class DLASeg(nn.Module):
         assert down_ratio in [2, 4, 8, 16]
         self.first_level = int(math.log2(down_ratio))
         self.last_level = last_level
+        self.nchw_out = False                 # True: return the reference's NCHW fp32 map instead of the NHWC handle
         self.base = globals()[base_name](pretrained=pretrained, compute_dtype=compute_dtype)
         channels = self.base.channels
         scales = [2 ** i for i in range(len(channels[self.first_level:]))]
@@ -232,7 +233,7 @@ class DLASeg(nn.Module):
         x = self.dla_up(self.base(img))
         y = [x[i] for i in range(self.last_level - self.first_level)]   # .clone() of the reference: tensors are never mutated here
         self.ida_up(y, 0, len(y))
-        return [y[-1]]
+        return ops.emit_maps([y[-1]], self.out_channels, self.nchw_out)
 
 
 def get_pose_net(num_layers, down_ratio=4, compute_dtype=torch.bfloat16, pretrained=False):

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import nn as hnn
+from ... import ops
 from .msra_resnet import PoseResNet as _MsraPoseResNet, resnet_spec
 
 
@@ -52,7 +53,7 @@ class PoseResNet(_MsraPoseResNet):
             else:
                 x = bn(dcn(x), None, True)
             x = d[i + 4](d[i + 3](x))
-        return [x]
+        return ops.emit_maps([x], self.out_channels, self.nchw_out)
 
     def init_weights(self, num_layers, pretrained=True):
         """resnet_dcn.py:250-261 minus the ImageNet download (no network): up-path BN weights 1 / biases 0."""

@@ -5,7 +5,12 @@ A head is conv3x3(+bias) -> ReLU -> conv1x1(+bias).  Here the ReLU lives in the 
 mask in the second conv's data-gradient epilogue (`defer_relu_bwd` / `mask_dx`), so a head is two forward launches and
 the hidden activation is never re-read just to be masked; the result leaves the engine as a public NCHW fp32 map
 [B, C, H/4, W/4] (`ops.ToNCHWFn`).
+
+Input contract (heads.py:38-43 takes the backbone's `Tensor[B, C, H, W]`): `CenterHead.forward` accepts the reference's NCHW
+fp32 tensor — converted ONCE for all heads by `ops.FromNCHWFn` (differentiable) — as well as the NHWC handle this package's
+backbones emit by default (tagged by `ops.mark_nhwc`; no conversion).
 """
+import torch
 import torch.nn as nn
 
 from .. import nn as hnn
@@ -48,14 +53,27 @@ class HeadConv(nn.Module):
 class CenterHead(nn.Module):
     """heads.py:28-50: one `HeadConv` per entry of `heads` (declaration order is the output order)."""
 
-    def __init__(self, heads, intermediate_channel, head_conv):
+    def __init__(self, heads, intermediate_channel, head_conv, compute_dtype=None):
         super().__init__()
         self.heads = heads
+        self.intermediate_channel = intermediate_channel
+        self.compute_dtype = compute_dtype      # dtype an NCHW input is converted to (None: bf16 for bf16/fp16 inputs, else fp32)
         for name, channels in heads.items():
             self.add_module(name, HeadConv(channels, intermediate_channel, head_conv))
         self.init_weights()
 
+    def _to_engine(self, x):
+        """NHWC handle -> as is; public [B, C, H, W] tensor -> NHWC activations in the compute dtype (one launch)."""
+        if ops.is_nhwc(x):
+            return x
+        if x.dim() != 4 or x.shape[1] != self.intermediate_channel:
+            raise ValueError(f"CenterHead expects [B, {self.intermediate_channel}, H, W] (or an NHWC handle of this package's "
+                             f"backbones), got {tuple(x.shape)}")
+        dt = self.compute_dtype or (torch.bfloat16 if x.dtype in (torch.bfloat16, torch.float16) else torch.float32)
+        return ops.FromNCHWFn.apply(x, dt)
+
     def forward(self, x):
+        x = self._to_engine(x)
         return {name: self._modules[name](x) for name in self.heads}
 
     def init_weights(self):

@@ -45,7 +45,8 @@ class Conv2d(nn.Module):
 
     def infer(self, x, scale, shift, residual, relu, out_dtype=None):
         """No-grad path: y = act(conv(x)*scale + shift + residual); packed (folded) weights are cached."""
-        key = (x.dtype, self.weight._version, None if scale is None else (scale.data_ptr(), scale._version))
+        key = (x.dtype, self.weight._version, None if self.bias is None else self.bias._version, ops.WeightsEpoch.value,
+               None if scale is None else (scale.data_ptr(), scale._version))
         hit = self._cache.get("k")
         if hit != key:
             wp = ops.pack_weight(self.weight, 1, x.dtype, scale)
@@ -75,8 +76,10 @@ class BatchNorm2d(nn.BatchNorm2d):
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
     def folded(self):
-        """(scale, shift) fp32 of the eval-mode affine; cached per buffer/parameter version."""
-        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version)
+        """(scale, shift) fp32 of the eval-mode affine; cached per buffer/parameter version and per `ops.WeightsEpoch` (the
+        optimizer and the training-mode kernel update parameters / running statistics behind `_version`'s back)."""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               ops.WeightsEpoch.value)
         if self._fold is None or self._fold[0] != key:
             with torch.no_grad():
                 scale = self.weight * torch.rsqrt(self.running_var + self.eps)   # [C] vectors, once per weight version
@@ -87,6 +90,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x, residual=None, relu=True):
         if self.training:
             self._pending += 1
+            ops.WeightsEpoch.bump()              # running_mean / running_var are about to change through raw pointers
             return ops.batch_norm_act(x, self, residual, relu)
         s, b = self.folded()
         return ops.scale_shift_act(x, s, b, residual, relu)
@@ -185,7 +189,7 @@ class DCN(nn.Module):
 
     def infer(self, x, scale, shift, relu):
         """No-grad path with the following BN folded in: offset conv -> sampling -> ONE 1x1 GEMM (+shift, ReLU)."""
-        key = (x.dtype, self.weight._version, self.bias._version, scale.data_ptr(), scale._version)
+        key = (x.dtype, self.weight._version, self.bias._version, ops.WeightsEpoch.value, scale.data_ptr(), scale._version)
         if self._cache.get("k") != key:
             wp = ops.pack_weight(self.weight, 1, x.dtype, scale)
             self._cache = {"k": key, "wp": wp, "b": (self.bias.detach() * scale + shift).contiguous()}

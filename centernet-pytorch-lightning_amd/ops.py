@@ -21,6 +21,17 @@ def rup(x, m):
     return (x + m - 1) // m * m
 
 
+class WeightsEpoch:
+    """Counter of every parameter / BN-buffer update that PyTorch's `_version` cannot see: FlatAdam writes the parameters and
+    cn_bn_train_fwd the running statistics through raw device pointers.  The no-grad caches (packed / BN-folded weights in
+    nn.Conv2d.infer, nn.DCN.infer, nn.BatchNorm2d.folded) key on it next to `_version`."""
+    value = 0
+
+    @classmethod
+    def bump(cls):
+        cls.value += 1
+
+
 def _empty_like_shape(x, shape):
     return torch.empty(shape, dtype=x.dtype, device=x.device)
 
@@ -616,6 +627,46 @@ class ToNCHWFn(Function):
         dx = torch.empty((N, H, W, ld), dtype=dt, device=dy.device)
         call("cn_nchw_to_nhwc", dy.contiguous(), dx, N, C, H, W, ld, dtype_code(dt))
         return dx, None
+
+
+class FromNCHWFn(Function):
+    """Public NCHW fp32 tensor [B,C,H,W] -> NHWC activations (channels zero-padded to a multiple of 16), differentiable: the
+    inverse of ToNCHWFn.  This is the seam a third-party (plain torch, NCHW) backbone enters the HIP heads through."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        N, C, H, W = x.shape
+        cpad = rup(C, 16)
+        out = torch.empty((N, H, W, cpad), dtype=dtype, device=x.device)
+        call("cn_nchw_to_nhwc", x.contiguous().float(), out, N, C, H, W, cpad, dtype_code(dtype))
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, ld = dy.shape
+        dx = torch.empty((N, ctx.C, H, W), dtype=torch.float32, device=dy.device)
+        call("cn_nhwc_to_nchw", dy.contiguous(), dx, N, ctx.C, H, W, ld, dtype_code(dy.dtype))
+        return dx, None
+
+
+def mark_nhwc(t, channels=None):
+    """Tag an engine-internal NHWC activation tensor (shape [B,H,W,Cpad]) so that a consumer at the package boundary can tell it
+    from a public NCHW tensor [B,C,H,W]; `channels` = real channel count (without the padding)."""
+    t._cn_nhwc = int(channels if channels is not None else t.shape[-1])
+    return t
+
+
+def is_nhwc(t):
+    return getattr(t, "_cn_nhwc", None) is not None
+
+
+def emit_maps(maps, out_channels, nchw_out):
+    """What a backbone returns: the reference contract `list[Tensor[B,out_channels,H/4,W/4]]` fp32 NCHW when `nchw_out`
+    (models/__init__.py:14-19), else the engine's NHWC handles, tagged for `heads.CenterHead`."""
+    if nchw_out:
+        return [ToNCHWFn.apply(m, out_channels) for m in maps]
+    return [mark_nhwc(m, out_channels) for m in maps]
 
 
 def to_nhwc(x_nchw, dtype, cpad=None):

