@@ -13,7 +13,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "centernet_hip.h")
-LIB_PATH = os.path.join(_PKG, "libcenternet_hip.so")
+LIB_PATH = os.environ.get("CN_LIB_PATH") or os.path.join(_PKG, "libcenternet_hip.so")   # CN_LIB_PATH: A/B against another build
 
 CN_F32, CN_BF16 = 0, 1
 

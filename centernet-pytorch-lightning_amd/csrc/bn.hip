@@ -26,6 +26,16 @@ static BnLayout bn_layout(int64_t npix, int C, int vec) {
     return L;
 }
 
+// layout of the element-wise passes: same thread -> (row slot, channel vector) map, up to 8 workgroups per CU, >= 4*U rows each
+static BnLayout ew_layout(int64_t npix, int C, int vec) {
+    BnLayout L = bn_layout(npix, C, vec);
+    int64_t want = (npix + (int64_t)L.RPB * 16 - 1) / ((int64_t)L.RPB * 16);
+    int64_t cap = 2048 / L.ycols;
+    L.nblk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
+    L.rows_per_blk = (npix + L.nblk - 1) / L.nblk;
+    return L;
+}
+
 extern "C" size_t cn_bn_workspace_bytes(int64_t npix, int C) {
     (void)npix;
     // partials [BN_MAX_BLOCKS][2][C] fp32 + coefficients [4][C] fp32
@@ -176,57 +186,114 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
     coef[2 * C + c] = (float)(q / (double)npix);
 }
 
+// Element-wise passes with the per-channel coefficients in REGISTERS: a thread owns one 16-byte channel vector (the same one
+// for every pixel row it visits, layout of bn_partial_kernel) and keeps U rows in flight.  The grid-stride form these replace
+// re-loaded 2-5 coefficients per channel from L1 for every vector: 16-40 four-byte loads next to 2-3 sixteen-byte ones
+// (3.7 TB/s on 64ch @128^2; the loads, not HBM, were the limit).
 template <typename T>
 __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                               T* __restrict__ y, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, int64_t nvec, int CV, int relu) {
+                                                              const float* __restrict__ shift, int64_t npix, int C, BnLayout L,
+                                                              int relu) {
     constexpr int V = Vec16<T>::N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = nvec < (1ll << 31) ? (int)((uint32_t)i % (uint32_t)CV) : (int)(i % CV);   // a 64-bit modulo per vector costs more ALU than the vector's FMAs
-        float xv[V], rv[V];
-        Vec16<T>::load(x + i * V, xv);
-        if (res) Vec16<T>::load(res + i * V, rv);
+    constexpr int U = 4;
+    const int tid = threadIdx.x;
+    const int cvl = tid % L.CVB, prow = tid / L.CVB;
+    const int cv = blockIdx.y * L.CVB + cvl;
+    if (prow >= L.RPB || cv >= L.CV) return;
+    float sc[V], sh[V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            float v = fmaf(xv[j], scale[cv * V + j], shift[cv * V + j]);
-            if (res) v += rv[j];
-            if (relu) v = fmaxf(v, 0.f);
-            xv[j] = v;
+    for (int j = 0; j < V; ++j) { sc[j] = scale[cv * V + j]; sh[j] = shift[cv * V + j]; }
+    const int64_t r0 = (int64_t)blockIdx.x * L.rows_per_blk;
+    const int64_t r1 = r0 + L.rows_per_blk < npix ? r0 + L.rows_per_blk : npix;
+    for (int64_t rb = r0 + prow; rb < r1; rb += (int64_t)U * L.RPB) {
+        uint4 xr[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                      // branch-free: rows past the end re-read row rb, their store is skipped
+            const int64_t r = rb + (int64_t)u * L.RPB;
+            const int64_t rc = r < r1 ? r : rb;
+            xr[u] = ldg16(x + rc * C + cv * V);
+            if (res) rr[u] = ldg16(res + rc * C + cv * V);
         }
-        Vec16<T>::store(y + i * V, xv);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + (int64_t)u * L.RPB;
+            float xv[V], rv[V];
+            Vec16<T>::unpack(xr[u], xv);
+            if (res) Vec16<T>::unpack(rr[u], rv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float v = fmaf(xv[j], sc[j], sh[j]);
+                if (res) v += rv[j];
+                if (relu) v = fmaxf(v, 0.f);
+                xv[j] = v;
+            }
+            if (r < r1) Vec16<T>::store(y + r * C + cv * V, xv);
+        }
     }
 }
 
+// dx = a (g' - b - xhat c),  xhat = (x - mean) invstd   ==   a g' + p x + q   with  p = -a c invstd,  q = -a b - p mean
+// (a = gamma invstd, b = mean(g'), c = mean(g' xhat): bn_finalize_bwd_kernel).  g' = ReLU-masked dy.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            const float* __restrict__ ss, T* __restrict__ dx,
-                                                           T* __restrict__ dres, int64_t nvec, int CV, int C, int relu) {
+                                                           T* __restrict__ dres, int64_t npix, int C, BnLayout L, int relu) {
     constexpr int V = Vec16<T>::N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const int cv = nvec < (1ll << 31) ? (int)((uint32_t)i % (uint32_t)CV) : (int)(i % CV);   // a 64-bit modulo per vector costs more ALU than the vector's FMAs
-        float gv[V], xv[V], yv[V];
-        Vec16<T>::load(dy + i * V, gv);
-        Vec16<T>::load(x + i * V, xv);
-        if (relu) {
-            if (y) {
-                Vec16<T>::load(y + i * V, yv);
+    constexpr int U = 4;
+    const int tid = threadIdx.x;
+    const int cvl = tid % L.CVB, prow = tid / L.CVB;
+    const int cv = blockIdx.y * L.CVB + cvl;
+    if (prow >= L.RPB || cv >= L.CV) return;
+    const bool mask_x = relu && y == nullptr;
+    float ca[V], cp[V], cq[V], sc[V], sh[V];
 #pragma unroll
-                for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
-            } else {                                       // same decision as the forward pass, without reading y
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j;
+        const float a = coef[c], b = coef[C + c], cc = coef[2 * C + c], mu = mean[c], is = invstd[c];
+        // same operation order as the two-step form (xh = (x - mu) * is; a * (g - b - xh * cc)) is NOT kept: the fused affine
+        // differs from it by rounding only (fp32), far below the bf16 / 2e-5 test tolerances
+        ca[j] = a;
+        cp[j] = -a * cc * is;
+        cq[j] = -a * b - cp[j] * mu;
+        sc[j] = mask_x ? ss[c] : 0.f;
+        sh[j] = mask_x ? ss[C + c] : 0.f;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * L.rows_per_blk;
+    const int64_t r1 = r0 + L.rows_per_blk < npix ? r0 + L.rows_per_blk : npix;
+    for (int64_t rb = r0 + prow; rb < r1; rb += (int64_t)U * L.RPB) {
+        uint4 gr[U], xr[U], yr[U];
 #pragma unroll
-                for (int j = 0; j < V; ++j) gv[j] = fmaf(xv[j], ss[cv * V + j], ss[C + cv * V + j]) > 0.f ? gv[j] : 0.f;
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + (int64_t)u * L.RPB;
+            const int64_t rc = r < r1 ? r : rb;
+            gr[u] = ldg16(dy + rc * C + cv * V);
+            xr[u] = ldg16(x + rc * C + cv * V);
+            if (relu && !mask_x) yr[u] = ldg16(y + rc * C + cv * V);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + (int64_t)u * L.RPB;
+            float gv[V], xv[V], yv[V];
+            Vec16<T>::unpack(gr[u], gv);
+            Vec16<T>::unpack(xr[u], xv);
+            if (relu) {
+                if (mask_x) {                              // same decision as the forward pass, without reading y
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gv[j] = fmaf(xv[j], sc[j], sh[j]) > 0.f ? gv[j] : 0.f;
+                } else {
+                    Vec16<T>::unpack(yr[u], yv);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
+                }
             }
-        }
-        if (dres) Vec16<T>::store(dres + i * V, gv);
+            if (dres && r < r1) Vec16<T>::store(dres + r * C + cv * V, gv);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const int c = cv * V + j;
-            const float xh = (xv[j] - mean[c]) * invstd[c];
-            xv[j] = coef[c] * (gv[j] - coef[C + c] - xh * coef[2 * C + c]);
+            for (int j = 0; j < V; ++j) xv[j] = fmaf(ca[j], gv[j], fmaf(cp[j], xv[j], cq[j]));
+            if (r < r1) Vec16<T>::store(dx + r * C + cv * V, xv);
         }
-        Vec16<T>::store(dx + i * V, xv);
     }
 }
 
@@ -268,9 +335,9 @@ extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, con
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, coef, save_scale_shift, momentum, eps);
     CN_LAUNCH_CHECK("cn_bn_train_fwd(finalize)");
-    int64_t nvec = npix * (C / V);
-    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, st,
-                                                   (const T*)x, (const T*)residual, (T*)y, coef, coef + C, nvec, C / V, relu));
+    BnLayout E = ew_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, st,
+                                                   (const T*)x, (const T*)residual, (T*)y, coef, coef + C, npix, C, E, relu));
     CN_LAUNCH_CHECK("cn_bn_train_fwd(apply)");
     return CN_OK;
 }
@@ -280,10 +347,10 @@ extern "C" int cn_scale_shift_act(const void* x, const void* residual, void* y, 
     CN_CHECK_ARG(x && y && scale && shift && npix > 0 && C > 0, "cn_scale_shift_act: bad args");
     int V = dtype == CN_F32 ? 4 : 8;
     CN_CHECK_ARG(C % V == 0, "cn_scale_shift_act: C=%d must be a multiple of %d", C, V);
-    int64_t nvec = npix * (C / V);
-    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0,
+    BnLayout E = ew_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0,
                                                    (hipStream_t)stream, (const T*)x, (const T*)residual, (T*)y, scale, shift,
-                                                   nvec, C / V, relu));
+                                                   npix, C, E, relu));
     CN_LAUNCH_CHECK("cn_scale_shift_act");
     return CN_OK;
 }
@@ -309,10 +376,10 @@ extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, con
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, save_invstd,
                        dgamma, dbeta, coef, accumulate);
     CN_LAUNCH_CHECK("cn_bn_train_bwd(finalize)");
-    int64_t nvec = npix * (C / V);
-    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(nvec)), dim3(256), 0, st,
+    BnLayout E = ew_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, st,
                                                    (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, coef,
-                                                   scale_shift, (T*)dx, (T*)dres, nvec, C / V, C, relu));
+                                                   scale_shift, (T*)dx, (T*)dres, npix, C, E, relu));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(apply)");
     return CN_OK;
 }

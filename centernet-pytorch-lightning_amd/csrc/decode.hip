@@ -6,6 +6,8 @@
 // One workgroup (1024 threads) owns one (batch, class) map: the map is read from HBM exactly once (16-byte loads),
 // the peak test and all select passes run out of LDS, and the only HBM writes are K (score, index) pairs.
 #include "common.h"
+#include "topk_stream.h"
+#include <stdlib.h>
 
 #define TK_THREADS 1024
 #define TK_MAXK 256
@@ -246,9 +248,78 @@ __global__ __launch_bounds__(TK_THREADS) void topk_channel_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------ streaming per-class top-K
+// 128x128 maps (512x512 inputs at stride 4: every BASELINE config).  Thread (x4 = tid % 32, rb = tid / 32) owns the 4 columns
+// 4*x4.. of the 16 rows rb*16..: its 16 row loads plus the two halo rows are 18 independent 16-byte loads in flight (a wave's
+// load is two contiguous 512-byte row segments), the vertical 3-max stays in registers and the horizontal one takes the two
+// neighbour columns from the adjacent lanes.  Bytes per map: 64 KB read once (+12 % halo rows, L2 hits), 800 B written.
+__device__ static inline float ts_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+template <bool NMS>
+__global__ __launch_bounds__(TS_THREADS, 3) void topk_map128_kernel(const float* __restrict__ heat, float* __restrict__ scores,
+                                                                    int32_t* __restrict__ inds, int K) {
+    __shared__ TsShared sh;
+    const int tid = threadIdx.x, x4 = tid & 31, row0 = (tid >> 5) * 16;
+    const float* src = heat + (int64_t)blockIdx.x * 16384 + x4 * 4;
+    if (tid == 0) sh.ctl[3] = 0;
+    uint32_t key[64];
+    if (NMS) {
+        float4 raw[18];
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {             // branch-free: rows outside the map re-read a border row and are replaced by -inf
+            const int r = row0 - 1 + j;
+            const int rc = r < 0 ? 0 : (r > 127 ? 127 : r);
+            raw[j] = *reinterpret_cast<const float4*>(src + rc * 128);
+        }
+        const float ninf = -INFINITY;
+        if (row0 == 0) raw[0] = make_float4(ninf, ninf, ninf, ninf);
+        if (row0 == 112) raw[17] = make_float4(ninf, ninf, ninf, ninf);
+        auto hmax = [&](const float4& v) {         // max over (x-1, x, x+1) inside the row; -inf beyond the row ends (max_pool2d padding)
+            float left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
+            left = x4 == 0 ? ninf : left;
+            right = x4 == 31 ? ninf : right;
+            return make_float4(ts_max3(left, v.x, v.y), ts_max3(v.x, v.y, v.z), ts_max3(v.y, v.z, v.w), ts_max3(v.z, v.w, right));
+        };
+        float4 hp = hmax(raw[0]), hc = hmax(raw[1]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 hn = hmax(raw[j + 2]);
+            const float4 c = raw[j + 1];
+            const float mx = ts_max3(hp.x, hc.x, hn.x), my = ts_max3(hp.y, hc.y, hn.y);
+            const float mz = ts_max3(hp.z, hc.z, hn.z), mw = ts_max3(hp.w, hc.w, hn.w);
+            key[4 * j + 0] = ts_f2key(c.x * (mx == c.x ? 1.f : 0.f));       // heat * keep  (utils/decode.py:9-10)
+            key[4 * j + 1] = ts_f2key(c.y * (my == c.y ? 1.f : 0.f));
+            key[4 * j + 2] = ts_f2key(c.z * (mz == c.z ? 1.f : 0.f));
+            key[4 * j + 3] = ts_f2key(c.w * (mw == c.w ? 1.f : 0.f));
+            hp = hc; hc = hn;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 c = *reinterpret_cast<const float4*>(src + (row0 + j) * 128);
+            key[4 * j + 0] = ts_f2key(c.x); key[4 * j + 1] = ts_f2key(c.y); key[4 * j + 2] = ts_f2key(c.z); key[4 * j + 3] = ts_f2key(c.w);
+        }
+    }
+    __syncthreads();
+    float* so = scores + (int64_t)blockIdx.x * K;
+    int32_t* io = inds + (int64_t)blockIdx.x * K;
+    ts_select<64>(key, [&](int s) { return (row0 + (s >> 2)) * 128 + x4 * 4 + (s & 3); }, K, 16384, sh,
+                  [&](int rank, uint32_t k, uint32_t id) { so[rank] = ts_key2f(k); io[rank] = (int32_t)id; });
+}
+
+static bool topk_stream_enabled() {
+    static const bool on = getenv("CN_DISABLE_TOPK_STREAM") == nullptr;
+    return on;
+}
+
 static int launch_topk_channel(const float* heat, float* scores, int32_t* inds, int BC, int H, int W, int K, int apply_nms,
                                hipStream_t st) {
     const int HW = H * W;
+    if (H == 128 && W == 128 && K >= 1 && K <= TS_CAND && topk_stream_enabled() && (((uintptr_t)heat) & 15) == 0) {
+        if (apply_nms) hipLaunchKernelGGL(topk_map128_kernel<true>, dim3(BC), dim3(TS_THREADS), 0, st, heat, scores, inds, K);
+        else hipLaunchKernelGGL(topk_map128_kernel<false>, dim3(BC), dim3(TS_THREADS), 0, st, heat, scores, inds, K);
+        return CN_OK;
+    }
     if (K > TK_MAXK || K > HW || K < 1) { cn_set_error("top-K: need 1 <= K <= min(%d, H*W) (K=%d)", TK_MAXK, K); return CN_EUNSUPPORTED; }
     if (HW > 32 * TK_THREADS) { cn_set_error("top-K: H*W=%d exceeds %d", HW, 32 * TK_THREADS); return CN_EUNSUPPORTED; }
     const size_t smem = (size_t)HW * 4;
@@ -385,6 +456,47 @@ __global__ __launch_bounds__(TK_THREADS) void ctdet_stage2_kernel(const float* _
     }
 }
 
+// stage 2, streaming form (C*K <= 8192): the per-class survivors sit in registers (32 per thread), same select as the map kernel
+__global__ __launch_bounds__(TS_THREADS) void ctdet_stage2_stream_kernel(const float* __restrict__ s1, const int32_t* __restrict__ i1,
+                                                                         const float* __restrict__ wh, const float* __restrict__ reg,
+                                                                         float* __restrict__ det, int64_t* __restrict__ inds_out,
+                                                                         int32_t* __restrict__ cls_out, int C, int H, int W, int K) {
+    __shared__ TsShared sh;
+    __shared__ uint32_t okey[TS_CAND], opos[TS_CAND];
+    const int tid = threadIdx.x, b = blockIdx.x, L = C * K;
+    const int64_t HW = (int64_t)H * W;
+    if (tid == 0) sh.ctl[3] = 0;
+    uint32_t key[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int pos = s * TS_THREADS + tid;
+        key[s] = pos < L ? ts_f2key(s1[(int64_t)b * L + (pos < L ? pos : 0)]) : 0u;
+    }
+    __syncthreads();
+    ts_select<32>(key, [&](int s) { return s * TS_THREADS + tid; }, K, L, sh,
+                  [&](int rank, uint32_t k, uint32_t id) { okey[rank] = k; opos[rank] = id; });
+    __syncthreads();
+    if (tid < K) {
+        const float score = ts_key2f(okey[tid]);
+        const int pos = (int)opos[tid];
+        const int cls = pos / K;
+        const int ind = i1[(int64_t)b * L + pos];
+        float xs = (float)(ind % W), ys = (float)(ind / W);
+        if (reg) {
+            xs = xs + reg[((int64_t)b * 2 + 0) * HW + ind];
+            ys = ys + reg[((int64_t)b * 2 + 1) * HW + ind];
+        } else {
+            xs = xs + 0.5f;
+            ys = ys + 0.5f;
+        }
+        const float w = wh[((int64_t)b * 2 + 0) * HW + ind], h = wh[((int64_t)b * 2 + 1) * HW + ind];
+        float* d = det + ((int64_t)b * K + tid) * 6;
+        d[0] = xs - w / 2; d[1] = ys - h / 2; d[2] = xs + w / 2; d[3] = ys + h / 2; d[4] = score; d[5] = (float)cls;
+        if (inds_out) inds_out[(int64_t)b * K + tid] = ind;
+        if (cls_out) cls_out[(int64_t)b * K + tid] = cls;
+    }
+}
+
 extern "C" size_t cn_ctdet_decode_workspace_bytes(int B, int C, int K) { return (size_t)B * C * K * 8; }
 
 extern "C" int cn_ctdet_decode(const float* heat, const float* wh, const float* reg, float* det, int64_t* inds, int32_t* clses,
@@ -398,6 +510,12 @@ extern "C" int cn_ctdet_decode(const float* heat, const float* wh, const float* 
     int rc = launch_topk_channel(heat, s1, i1, B * C, H, W, K, 1, st);
     if (rc) return rc;
     CN_LAUNCH_CHECK("cn_ctdet_decode(stage1)");
+    if (C * K <= 32 * TS_THREADS && K <= TS_CAND && topk_stream_enabled()) {
+        hipLaunchKernelGGL(ctdet_stage2_stream_kernel, dim3(B), dim3(TS_THREADS), 0, st, (const float*)s1, (const int32_t*)i1, wh, reg,
+                           det, inds, clses, C, H, W, K);
+        CN_LAUNCH_CHECK("cn_ctdet_decode(stage2)");
+        return CN_OK;
+    }
     const size_t smem = (size_t)C * K * 4;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctdet_stage2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(ctdet_stage2_kernel, dim3(B), dim3(TK_THREADS), smem, st, (const float*)s1, (const int32_t*)i1, wh, reg, det,

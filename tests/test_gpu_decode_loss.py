@@ -92,6 +92,73 @@ def test_topk_edge_cases_match_oracle(case):
     assert torch.equal(det.cpu(), rdet)
 
 
+@pytest.mark.parametrize("case", ["plateau", "all_equal", "few_peaks", "negative", "k1", "k256", "bf16_logits", "two_values",
+                                  "ties_cross_rows", "one_bin", "no_nms_random", "no_nms_flat"])
+def test_topk_stream_kernel_edge_cases_128(case):
+    """The streaming top-K (csrc/topk_stream.h: register-resident keys, 12-bit histogram select with early exit, index
+    histograms for ties) only serves 128x128 maps: every tie / plateau / degenerate situation at THAT size, against the oracle."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.utils.decode import _topk_channel
+    B, C, H, W, K = 2, 3, 128, 128, 100
+    heat = torch.sigmoid(rng.t_normal(60, case, (B, C, H, W)))
+    if case == "plateau":
+        heat = (heat * 8).round() / 8
+    elif case == "all_equal":                       # every element ties: the K lowest flat indices win (index histograms)
+        heat = torch.full_like(heat, 0.25)
+    elif case == "few_peaks":                       # fewer than K non-zero peaks: zeros (lowest indices) fill the tail
+        heat = torch.zeros_like(heat); heat[:, :, 5, 7] = 0.9; heat[:, 1, 120, 3] = 0.9; heat[0, 2, 127, 127] = 0.4
+    elif case == "negative":
+        heat = rng.t_normal(60, "neg", (B, C, H, W))
+    elif case == "k1":
+        K = 1
+    elif case == "k256":
+        K = 256
+    elif case == "bf16_logits":                     # head maps of an untrained bf16 network: a handful of distinct values per map
+        heat = torch.sigmoid((rng.t_normal(60, "bf", (B, C, H, W)) * 0.01 - 2.19).to(torch.bfloat16).float())
+    elif case == "two_values":                      # K-th value shared by thousands, a few hundred strictly above it
+        z = rng.t_uniform(60, "tv", (B, C, H, W))
+        heat = torch.where(z > 0.995, torch.full_like(z, 0.75), torch.full_like(z, 0.5))
+    elif case == "ties_cross_rows":                 # the index cut falls in the middle of a row, 3 keys resolved to the last bit
+        heat = torch.zeros_like(heat)
+        heat[:, :, ::3, ::3] = 0.3                  # isolated equal peaks: 43*43 = 1849 of them
+        heat[:, 0, 3, 6] = float(np.nextafter(np.float32(0.3), np.float32(1)))      # one ulp above
+    elif case == "one_bin":                         # distinct values that share key bits [31:8]: resolved by the third pass
+        base = np.float32(0.3).view(np.uint32) & np.uint32(0xffffff00)
+        u = (rng.t_uniform(60, "ob", (B, C, H, W)) * 255).to(torch.int32).numpy().astype(np.uint32)
+        heat = torch.from_numpy((base | u).view(np.float32))
+    if case.startswith("no_nms"):                   # _topk_channel on raw maps (apply_nms = 0)
+        if case == "no_nms_flat":
+            heat = torch.full_like(heat, -1.5)
+        s, i, ys, xs = _topk_channel(heat.to(DEV), K)
+        rs, ri, rys, rxs = ops_ref.topk_channel(heat, K)
+        assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri) and torch.equal(ys.cpu(), rys) and torch.equal(xs.cpu(), rxs)
+        return
+    wh = rng.t_uniform(61, case, (B, 2, H, W), 1, 9); reg = rng.t_uniform(62, case, (B, 2, H, W))
+    det, inds, clses = ctdet_decode(heat.to(DEV), wh.to(DEV), reg.to(DEV), K=K, return_aux=True)
+    rdet, rinds, rcls = ops_ref.ctdet_decode(heat, wh, reg, K=K, return_aux=True)
+    assert torch.equal(inds.cpu(), rinds) and torch.equal(clses.cpu(), rcls)
+    assert torch.equal(det.cpu(), rdet)
+    s, i, _, _ = _topk_channel(ops_ref.nms(heat).to(DEV), min(K, 128))       # per-class lists (stage 1 alone)
+    rs, ri, _, _ = ops_ref.topk_channel(ops_ref.nms(heat), min(K, 128))
+    assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_topk_stream_kernel_fuzz_128(seed):
+    """Random quantisation levels (ties of every multiplicity), random K, 1..5 classes."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    g = torch.Generator().manual_seed(1000 + seed)
+    B, C = 2, int(torch.randint(1, 6, (1,), generator=g))
+    K = int(torch.randint(1, 257, (1,), generator=g))
+    levels = int(2 ** torch.randint(1, 16, (1,), generator=g))
+    heat = torch.sigmoid(torch.randn(B, C, 128, 128, generator=g) * 1.5 - 1.0)
+    heat = (heat * levels).round() / levels
+    wh = torch.rand(B, 2, 128, 128, generator=g) * 20; reg = torch.rand(B, 2, 128, 128, generator=g)
+    det, inds, clses = ctdet_decode(heat.to(DEV), wh.to(DEV), reg.to(DEV), K=K, return_aux=True)
+    rdet, rinds, rcls = ops_ref.ctdet_decode(heat, wh, reg, K=K, return_aux=True)
+    assert torch.equal(inds.cpu(), rinds) and torch.equal(clses.cpu(), rcls) and torch.equal(det.cpu(), rdet)
+
+
 def test_decode_full_size_properties():
     """BASELINE config size (B=64, C=80, 128x128): size-independent properties instead of a CPU oracle run."""
     from centernet_amd.decode.ctdet import ctdet_decode

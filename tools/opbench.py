@@ -1,0 +1,90 @@
+"""Isolated timings of single entry points at the bench's shapes (HIP events on the launch stream, median of N):
+    python tools/opbench.py decode bn            # families: decode bn
+Prints microseconds and the achieved GB/s against the algorithmic bytes of each call."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from centernet_amd import _hip, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def report(name, us, mn, nbytes):
+    print(f"{name:58s} {us:9.1f} us (min {mn:8.1f})  {nbytes / us / 1e3:8.1f} GB/s", flush=True)
+
+
+def bench_decode():
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.decode.multi_pose import multi_pose_decode
+    B, C, H, W = 64, 80, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(3)
+    maps = {"realistic sigmoid(0.5 N - 2.19)": torch.sigmoid(torch.randn(B, C, H, W, generator=g) * 0.5 - 2.19),
+            "bf16 logits of an untrained net": torch.sigmoid((torch.randn(B, C, H, W, generator=g) * 0.01 - 2.19).bfloat16().float()),
+            "flat 0.25": torch.full((B, C, H, W), 0.25)}
+    wh = torch.rand(B, 2, H, W, generator=g).to(DEV) * 30
+    reg = torch.rand(B, 2, H, W, generator=g).to(DEV)
+    for tag, heat in maps.items():
+        heat = heat.to(DEV)
+        us, mn = timeit(lambda: ctdet_decode(heat, wh, reg, K=100))
+        report(f"cn_ctdet_decode B64 C80 128^2 [{tag}]", us, mn, heat.numel() * 4)
+        s = torch.empty(B, C, 100, device=DEV); i = torch.empty(B, C, 100, dtype=torch.int32, device=DEV)
+        us, mn = timeit(lambda: _hip.call("cn_topk_channel", heat, s, i, B, C, H, W, 100, 1))
+        report(f"  cn_topk_channel (stage 1 only)", us, mn, heat.numel() * 4)
+    B = 32
+    d = lambda *sh: torch.rand(*sh, generator=g).to(DEV)
+    heat, hp = torch.sigmoid(d(B, 1, H, W) * 4 - 4), torch.sigmoid(d(B, 17, H, W) * 4 - 4)
+    whp, kps, rg = d(B, 2, H, W), d(B, 34, H, W), reg[:B].contiguous()
+    us, mn = timeit(lambda: multi_pose_decode(heat, whp, kps, reg=rg, hm_hp=hp, hp_offset=rg, K=100))
+    report("cn_multi_pose_decode B32 J17 128^2", us, mn, (1 + 17 + 34 + 6) * B * H * W * 4)
+
+
+def bench_bn():
+    dt = torch.bfloat16
+    for npix, C in [(64 * 128 * 128, 64), (64 * 512 * 512, 16), (64 * 256 * 256, 32), (64 * 64 * 64, 128), (64 * 32 * 32, 256),
+                    (64 * 16 * 16, 512)]:
+        x = torch.randn(npix, C, device=DEV).to(dt)
+        dy = torch.randn(npix, C, device=DEV).to(dt)
+        res = torch.randn(npix, C, device=DEV).to(dt)
+        y, dx, dres = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        stats = torch.empty(4, C, device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        ws, n = ops._bn_ws(npix, C, DEV)
+        code = _hip.dtype_code(dt)
+        nb = npix * C * 2
+
+        def fwd(r):
+            _hip.call("cn_bn_train_fwd", x, r, y, gamma, beta, rm, rv, stats[0], stats[1], stats[2:], npix, C, 0.1, 1e-5, 1, code, ws, n)
+
+        def bwd(yy, dr):
+            _hip.call("cn_bn_train_bwd", dy, x, yy, gamma, stats[0], stats[1], stats[2:], dx, dr, dg, db, 1, npix, C, 1, code, ws, n)
+        us, mn = timeit(lambda: fwd(None)); report(f"cn_bn_train_fwd npix={npix} C={C} relu (3 passes)", us, mn, 3 * nb)
+        us, mn = timeit(lambda: fwd(res)); report(f"cn_bn_train_fwd npix={npix} C={C} +res relu (4 passes)", us, mn, 4 * nb)
+        us, mn = timeit(lambda: bwd(None, None)); report(f"cn_bn_train_bwd npix={npix} C={C} mask from x (5 passes)", us, mn, 5 * nb)
+        us, mn = timeit(lambda: bwd(y, dres)); report(f"cn_bn_train_bwd npix={npix} C={C} +res, mask from y (8 passes)", us, mn, 8 * nb)
+        del x, dy, res, y, dx, dres
+
+
+if __name__ == "__main__":
+    fams = sys.argv[1:] or ["decode", "bn"]
+    print("CN_DISABLE_TOPK_STREAM =", os.environ.get("CN_DISABLE_TOPK_STREAM"))
+    for f in fams:
+        globals()["bench_" + f]()
