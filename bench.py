@@ -5,8 +5,10 @@
 
 One "step" = forward + focal/L1 losses + backward (+ RCCL gradient all-reduce overlapped with backward when N > 1) + Adam
 + ctdet_decode of that step's head maps, on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
-`roofline` is measured live with HIP events around every implicit-GEMM conv launch (on the launch stream) inside the
-timed region; `cpu_baseline` times the torch-CPU oracle (port of the reference path) on the host cores, rank 0, N=1 only.
+`roofline` is measured live with HIP events around EVERY C-ABI launch of the step (on the launch stream): the dominant MFMA-bound
+kernel template over all entry points (convs, weight gradients, the four DCNv2 kernels), plus `roofline.step` for the whole step
+against both roofs.  `inference` is the north-star inference figure of the same config (eval forward + decode, hipGraph).
+`cpu_baseline` times the torch-CPU oracle (port of the reference path) on the host cores, rank 0, N=1 only.
 """
 import argparse
 import json
@@ -24,40 +26,86 @@ PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
 
-class ConvProbe:
-    """HIP-event timing of every cn_conv2d_fwd launch (the conv_igemm_kernel family), grouped by tile variant."""
+# Algorithmic work per image: forward GFLOP and the unfused bf16 activation+weight
+# traffic of the forward pass; a train step is 3x both (data gradient + weight gradient).
+WORK = {"dla_34": (66.20, 289.5), "res_18": (45.43, None), "resdcn_18": (None, None)}
+PEAK_HBM_GBPS = 8000.0
 
-    def __init__(self, hip, all_ops=False):
-        self.hip, self.records, self.orig = hip, [], hip.call
-        self.all_ops = [] if all_ops else None
+
+def _mfma_flops(name, a):
+    """2 * MACs of one launch of an MFMA-bound entry point (None: not an MFMA kernel), from its integer arguments."""
+    if name == "cn_conv2d_fwd":
+        N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed = a[:15]
+        if transposed and stride > 1:   # only the taps of the output pixel's parity class are visited
+            return 2.0 * N * H * W * KH * KW * Ci * Co
+        return 2.0 * N * OH * OW * KH * KW * Ci * Co
+    if name == "cn_conv2d_wgrad":
+        N, H, W, Ci, x_ld, OH, OW, Co, ld, KH, KW = a[:11]
+        return 2.0 * N * OH * OW * KH * KW * Ci * Co
+    if name == "cn_dcn_fwd":
+        N, H, W, Ci, x_ld, Co = a[:6]
+        return 2.0 * N * H * W * 9 * Ci * Co
+    if name == "cn_dcn_wgrad":
+        N, H, W, Ci, x_ld, Co = a[:6]
+        return 2.0 * N * H * W * 9 * Ci * Co
+    if name == "cn_dcn_bwd_dom":
+        slabs, N, H, W, Ci, Co = a[:6]
+        return 2.0 * N * H * W * 9 * Ci * Co
+    if name == "cn_dcn_bwd_dx":
+        N, H, W, Ci, dy_ld = a[:5]
+        return 2.0 * N * H * W * 9 * Ci * dy_ld
+    if name == "cn_conv1x1_smallk":
+        npix, K, k_ld, Co = a[:4]
+        return 2.0 * npix * K * Co
+    return None
+
+
+def _kernel_name(hip, name, a, tn):
+    """rocprofv3's name of the kernel template an MFMA entry point dispatches to (mirrors the launch functions in csrc/)."""
+    if name == "cn_conv2d_fwd":
+        N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed, relu, dt, odt = a[:18]
+        v = hip.lib().cn_conv2d_variant(Ci, Co, KH, KW, stride, pad, dt)
+        waves8 = os.environ.get("CN_CONV3X3_WAVES", "0") in ("0", "8")      # csrc/conv3x3.hip launch3(): 8 waves on the 128x64 tile
+        if v >= 3000000:
+            if v == 3128064 and tn == "bf16" and waves8:
+                return f"conv3x3s1_kernel<{tn},128,64,8>"
+            return f"conv3x3s1_kernel<{tn},{(v - 3000000) // 1000},{v % 1000}>"
+        return f"conv_igemm_kernel<{tn},{v // 1000},{v % 1000}>"
+    blk = lambda c: 128 if c % 128 == 0 else (64 if c % 64 == 0 else 32)
+    if name == "cn_dcn_bwd_dx":
+        N, H, W, Ci, dy_ld = a[:5]
+        return f"dcn_bwd_dx_kernel<{tn},{blk(Ci)},{64 if dy_ld % 64 == 0 else (32 if dy_ld % 32 == 0 else 16)}>"
+    if name == "cn_dcn_bwd_dom":
+        return f"dcn_bwd_dom_kernel<{a[6] if a[6] in (64, 128) else 'generic'}>"       # COP = dy_ld
+    if name == "cn_dcn_fwd":
+        N, H, W, Ci, x_ld, Co = a[:6]
+        return f"dcn_fwd[{Ci}->{Co}]"            # gather kernel or LDS-tile kernel by shape (csrc/dcn.hip)
+    if name == "cn_dcn_wgrad":
+        N, H, W, Ci, x_ld, Co = a[:6]
+        return f"dcn_wgrad_kernel[{Ci}->{Co}]"
+    if name == "cn_conv2d_wgrad":
+        N, H, W, Ci, x_ld, OH, OW, Co, ld, KH, KW, stride = a[:12]
+        return f"conv_wgrad[{KH}x{KW}s{stride} {Ci}->{Co}]"
+    return name
+
+
+class ConvProbe:
+    """HIP-event timing of EVERY C-ABI launch of a step (events on the launch stream, side streams folded into it so that each launch
+    is timed alone), grouped by entry point and, for the MFMA-bound ones, by the kernel template they dispatch to."""
+
+    def __init__(self, hip, tn):
+        self.hip, self.ops, self.orig, self.tn = hip, [], hip.call, tn
 
     def __enter__(self):
-        hip = self.hip
-
         def call(name, *args):
-            if name != "cn_conv2d_fwd":
-                if self.all_ops is None:
-                    return self.orig(name, *args)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = self.orig(name, *args)
-                e1.record()
-                self.all_ops.append((name, tuple(a for a in args if isinstance(a, (int, float)) and not isinstance(a, bool)), e0, e1))
-                return r
-            (x, wp, bias, res, y, N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed, relu, dt, odt) = args
-            if transposed and stride > 1:   # only the taps of the output pixel's parity class are visited
-                macs = N * H * W * KH * KW * Ci * Co          # every (input pixel, tap) pair contributes once
-            else:
-                macs = N * OH * OW * KH * KW * Ci * Co
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.orig(name, *args)
+            r = self.orig(name, *args)
             e1.record()
-            self.records.append((hip.lib().cn_conv2d_variant(Ci, Co, KH, KW, stride, pad, dt), 2.0 * macs, e0, e1,
-                                 (N, H, W, Ci, OH, OW, Co, KH, stride, int(transposed))))
-        hip.call = call
+            self.ops.append((name, tuple(a for a in args if isinstance(a, (int, float)) and not isinstance(a, bool)), e0, e1))
+            return r
+        self.hip.call = call
         import centernet_amd.ops as ops
-        import centernet_amd.nn as hnn
         self._mods = [(ops, ops.call)]
         ops.call = call
         return self
@@ -67,21 +115,9 @@ class ConvProbe:
         for m, f in self._mods:
             m.call = f
 
-    def detail(self, path, steps):
-        by = {}
-        for var, flops, e0, e1, shape in self.records:
-            d = by.setdefault((var,) + shape, [0.0, 0.0, 0])
-            d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
-        with open(path, "w") as f:
-            f.write("variant N H W Ci OH OW Co K stride transposed | calls/step ms/step us/call TFLOP/s GB/s(in+out bf16)\n")
-            for k, (fl, t, n) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-                N, H, W, Ci, OH, OW, Co = k[1:8]
-                byts = 2.0 * N * (H * W * Ci + OH * OW * Co) * n
-                f.write(f"{k} | {n / steps:.0f} {t / steps * 1e3:.3f} {t / n * 1e6:.1f} {fl / t / 1e12:.1f} {byts / t / 1e9:.0f}\n")
-
     def detail_all(self, path, steps):
         by = {}
-        for name, sig, e0, e1 in self.all_ops:
+        for name, sig, e0, e1 in self.ops:
             d = by.setdefault((name,) + sig, [0.0, 0])
             d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += 1
         tot = {}
@@ -93,26 +129,85 @@ class ConvProbe:
             for k, t in sorted(tot.items(), key=lambda kv: -kv[1]):
                 f.write(f"{t / steps * 1e3:9.3f} ms/step  {k}\n")
 
-    def summary(self):
+    def mfma_kernels(self):
+        """{kernel template: [flops, seconds, launches]} over the MFMA-bound launches"""
         by = {}
-        for var, flops, e0, e1, _ in self.records:
-            t = e0.elapsed_time(e1) * 1e-3
-            d = by.setdefault(var, [0.0, 0.0, 0])
-            d[0] += flops; d[1] += t; d[2] += 1
+        for name, sig, e0, e1 in self.ops:
+            fl = _mfma_flops(name, sig)
+            if fl is None:
+                continue
+            d = by.setdefault(_kernel_name(self.hip, name, sig, self.tn), [0.0, 0.0, 0])
+            d[0] += fl; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
         return by
+
+    def entry_points(self):
+        by = {}
+        for name, sig, e0, e1 in self.ops:
+            d = by.setdefault(name, [0.0, 0.0, 0])
+            d[0] += _mfma_flops(name, sig) or 0.0; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        return by
+
+
+def _git_blob_sha(path):
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (FETCH_SIZE and WRITE_SIZE are
-    collected in separate rocprofv3 --pmc runs, see profiles/r01_pmc_traffic.json for the recipe and the gfx950
-    correction); None when no measurement of that kernel is on file."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        return rec["kernels"][kernel]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    collected in separate rocprofv3 --pmc runs; recipe and the gfx950 correction are in the JSON).  The record is stamped with the
+    git blob hash of the kernel's source file: when the source has changed since the measurement the number is stale -> None."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(root, "profiles", fn)) as f:
+                rec = json.load(f)
+            k = rec["kernels"][kernel]
+            src = k.get("source", rec.get("source"))
+            if src and k.get("source_blob_sha", rec.get("source_blob_sha")) != _git_blob_sha(os.path.join(root, src)):
+                continue
+            if not src:
+                continue                 # unstamped record (round 1): cannot be tied to the current kernel source
+            return k["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def inference_rate(model, x, steps=20):
+    """The north-star inference figure, driver-timed: eval forward (BN folded into the conv epilogues) + sigmoid + ctdet_decode of
+    the SAME config (same weights, batch, resolution, bf16), one hipGraph, `steps` replays between two synchronisations."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.utils.decode import sigmoid_clamped
+    was_training = model.training
+    model.eval()
+
+    def infer():
+        with torch.no_grad():
+            out = model(x)[-1]
+            return ctdet_decode(sigmoid_clamped(out["heatmap"]), out["width_height"], reg=out["regression"])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            det = infer()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        det = infer()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert det.shape[0] == x.shape[0] and bool(torch.isfinite(det).all())
+    model.train(was_training)
+    return dt
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -167,13 +262,14 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-launch HIP-event pass that feeds `roofline`")
+    ap.add_argument("--no-inference", action="store_true", help="skip the eval forward + decode sub-measurement (`inference`)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + backward-overlapped RCCL buckets instead of hipGraph replay")
     ap.add_argument("--host-input", default="none", choices=["none", "image", "full"],
                     help="NOT the headline: hand the step pinned HOST buffers (image, or image + dense targets like the reference's "
                          "dataloader) so that the PCIe copy is inside the timed region; DESIGN.md quotes these rates")
     ap.add_argument("--no-prefetch", action="store_true", help="with --host-input: copy on the launch stream (no HostFeed overlap)")
     ap.add_argument("--probe-steps", type=int, default=2)
-    ap.add_argument("--probe-detail", default=None, help="write a per-shape table of the implicit-GEMM launches to this file")
+    ap.add_argument("--probe-detail", default=None, help="write a per-shape table of every launch of a step to this file")
     args = ap.parse_args()
 
     from centernet_amd import _hip, synth
@@ -249,47 +345,75 @@ def main():
     assert det.shape == (args.batch, 100, 6) and bool(torch.isfinite(det).all())
 
     probe = None
-    if rank != 0 and not args.no_probe:      # the probe steps hold collectives: every rank runs them, rank 0 measures
+    tn = "bf16" if dt == torch.bfloat16 else "f32"
+    if rank != 0 and not args.no_probe and step.sync is not None and not step.graph:
+        # eager DP mode: the probe steps hold collectives, so every rank runs them; rank 0 measures.  (Graph mode's probe steps on
+        # rank 0 skip the exchange below: nothing for the other ranks to take part in.)
         side_was, step.side = step.side, False
         for _ in range(args.probe_steps):
             step._eager(batch)
         torch.cuda.synchronize()
         step.side = side_was
     if rank == 0 and not args.no_probe:
-        # same step, launched eagerly, with a HIP event pair around every implicit-GEMM launch on the launch stream
-        probe = ConvProbe(_hip, all_ops=bool(args.probe_detail))
+        # same step, launched eagerly, with a HIP event pair around every launch on the launch stream
+        probe = ConvProbe(_hip, tn)
         side_was, step.side = step.side, False      # weight gradients on the launch stream: every launch is timed alone
+        sync_was = step.sync
+        if step.graph:
+            step.sync = None                        # single-rank probe: no collective in the probe steps
         with probe:
             for _ in range(args.probe_steps):
                 step._eager(batch)
             torch.cuda.synchronize()
-        step.side = side_was
+        step.side, step.sync = side_was, sync_was
         if args.probe_detail:
-            probe.detail(args.probe_detail, args.probe_steps)
-            probe.detail_all(args.probe_detail + ".ops", args.probe_steps)
+            probe.detail_all(args.probe_detail, args.probe_steps)
+
+    inference = None
+    if rank == 0 and world == 1 and not args.no_inference and args.host_input == "none":
+        dt_inf = inference_rate(model, x)
+        inference = {"metric": "images/sec (eval forward + ctdet_decode), same config", "value": round(args.batch / dt_inf, 1),
+                     "unit": "images/s", "ms_per_batch": round(dt_inf * 1e3, 3), "launch": "hipGraph replay", "dtype": args.dtype,
+                     "target": 3000.0}
 
     if rank == 0:
         total_images = args.batch * world * args.steps
         roof = None
-        tn = "bf16" if dt == torch.bfloat16 else "f32"
-        waves8 = os.environ.get("CN_CONV3X3_WAVES", "0") in ("0", "8")      # csrc/conv3x3.hip launch3(): 8 waves on the 128x64 tile
-        kname = lambda v: ((f"conv3x3s1_kernel<{tn},128,64,8>" if (v == 3128064 and tn == "bf16" and waves8) else
-                            f"conv3x3s1_kernel<{tn},{(v - 3000000) // 1000},{v % 1000}>") if v >= 3000000
-                           else f"conv_igemm_kernel<{tn},{v // 1000},{v % 1000}>")
+        peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+        gflop_img, mb_img = WORK.get(args.arch, (None, None)) if args.size == 512 else (None, None)
+        step_s = elapsed / args.steps
+        step_roof = None
+        if gflop_img:
+            tfl = 3.0 * gflop_img * args.batch / step_s / 1e3          # per GPU: every rank runs the same step
+            step_roof = {"tflops": round(tfl, 1), "frac_mfma": round(tfl / peak, 4),
+                         "flop_per_image": f"3 x {gflop_img} GFLOP (SURVEY 8d)"}
+            if mb_img:
+                gbps = 3.0 * mb_img * args.batch / step_s / 1e3
+                step_roof.update({"gbps": round(gbps, 1), "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4),
+                                  "bytes_per_image": f"3 x {mb_img} MB unfused bf16 traffic (SURVEY 8d)"})
         if probe:
-            by = probe.summary()
-            var, (fl, tt, n) = max(by.items(), key=lambda kv: kv[1][1])
-            peak = PEAK_BF16_TFLOPS if dt == torch.bfloat16 else PEAK_F32_TFLOPS
+            by = probe.mfma_kernels()
+            kern, (fl, tt, n) = max(by.items(), key=lambda kv: kv[1][1])
             ach = fl / tt / 1e12
-            allf = sum(v[0] for v in by.values()); allt = sum(v[1] for v in by.values())
+            ig = {k: v for k, v in by.items() if k.startswith("conv3x3s1_kernel") or k.startswith("conv_igemm_kernel")}
+            allf = sum(v[0] for v in ig.values()); allt = sum(v[1] for v in ig.values())
+            eps = probe.entry_points()
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": pmc_traffic(kname(var)),
-                    "how": f"HIP events around each launch, {args.probe_steps} eagerly launched step(s) of the same workload right after the timed region",
-                    "kernel": kname(var),
+                    "traffic": pmc_traffic(kern),
+                    "how": f"HIP events around each launch, {args.probe_steps} eagerly launched step(s) of the same workload right after "
+                           f"the timed region; dominant = largest total time among the MFMA-bound kernel templates of ALL entry points",
+                    "kernel": kern,
                     "launches": n, "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": round(fl / n, 1),
-                    "all_igemm": {"achieved": round(allf / allt / 1e12, 2), "ms_per_step": round(allt / args.probe_steps * 1e3, 3),
-                                  "variants": {kname(k): {"tflops": round(v[0] / v[1] / 1e12, 2), "ms_per_step": round(v[1] / args.probe_steps * 1e3, 3), "launches_per_step": v[2] // args.probe_steps}
-                                               for k, v in sorted(by.items())}}}
+                    "step": step_roof,
+                    "mfma_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "frac": round(v[0] / v[1] / 1e12 / peak, 4),
+                                         "ms_per_step": round(v[1] / args.probe_steps * 1e3, 3),
+                                         "launches_per_step": v[2] // args.probe_steps}
+                                     for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])},
+                    "all_igemm": {"achieved": round(allf / allt / 1e12, 2), "ms_per_step": round(allt / args.probe_steps * 1e3, 3)},
+                    "entry_points_ms_per_step": {k: round(v[1] / args.probe_steps * 1e3, 3)
+                                                 for k, v in sorted(eps.items(), key=lambda kv: -kv[1][1])[:24]}}
+        elif step_roof:
+            roof = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None, "step": step_roof}
         line = {"metric": "images/sec (train step + decode) DLA-34 512\u00d7512 bs=64 at 1/2/4/8 MI355X",
                 "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -300,6 +424,7 @@ def main():
                            "launch": "hipGraph replay (2 graphs/step)" if step.graph else "eager",
                            "final_loss": round(float(loss.detach()), 4)},
                 "roofline": roof,
+                "inference": inference,
                 "cpu_baseline": None}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
-from .ops import SideGrads, PackArena, WeightsEpoch
+from .ops import SideGrads, PackArena, WeightsEpoch, GradReady
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -146,7 +146,14 @@ class FlatAdam(torch.optim.Optimizer):
 
 
 class GradSync:
-    """Bucketed, backward-overlapped SUM all-reduce of FlatAdam.flat_g across ranks (RCCL on GPUs, gloo on CPU)."""
+    """Bucketed SUM all-reduce of FlatAdam.flat_g across ranks (RCCL on GPUs, gloo on CPU), overlapped with backward in BOTH launch
+    modes.  A bucket (~25 MB of consecutive parameters, built in reverse parameter order = the order backward produces them) is
+    exchanged as soon as its last gradient has been ENQUEUED.  Gradients reach the flat buffer three ways — autograd's accumulation
+    (post-accumulate hook), weight-gradient kernels on the side stream, the BN backward on the launch stream — and the last two
+    report through `ops.GradReady`.  The collective is issued from a small fork stream that first waits for everything enqueued
+    so far on the launch stream AND on the weight-gradient stream (a bucket mixes both), so neither of those two streams ever
+    waits for the other or for the network.  Under hipGraph capture the fork, the RCCL kernels and the join are captured into the
+    step's graph: the replayed step overlaps its exchange exactly like the eager one."""
 
     def __init__(self, opt, bucket_bytes=25 << 20, group=None, hooks=True):
         self.opt, self.group = opt, group
@@ -166,36 +173,59 @@ class GradSync:
         for b, (_, _, idx) in enumerate(self.buckets):
             for i in idx:
                 self.bucket_of[i] = b
+        self.index = {id(p): i for i, p in enumerate(opt.params)}
         self.live = None       # params that receive gradients (learned on the first backward)
         self._seen, self._pending, self._works, self._launched = set(), [], [], set()
+        self._fork = self._main = None
+        self.launch_log = []   # (bucket, #parameters noted when it was launched) of the last backward: tests read the interleaving
         if self.exchange and hooks:
-            for i, p in enumerate(opt.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+            for p in opt.params:
+                p.register_post_accumulate_grad_hook(self.note)
 
-    def _make_hook(self, i):
-        def hook(_p):
-            self._seen.add(i)
-            b = self.bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0 and self.live is not None:
-                self._launch(b)
-        return hook
+    def note(self, p):
+        """parameter `p`'s gradient has been enqueued (each parameter is produced once per backward in these networks)"""
+        i = self.index.get(id(p))
+        if i is None or i in self._seen or not self._pending:
+            return
+        self._seen.add(i)
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self.live is not None:
+            self._launch(b)
 
     def _launch(self, b):
         if b in self._launched:
             return
         self._launched.add(b)
+        self.launch_log.append((b, len(self._seen)))
         s, e, _ = self.buckets[b]
-        self._works.append(dist.all_reduce(self.opt.flat_g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        buf = self.opt.flat_g[s:e]
+        if buf.is_cuda:
+            if self._fork is None:
+                self._fork = torch.cuda.Stream()
+            self._fork.wait_stream(self._main)
+            if SideGrads.stream is not None:
+                self._fork.wait_stream(SideGrads.stream)
+            with torch.cuda.stream(self._fork):
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append(work)
 
     def begin(self):
-        """Call before backward."""
-        self._seen, self._works, self._launched = set(), [], set()
+        """Call before backward (on the stream the step is launched on)."""
+        self._seen, self._works, self._launched, self.launch_log = set(), [], set(), []
         live = self.live
         self._pending = [sum(1 for i in idx if live is None or i in live) for _, _, idx in self.buckets]
+        if self.exchange:
+            if self.opt.flat_g.is_cuda:
+                self._main = torch.cuda.current_stream()
+            GradReady.sink = self.note
 
     def finish(self):
-        """Call after backward: launches whatever is left (first step / dead parameters) and waits for all buckets."""
+        """Call after backward (and after the weight-gradient stream was joined): launches whatever is left (first step / dead
+        parameters), then makes the launch stream wait for every bucket."""
+        GradReady.sink = None
         if not self.exchange:
             return
         for b in range(len(self.buckets)):
@@ -204,6 +234,13 @@ class GradSync:
             w.wait()
         if self.live is None:
             self.live = set(self._seen)
+            # one-time audit (first step only; one host sync): a parameter nobody reported must really be dead — an un-reported
+            # deposit site would let its bucket leave before the gradient is written
+            for i, (p, o) in enumerate(zip(self.opt.params, self.opt.offsets)):
+                if i not in self.live and bool(self.opt.flat_g[o:o + p.numel()].any()):
+                    raise RuntimeError(f"GradSync: parameter #{i} {tuple(p.shape)} received a gradient that no hook / "
+                                       "ops.GradReady.note reported")
+        self._pending = []
 
     def allreduce_all(self):
         """Non-overlapped variant (used between the two captured graphs): every bucket, then wait."""
@@ -274,10 +311,11 @@ class TrainStep:
     """forward + loss + backward (+ gradient exchange) + Adam, i.e. what Lightning's loop does around
     `CenterNet.training_step` (centernet.py:70-80).
 
-    graph=False: eager launches; RCCL buckets are issued from grad-ready hooks and overlap backward.
-    graph=True : the ~1600 launches of a step are captured once into two hipGraphs (zero_grad+forward+loss+backward |
-                 Adam+post_step) and replayed, which removes the launch-bound gaps; the all-reduce runs between the two
-                 graphs (79 MB over xGMI is < 1 ms, so losing the overlap costs less than the launch gaps did).
+    graph=False: eager launches.
+    graph=True : the ~1150 launches of a step are captured once into two hipGraphs (zero_grad+forward+loss+backward incl. the
+                 gradient exchange | Adam+post_step) and replayed, which removes the launch-bound gaps.
+    In both modes the RCCL buckets are issued as soon as their gradients are enqueued and overlap the rest of backward
+    (`GradSync`); weight gradients run on the side stream in both modes.
     `post_step` (optional callable, no grad) runs after the optimizer.  `post_forward` (optional callable, no grad) is
     forked onto its own stream right after the forward pass and joined at the end of the step, so work that only needs
     the forward outputs (the bench's ctdet_decode of the head maps) overlaps backward instead of trailing it.
@@ -291,11 +329,10 @@ class TrainStep:
         self.opt = FlatAdam(model.parameters(), lr=lr)
         self.graph, self.post_step, self.post_out = graph, post_step, None
         use_dist = dist.is_initialized() if distributed is None else distributed
-        self.sync = GradSync(self.opt, hooks=not graph) if use_dist else None
-        # weight gradients on a second stream (deposited straight into the flat gradient buffer) unless grad-ready hooks
-        # need autograd to see every parameter gradient (eager multi-GPU mode)
-        hooks_on = self.sync is not None and self.sync.exchange and not graph
-        self.side = SideGrads.enable(side_grads and not hooks_on and self.opt.flat_p.is_cuda and not os.environ.get("CN_NO_SIDE"))
+        self.sync = GradSync(self.opt) if use_dist else None
+        # weight gradients on a second stream, deposited straight into the flat gradient buffer (they report to the exchange
+        # through ops.GradReady, so data parallelism keeps them)
+        self.side = SideGrads.enable(side_grads and self.opt.flat_p.is_cuda and not os.environ.get("CN_NO_SIDE"))
         if self.sync is not None:
             self.sync.broadcast_state(model)
         self._g1 = self._g2 = None
@@ -336,7 +373,7 @@ class TrainStep:
         self._begin_packs()
         loss = self.model.training_step(batch, batch_idx)
         self._fork_post_forward()
-        if self.sync is not None and not self.graph:
+        if self.sync is not None:
             self.sync.begin()
         SideGrads.active = self.side
         loss.backward()
@@ -344,7 +381,7 @@ class TrainStep:
         self._end_packs()
         self._join_post_forward()
         if self.sync is not None:
-            self.sync.allreduce_all() if self.graph else self.sync.finish()
+            self.sync.finish()
         self.opt.step()
         if self.post_step is not None:
             with torch.no_grad():
@@ -391,11 +428,15 @@ class TrainStep:
             self._begin_packs()
             loss = self.model.training_step(static, 0)
             self._fork_post_forward()
+            if self.sync is not None:
+                self.sync.begin()
             SideGrads.active = self.side
             loss.backward()
             SideGrads.join()
             self._end_packs()
             self._join_post_forward()
+            if self.sync is not None:
+                self.sync.finish()         # the bucketed all-reduces are part of the captured graph
             self._loss = loss.detach()
         for m in self._bns:
             m._pending -= 1          # the capture pass ran host code only; nothing executed on the device
@@ -421,6 +462,7 @@ class TrainStep:
                 self._g1 = self._g2 = None
                 self.graph = False
                 SideGrads.pending, SideGrads.active = [], False
+                GradReady.sink = None
                 PackArena.current, self._packs.recording = None, False
                 torch.cuda.synchronize()
                 return self._eager(batch, batch_idx)
@@ -430,8 +472,6 @@ class TrainStep:
                 self._st[k].copy_(v, non_blocking=True)
         self.opt.prepare_step()
         self._g1.replay()
-        if self.sync is not None:
-            self.sync.allreduce_all()
         self._g2.replay()
         for m in self._bns:
             m._pending += 1

@@ -67,6 +67,22 @@ def _far_buffer(shape, device):
     return buf
 
 
+class GradReady:
+    """Deposit notifications for the data-parallel exchange.  Inside a TrainStep most parameter gradients never pass through
+    autograd: weight-gradient kernels (side stream) and the BN backward (launch stream) write straight into the flat gradient
+    buffer.  Every such site calls `GradReady.note(*params)` right after ENQUEUEING its kernels, on the stream that runs them;
+    `engine.GradSync` installs `sink` for the duration of a backward pass and launches a bucket's all-reduce when its last
+    parameter has been noted."""
+    sink = None
+
+    @classmethod
+    def note(cls, *params):
+        if cls.sink is not None:
+            for p in params:
+                if p is not None:
+                    cls.sink(p)
+
+
 class PackArena:
     """Every weight packing a training step needs, produced by ONE launch at the start of the step.
 
@@ -294,6 +310,7 @@ class Conv2dFn(Function):
             def side_work(x=x, dy=dy, bias=ctx.bias_ref):
                 dwp, _ = _wgrad(x, dy, Co, KH, KW, stride, pad, False, db_into=bias.grad if has_bias else None)
                 unpack_wgrad(dwp, Co, Ci, KH, KW, into=weight.grad)
+                GradReady.note(weight, bias)
             SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), x, dy)
         elif ctx.needs_input_grad[1]:
             dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, has_bias and ctx.needs_input_grad[2])
@@ -350,6 +367,7 @@ class ConvTranspose2dFn(Function):
             def side_work(x=x, dy=dy):
                 dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
                 unpack_wgrad(dwp, Ci, Co, KH, KW, into=weight.grad)
+                GradReady.note(weight)
             SideGrads.submit(side_work, x, dy)
         elif ctx.needs_input_grad[1]:
             # dW[ci][co][t] = sum x[n,ih,iw,ci] * dy[n, ih*s-p+kh, iw*s-p+kw, co]: the wgrad kernel with roles swapped
@@ -400,6 +418,7 @@ class StemConvFn(Function):
             def side_work(img=img, dy=dy):  # the kernel accumulates with atomics: deposit straight into weight.grad
                 call("cn_stem_conv_wgrad", img, dy, weight.grad, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2],
                      dtype_code(dy.dtype))
+                GradReady.note(weight)
             SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy)
             return None, None, None, None, None
         dw = torch.zeros_like(weight, dtype=torch.float32)
@@ -443,6 +462,7 @@ class BatchNormActFn(Function):
         if SideGrads.usable(gamma, beta):      # inside a TrainStep: deposit straight into the flat gradient buffer
             call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, gamma.grad, beta.grad, 1, npix, C,
                  int(relu), dtype_code(x.dtype), ws, n)
+            GradReady.note(gamma, beta)
             return dx, None, None, None, None, dres, None
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -538,6 +558,7 @@ class DwDeconvFn(Function):
         if ctx.needs_input_grad[1] and SideGrads.usable(weight):
             def side_work(x=x, dy=dy):
                 call("cn_dwdeconv_bwd_weight", x, dy, weight.grad, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+                GradReady.note(weight)
             SideGrads.submit(side_work, x, dy)
         elif ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight, dtype=torch.float32)
@@ -735,6 +756,7 @@ class DCNv2Fn(Function):
             def side_work():
                 dwp, _ = main_wgrad(ctx.params[0].grad, False)
                 unpack_wgrad(dwp, Co, Ci, 3, 3, into=weight.grad)
+                GradReady.note(weight, ctx.params[0])
             SideGrads.submit(side_work, x, om, dy, col)
         else:
             dwp, db = main_wgrad(None, True)
@@ -786,6 +808,7 @@ class DCNv2Fn(Function):
             def side_work_om(x=x, dom=dom, p1=ctx.params[1], p2=ctx.params[2]):
                 dwp_om, _ = _wgrad(x, dom, 27, 3, 3, 1, 1, False, db_into=p2.grad)
                 unpack_wgrad(dwp_om, 27, Ci, 3, 3, into=p1.grad)
+                GradReady.note(p1, p2)
             SideGrads.submit(side_work_om, x, dom)
         else:
             dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)

@@ -283,9 +283,12 @@ for graph in (False, True):
     rng.fill_state_dict(m, 97)
     m = m.cuda().train()
     step = TrainStep(m, lr=2e-4, graph=graph)
-    assert step.sync is not None and step.sync.exchange
+    assert step.sync is not None and step.sync.exchange and step.side, "weight gradients stay on the side stream under DP"
     out["graph" if graph else "eager"] = [float(step(batch)) for _ in range(4)]
     out["is_graph_" + str(graph)] = bool(step.graph)
+    # buckets leave DURING backward (for the graph: during the captured backward): (bucket, #parameters produced at launch)
+    out["log_" + ("graph" if graph else "eager")] = step.sync.launch_log
+    out["live"] = len(step.sync.live)
 dist.barrier(); dist.destroy_process_group()
 print("RESULT " + json.dumps(out))
 """
@@ -305,9 +308,79 @@ def test_rccl_exchange_next_to_graphs(tmp_path):
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res["is_graph_True"], "capture fell back to eager next to the process group:\n" + r.stderr[-2000:]
     assert all(np.isfinite(res["eager"])) and all(np.isfinite(res["graph"]))
+    for mode in ("eager", "graph"):
+        log = res["log_" + mode]
+        assert len(log) >= 2 and log[0][1] < res["live"], f"{mode}: the first bucket must leave before backward is over: {log}"
+        assert [b for b, _ in log] == sorted(b for b, _ in log), f"{mode}: buckets leave in reverse-layer order: {log}"
     assert res["graph"][0] == pytest.approx(res["eager"][0], rel=1e-4)     # the warm-up steps before the capture are rolled back
     assert res["graph"][1] == pytest.approx(res["eager"][1], rel=5e-3)
     assert res["eager"][3] < res["eager"][0]
+
+
+_GLOO2_SCRIPT = r"""
+import os, sys, json, torch, torch.distributed as dist, torch.multiprocessing as mp
+sys.path.insert(0, os.environ["CN_REPO"])
+from centernet_amd import rng, synth
+from centernet_amd.engine import TrainStep
+from centernet_amd.centernet_detection import CenterNetDetection
+
+def make(arch):
+    m = CenterNetDetection(arch, compute_dtype=torch.float32)
+    rng.fill_state_dict(m, 97)
+    return m.cuda().train()
+
+def batch_of(rank):
+    x, tgt = synth.ctdet_batch(97, 2, 128, 128, start=2 * rank)
+    return x.cuda(), {k: v.cuda() for k, v in tgt.items()}
+
+def worker(rank, world, port, arch, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)          # two ranks on ONE GPU: RCCL refuses that, gloo does not
+    step = TrainStep(make(arch), lr=0.0, graph=False)
+    assert step.sync is not None and step.sync.exchange and step.side
+    b = batch_of(rank)
+    step(b)                                   # learns which parameters are live; every bucket leaves in finish()
+    step(b)                                   # buckets leave while backward is still producing gradients
+    torch.cuda.synchronize()
+    out[rank] = (step.opt.flat_g.cpu(), list(step.sync.launch_log), len(step.sync.live))
+    dist.barrier(); dist.destroy_process_group()
+
+if __name__ == "__main__":
+    arch = sys.argv[1]
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(worker, args=(2, int(os.environ["CN_PORT"]), arch, out), nprocs=2, join=True)
+    ref = 0
+    for r in range(2):                         # what each rank computes on its own, no exchange
+        step = TrainStep(make(arch), lr=0.0, distributed=False, graph=False)
+        step(batch_of(r)); step(batch_of(r))
+        torch.cuda.synchronize()
+        ref = ref + step.opt.flat_g.cpu()
+    g0, log, live = out[0]
+    g1 = out[1][0]
+    err = float((g0 - ref).abs().max() / ref.abs().max())
+    print("RESULT " + json.dumps({"same": bool(torch.equal(g0, g1)), "err": err, "log": log, "live": live,
+                                  "nonzero": float(ref.abs().max())}))
+"""
+
+
+@pytest.mark.parametrize("arch", ["res_18", "dla_34"])
+def test_overlapped_exchange_sums_complete_gradients_two_ranks_one_gpu(tmp_path, arch):
+    """The backward-overlapped bucket exchange with REAL data movement between two ranks (gloo on CUDA tensors, both ranks on
+    this GPU): weight gradients arrive from the side stream and BN gradients from the launch stream through ops.GradReady, the
+    buckets leave mid-backward — and every rank must still end up with exactly g_rank0 + g_rank1.  A bucket that left before
+    its last deposit landed would miss that deposit."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "gloo_two_ranks.py"
+    script.write_text(_GLOO2_SCRIPT)
+    env = dict(os.environ, CN_REPO=repo, CN_PORT=str(29600 + os.getpid() % 300))
+    r = subprocess.run([sys.executable, str(script), arch], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["same"], "both ranks hold the same summed gradient"
+    assert res["nonzero"] > 0 and res["err"] < 2e-5, res      # fp32 atomics in the weight-gradient kernels: order noise only
+    assert len(res["log"]) >= 2 and res["log"][0][1] < res["live"], res["log"]
 
 
 def test_graph_replay_host_never_runs_far_ahead():

@@ -103,55 +103,106 @@ def test_flat_adam_cpu_matches_torch_adam():
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
 
 
+def _toy_net(seed):
+    torch.manual_seed(seed)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 8))
+    dead = torch.nn.Linear(3, 3)                        # never used: no gradient, like the reference's dead DLA projections
+    return net, dead
+
+
+def _toy_batch(it, rank):
+    """uneven per-rank sizes: rank r holds 3 + 2r samples, its loss is normalised by its LOCAL count (Lightning-DDP semantics,
+    like num_pos in utils/losses.py:31-38)"""
+    g = torch.Generator().manual_seed(1000 * it + rank)
+    return torch.randn(3 + 2 * rank, 16, generator=g)
+
+
 def _ddp_worker(rank, world, port, out, between_graphs=False):
     import torch.distributed as dist
     from centernet_amd.engine import FlatAdam, GradSync
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.manual_seed(100 + rank)                       # different init per rank: broadcast must fix it
-    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 8))
-    dead = torch.nn.Linear(3, 3)                        # never used: no gradient, like the reference's dead DLA projections
+    net, dead = _toy_net(100 + rank)                    # different init per rank: broadcast must fix it
     params = list(net.parameters()) + list(dead.parameters())
     opt = FlatAdam(params, lr=1e-2)
-    sync = GradSync(opt, bucket_bytes=256, hooks=not between_graphs)      # graph mode: no hooks, one collective after backward
+    sync = GradSync(opt, bucket_bytes=256, hooks=not between_graphs)      # between_graphs: no hooks, one collective after backward
     sync.broadcast_state(net)
     assert len(sync.buckets) > 2
+    logs = []
     for it in range(3):
-        g = torch.Generator().manual_seed(1000 * it + rank)
-        x = torch.randn(4, 16, generator=g)
         opt.zero_grad()
-        loss = net(x).square().mean()
+        loss = net(_toy_batch(it, rank)).square().mean()
         if between_graphs:
             loss.backward(); sync.allreduce_all()
         else:
             sync.begin(); loss.backward(); sync.finish()
+            logs.append(list(sync.launch_log))
         opt.step()
+    if not between_graphs:
+        # step 0 learns which parameters are live (everything leaves in finish()); from step 1 on the buckets leave DURING
+        # backward: the first one when only its own parameters have been produced
+        n_live = len(sync.live)
+        assert n_live == len(params) - 2 and all(len(l) == len(sync.buckets) for l in logs)
+        assert logs[1][0][1] < n_live and logs[2][0][1] < n_live, logs
+        assert [b for b, _ in logs[1]] != [] and logs[1][-1][1] <= n_live
     out[rank] = opt.flat_p.clone()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("between_graphs", [False, True])
-def test_gradient_buckets_over_gloo_world2(between_graphs):
-    """N>1 path on CPU: ranks end bit-identical, and equal to one process that averages the two gradients itself — with the
-    backward-overlapped buckets of eager mode and with the single collective graph mode runs between its two hipGraphs."""
+@pytest.mark.parametrize("world,between_graphs", [(2, False), (2, True), (4, False)])
+def test_gradient_buckets_over_gloo(world, between_graphs):
+    """N>1 path on CPU: ranks end bit-identical, and equal to one process that averages the per-rank (locally normalised)
+    gradients itself — with the backward-overlapped buckets both launch modes use, with a single collective after backward, and
+    at world size 4 with a dead parameter and uneven per-rank batch sizes."""
     from centernet_amd.engine import FlatAdam
-    port = 29000 + os.getpid() % 2000 + (7 if between_graphs else 0)
+    port = 29000 + os.getpid() % 2000 + 7 * world + (3 if between_graphs else 0)
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_ddp_worker, args=(2, port, out, between_graphs), nprocs=2, join=True)
-    assert torch.equal(out[0], out[1])
-    torch.manual_seed(100)
-    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 8))
-    dead = torch.nn.Linear(3, 3)
+    mp.spawn(_ddp_worker, args=(world, port, out, between_graphs), nprocs=world, join=True)
+    assert all(torch.equal(out[0], out[r]) for r in range(1, world))
+    net, dead = _toy_net(100)
     opt = FlatAdam(list(net.parameters()) + list(dead.parameters()), lr=1e-2)
     for it in range(3):
         opt.zero_grad()
-        for r in range(2):
-            g = torch.Generator().manual_seed(1000 * it + r)
-            (net(torch.randn(4, 16, generator=g)).square().mean() / 2).backward()
+        for r in range(world):
+            (net(_toy_batch(it, r)).square().mean() / world).backward()
         opt.step()
     n = sum(p.numel() for p in net.parameters())
     torch.testing.assert_close(out[0][:n], opt.flat_p[:n], rtol=1e-5, atol=1e-6)
+
+
+def test_grad_sync_counts_direct_deposits():
+    """Gradients that bypass autograd (weight-gradient kernels, BN backward) report through ops.GradReady: a bucket must not
+    leave before its last DIRECT deposit was reported, and an un-reported deposit is caught by the first-step audit."""
+    from centernet_amd import ops
+    from centernet_amd.engine import FlatAdam, GradSync
+    ps = [torch.nn.Parameter(torch.zeros(40)) for _ in range(4)]
+    opt = FlatAdam(ps, lr=1e-2)
+    sync = GradSync(opt, bucket_bytes=300)              # 2 parameters per bucket, reverse order: {3,2}, {1,0}
+    sync.exchange = True                                # exercise the bookkeeping without a process group
+    launched = []
+    sync._launch = lambda b: launched.append((b, sorted(sync._seen)))
+    sync.live = {0, 1, 2, 3}
+    sync.begin()
+    assert ops.GradReady.sink is not None
+    ops.GradReady.note(ps[3])
+    assert launched == []
+    ops.GradReady.note(ps[3], None)                     # a second report of the same parameter does not count twice
+    assert launched == []
+    ops.GradReady.note(ps[2])
+    assert launched == [(0, [2, 3])]
+    ops.GradReady.note(ps[0], ps[1])
+    assert launched[-1] == (1, [0, 1, 2, 3])
+    ops.GradReady.sink = None
+    # audit: a gradient nobody reported
+    sync2 = GradSync(FlatAdam([torch.nn.Parameter(torch.zeros(8))], lr=1e-2))
+    sync2.exchange = True
+    sync2._launch = lambda b: None
+    sync2.begin()
+    sync2.opt.flat_g.fill_(1.0)
+    with pytest.raises(RuntimeError, match="no hook"):
+        sync2.finish()
+    assert ops.GradReady.sink is None
 
 
 def test_synthetic_batches():

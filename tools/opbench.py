@@ -83,6 +83,48 @@ def bench_bn():
         del x, dy, res, y, dx, dres
 
 
+def bench_dcn():
+    """the four DCNv2 kernels at the DLA-34 up-path shapes (batch 64), zero offsets (an untrained net) and N(0, 0.5 px) offsets"""
+    dt = torch.bfloat16
+    code = _hip.dtype_code(dt)
+    shapes = [(128, 64, 64), (64, 128, 64), (64, 128, 128), (32, 256, 128), (32, 256, 256), (16, 512, 256)]
+    if os.environ.get("DCN_SHAPES"):
+        shapes = shapes[:int(os.environ["DCN_SHAPES"])]
+    for HW, Ci, Co in shapes:
+        N = H = W = None
+        N, H, W = 64, HW, HW
+        for tag, sigma in (("zero offsets", 0.0), ("offsets N(0,0.5)", 0.5)):
+            g = torch.Generator(device="cpu").manual_seed(5)
+            x = torch.randn(N, H, W, Ci, device=DEV).to(dt)
+            om = torch.zeros(N, H, W, 32, device=DEV)
+            if sigma:
+                om[..., :18] = torch.randn(N, H, W, 18, device=DEV) * sigma
+                om[..., 18:27] = torch.randn(N, H, W, 9, device=DEV)
+            w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).to(DEV)
+            bias = torch.zeros(Co, device=DEV)
+            wp1, wp0, wp2 = ops.pack_weight(w, 1, dt), ops.pack_weight(w, 0, dt), ops.pack_weight(w, 2, dt)
+            y = torch.empty(N, H, W, Co, device=DEV, dtype=dt)
+            dy = torch.randn(N, H, W, Co, device=DEV).to(dt)
+            flops = 2.0 * N * H * W * 9 * Ci * Co
+            us, mn = timeit(lambda: _hip.call("cn_dcn_fwd", x, om, wp1, bias, y, N, H, W, Ci, Ci, Co, Co, 32, 0, code), n=10)
+            print(f"dcn {Ci:3d}->{Co:3d} @{HW:3d}^2 [{tag:16s}] fwd   {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
+            far = ops._far_buffer((N, H, W, Ci), DEV)
+            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+            slabs = _hip.query("cn_dcn_bwd_dom_slabs", Ci, Co, code)
+            dom = torch.empty((max(slabs, 1), N, H, W, 32), device=DEV)
+            if slabs != Ci // 64:
+                slabs, dom = 1, torch.zeros(1, N, H, W, 32, device=DEV)
+            us, mn = timeit(lambda: _hip.call("cn_dcn_bwd_dom", dy, wp2, x, om, dom, slabs, far, flag, N, H, W, Ci, Co, Co, Ci, 32, code), n=10)
+            print(f"dcn {Ci:3d}->{Co:3d} @{HW:3d}^2 [{tag:16s}] dom   {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
+            dx = torch.empty_like(x)
+            us, mn = timeit(lambda: _hip.call("cn_dcn_bwd_dx", dy, wp0, om, far, flag, dx, N, H, W, Ci, Co, 32, code), n=10)
+            print(f"dcn {Ci:3d}->{Co:3d} @{HW:3d}^2 [{tag:16s}] dx    {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
+            dwp = torch.zeros(ops.rup(Co, 32), 9 * Ci, device=DEV)
+            us, mn = timeit(lambda: _hip.call("cn_dcn_wgrad", x, om, dy, dwp, N, H, W, Ci, Ci, Co, Co, 32, code), n=10)
+            print(f"dcn {Ci:3d}->{Co:3d} @{HW:3d}^2 [{tag:16s}] wgrad {us:8.1f} us  {flops / us / 1e6:7.1f} TF", flush=True)
+            del x, om, y, dy, dx, dom
+
+
 if __name__ == "__main__":
     fams = sys.argv[1:] or ["decode", "bn"]
     print("CN_DISABLE_TOPK_STREAM =", os.environ.get("CN_DISABLE_TOPK_STREAM"))
