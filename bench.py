@@ -408,7 +408,7 @@ def main():
                     "mfma_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "frac": round(v[0] / v[1] / 1e12 / peak, 4),
                                          "ms_per_step": round(v[1] / args.probe_steps * 1e3, 3),
                                          "launches_per_step": v[2] // args.probe_steps}
-                                     for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])},
+                                     for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]},
                     "all_igemm": {"achieved": round(allf / allt / 1e12, 2), "ms_per_step": round(allt / args.probe_steps * 1e3, 3)},
                     "entry_points_ms_per_step": {k: round(v[1] / args.probe_steps * 1e3, 3)
                                                  for k, v in sorted(eps.items(), key=lambda kv: -kv[1][1])[:24]}}

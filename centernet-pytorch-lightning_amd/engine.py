@@ -178,9 +178,21 @@ class GradSync:
         self._seen, self._pending, self._works, self._launched = set(), [], [], set()
         self._fork = self._main = None
         self.launch_log = []   # (bucket, #parameters noted when it was launched) of the last backward: tests read the interleaving
+        self._claimed = set()
         if self.exchange and hooks:
             for p in opt.params:
-                p.register_post_accumulate_grad_hook(self.note)
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        """autograd accumulated (or was handed None for) `p`: counts unless a deferred direct deposit has claimed the parameter —
+        the hook fires when the autograd NODE returns, which is before a side-stream closure has enqueued its kernels"""
+        if self.index.get(id(p)) not in self._claimed:
+            self.note(p)
+
+    def claim(self, p):
+        i = self.index.get(id(p))
+        if i is not None:
+            self._claimed.add(i)
 
     def note(self, p):
         """parameter `p`'s gradient has been enqueued (each parameter is produced once per backward in these networks)"""
@@ -214,18 +226,18 @@ class GradSync:
 
     def begin(self):
         """Call before backward (on the stream the step is launched on)."""
-        self._seen, self._works, self._launched, self.launch_log = set(), [], set(), []
+        self._seen, self._works, self._launched, self.launch_log, self._claimed = set(), [], set(), [], set()
         live = self.live
         self._pending = [sum(1 for i in idx if live is None or i in live) for _, _, idx in self.buckets]
         if self.exchange:
             if self.opt.flat_g.is_cuda:
                 self._main = torch.cuda.current_stream()
-            GradReady.sink = self.note
+            GradReady.sink, GradReady.claim_sink = self.note, self.claim
 
     def finish(self):
         """Call after backward (and after the weight-gradient stream was joined): launches whatever is left (first step / dead
         parameters), then makes the launch stream wait for every bucket."""
-        GradReady.sink = None
+        GradReady.sink = GradReady.claim_sink = None
         if not self.exchange:
             return
         for b in range(len(self.buckets)):
@@ -414,6 +426,7 @@ class TrainStep:
             for dst, src in zip(bufs, snap_b):
                 dst.copy_(src)
         opt.t = t0
+        opt._lr_dev = None               # the restored `hyper` predates the first learning-rate upload
         for m, n in zip(self._bns, pend):
             m._pending = n
         WeightsEpoch.bump()
@@ -462,7 +475,7 @@ class TrainStep:
                 self._g1 = self._g2 = None
                 self.graph = False
                 SideGrads.pending, SideGrads.active = [], False
-                GradReady.sink = None
+                GradReady.sink = GradReady.claim_sink = None
                 PackArena.current, self._packs.recording = None, False
                 torch.cuda.synchronize()
                 return self._eager(batch, batch_idx)

@@ -72,8 +72,11 @@ class GradReady:
     autograd: weight-gradient kernels (side stream) and the BN backward (launch stream) write straight into the flat gradient
     buffer.  Every such site calls `GradReady.note(*params)` right after ENQUEUEING its kernels, on the stream that runs them;
     `engine.GradSync` installs `sink` for the duration of a backward pass and launches a bucket's all-reduce when its last
-    parameter has been noted."""
+    parameter has been noted.  A site whose deposit is DEFERRED (side-stream closures run one submit later) first `claim`s its
+    parameters from inside the autograd node: autograd's post-accumulate hook fires for a parameter even when the node returned
+    None for it (torch 2.10), i.e. before the deferred kernels exist, and must not count as the deposit."""
     sink = None
+    claim_sink = None
 
     @classmethod
     def note(cls, *params):
@@ -81,6 +84,13 @@ class GradReady:
             for p in params:
                 if p is not None:
                     cls.sink(p)
+
+    @classmethod
+    def claim(cls, *params):
+        if cls.claim_sink is not None:
+            for p in params:
+                if p is not None:
+                    cls.claim_sink(p)
 
 
 class PackArena:
@@ -207,12 +217,13 @@ class SideGrads:
     pending = []          # (event on the main stream, closure, tensors) not yet launched
 
     @classmethod
-    def submit(cls, fn, *tensors):
+    def submit(cls, fn, *tensors, claims=()):
         """Run `fn` (weight-gradient launches) on the side stream once everything enqueued on the main stream so far is
         done.  The launch itself is DEFERRED to the next submit()/join(): by then the main stream has enqueued its own
         continuation (the data gradient), so under hipGraph capture that continuation is the FIRST child of the
         producer node and keeps the producer's queue — when the side branch was captured first, replay put main-chain
         kernels behind weight-gradient kernels on the same hardware queue (5 ms of main-stream stalls per step)."""
+        GradReady.claim(*claims)          # `fn` deposits (and reports) these parameters' gradients later
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         cls._flush()
@@ -311,7 +322,7 @@ class Conv2dFn(Function):
                 dwp, _ = _wgrad(x, dy, Co, KH, KW, stride, pad, False, db_into=bias.grad if has_bias else None)
                 unpack_wgrad(dwp, Co, Ci, KH, KW, into=weight.grad)
                 GradReady.note(weight, bias)
-            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), x, dy)
+            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), x, dy, claims=(weight, ctx.bias_ref))
         elif ctx.needs_input_grad[1]:
             dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, has_bias and ctx.needs_input_grad[2])
             dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
@@ -368,7 +379,7 @@ class ConvTranspose2dFn(Function):
                 dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
                 unpack_wgrad(dwp, Ci, Co, KH, KW, into=weight.grad)
                 GradReady.note(weight)
-            SideGrads.submit(side_work, x, dy)
+            SideGrads.submit(side_work, x, dy, claims=(weight,))
         elif ctx.needs_input_grad[1]:
             # dW[ci][co][t] = sum x[n,ih,iw,ci] * dy[n, ih*s-p+kh, iw*s-p+kw, co]: the wgrad kernel with roles swapped
             dwp, _ = _wgrad(dy, x, Ci, KH, KW, stride, pad, False)
@@ -419,7 +430,7 @@ class StemConvFn(Function):
                 call("cn_stem_conv_wgrad", img, dy, weight.grad, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2],
                      dtype_code(dy.dtype))
                 GradReady.note(weight)
-            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy)
+            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy, claims=(weight,))
             return None, None, None, None, None
         dw = torch.zeros_like(weight, dtype=torch.float32)
         call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))
@@ -559,7 +570,7 @@ class DwDeconvFn(Function):
             def side_work(x=x, dy=dy):
                 call("cn_dwdeconv_bwd_weight", x, dy, weight.grad, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
                 GradReady.note(weight)
-            SideGrads.submit(side_work, x, dy)
+            SideGrads.submit(side_work, x, dy, claims=(weight,))
         elif ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight, dtype=torch.float32)
             call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
@@ -757,7 +768,7 @@ class DCNv2Fn(Function):
                 dwp, _ = main_wgrad(ctx.params[0].grad, False)
                 unpack_wgrad(dwp, Co, Ci, 3, 3, into=weight.grad)
                 GradReady.note(weight, ctx.params[0])
-            SideGrads.submit(side_work, x, om, dy, col)
+            SideGrads.submit(side_work, x, om, dy, col, claims=(weight, ctx.params[0]))
         else:
             dwp, db = main_wgrad(None, True)
             dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
@@ -809,7 +820,7 @@ class DCNv2Fn(Function):
                 dwp_om, _ = _wgrad(x, dom, 27, 3, 3, 1, 1, False, db_into=p2.grad)
                 unpack_wgrad(dwp_om, 27, Ci, 3, 3, into=p1.grad)
                 GradReady.note(p1, p2)
-            SideGrads.submit(side_work_om, x, dom)
+            SideGrads.submit(side_work_om, x, dom, claims=(ctx.params[1], ctx.params[2]))
         else:
             dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)
             dw_om = unpack_wgrad(dwp_om, 27, Ci, 3, 3)

@@ -246,9 +246,11 @@ def gen_models101():
         net = msra_resnet.PoseResNet(*msra_resnet.resnet_spec[101])
         # 33 residual blocks: with unit running variances every eval-mode block doubles the variance (maps reach 1e12 and the
         # DCN offsets of resdcn_101 leave the image); var_scale keeps the maps O(1), like the Hourglass fixture
-        model_fixture(f"res101_{'train' if train else 'eval'}.npz", net, 64, 128, 34, train, var_scale=R101_VAR_SCALE)
+        # training mode at 256 px: layer4 normalises over 2 x 8 x 8 = 128 samples per channel (32 at 128 px amplify fp32 summation
+        # order through 33 batch-statistic blocks to 1e-3)
+        model_fixture(f"res101_{'train' if train else 'eval'}.npz", net, 64, 256 if train else 128, 34, train, var_scale=R101_VAR_SCALE)
         net = resnet_dcn.PoseResNet(*resnet_dcn.resnet_spec[101])
-        model_fixture(f"resdcn101_{'train' if train else 'eval'}.npz", net, 64, 128, 35, train, var_scale=R101_VAR_SCALE)
+        model_fixture(f"resdcn101_{'train' if train else 'eval'}.npz", net, 64, 256 if train else 128, 35, train, var_scale=R101_VAR_SCALE)
 
 
 HG_VAR_SCALE = 16.0     # see rng.fill_state_dict: keeps the eval-mode hourglass maps O(1)

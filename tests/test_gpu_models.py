@@ -25,8 +25,8 @@ def _model(arch, seed, dtype, task="ctdet", var_scale=1.0):
 @pytest.mark.parametrize("arch,size,train", [("res_18", 256, False), ("res_18", 256, True),
                                              ("dla_34", 128, False), ("dla_34", 128, True),
                                              ("resdcn_18", 128, False), ("resdcn_18", 128, True),
-                                             ("res_101", 128, False), ("res_101", 128, True),         # Bottleneck (msra_resnet.py:61-100)
-                                             ("resdcn_101", 128, False), ("resdcn_101", 128, True)])
+                                             ("res_101", 128, False), ("res_101", 256, True),         # Bottleneck (msra_resnet.py:61-100)
+                                             ("resdcn_101", 128, False), ("resdcn_101", 256, True)])
 def test_network_fp32_vs_reference_golden(golden, arch, size, train):
     name = arch.replace("_", "") + ("_train" if train else "_eval") + ".npz"
     g = golden(name)

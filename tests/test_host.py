@@ -183,6 +183,20 @@ def test_grad_sync_counts_direct_deposits():
     launched = []
     sync._launch = lambda b: launched.append((b, sorted(sync._seen)))
     sync.live = {0, 1, 2, 3}
+    w = torch.nn.Parameter(torch.ones(3)); w.grad = torch.zeros(3)
+    fired = []
+    w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+
+    class _NoGrad(torch.autograd.Function):             # the premise of `claim`: a None gradient still fires the hook
+        @staticmethod
+        def forward(ctx, x, w):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, dy):
+            return dy, None
+    _NoGrad.apply(torch.ones(2, requires_grad=True), w).sum().backward()
+    assert fired == [1]
     sync.begin()
     assert ops.GradReady.sink is not None
     ops.GradReady.note(ps[3])
@@ -193,7 +207,17 @@ def test_grad_sync_counts_direct_deposits():
     assert launched == [(0, [2, 3])]
     ops.GradReady.note(ps[0], ps[1])
     assert launched[-1] == (1, [0, 1, 2, 3])
-    ops.GradReady.sink = None
+    sync.finish()
+    # autograd's post-accumulate hook fires for a parameter even when its node returned None for it (torch 2.10) — i.e. before a
+    # DEFERRED side-stream deposit exists: a claimed parameter only counts when the deposit itself reports
+    launched.clear()
+    sync.begin()
+    ops.GradReady.claim(ps[3], None)
+    sync._hook(ps[3]); sync._hook(ps[2])
+    assert launched == [], "the hook of a claimed parameter is not its deposit"
+    ops.GradReady.note(ps[3])
+    assert launched == [(0, [2, 3])]
+    ops.GradReady.sink = ops.GradReady.claim_sink = None
     # audit: a gradient nobody reported
     sync2 = GradSync(FlatAdam([torch.nn.Parameter(torch.zeros(8))], lr=1e-2))
     sync2.exchange = True

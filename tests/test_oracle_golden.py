@@ -109,8 +109,8 @@ def test_pose_decode(golden):
 @pytest.mark.parametrize("arch,size,train", [("res_18", 256, False), ("res_18", 256, True),
                                              ("dla_34", 128, False), ("dla_34", 128, True),
                                              ("resdcn_18", 128, False), ("resdcn_18", 128, True),
-                                             ("res_101", 128, False), ("res_101", 128, True),         # Bottleneck (msra_resnet.py:61-100)
-                                             ("resdcn_101", 128, False), ("resdcn_101", 128, True)])
+                                             ("res_101", 128, False), ("res_101", 256, True),         # Bottleneck (msra_resnet.py:61-100)
+                                             ("resdcn_101", 128, False), ("resdcn_101", 256, True)])
 def test_model_matches_reference_graph(golden, arch, size, train):
     name = arch.replace("_", "") + ("_train" if train else "_eval") + ".npz"
     g = golden(name)
