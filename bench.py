@@ -307,7 +307,9 @@ def main():
         out = captured["out"]
         return ctdet_decode(out["heatmap"].detach(), out["width_height"].detach(), reg=out["regression"].detach())
 
-    step = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_forward=decode)   # decode overlaps backward
+    # decode overlaps backward; the resident synthetic batch IS the graph's static input (no per-step device-to-device copy of
+    # inputs that are already in HBM — with --host-input the copy is host -> device and stays in the timed region)
+    step = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_forward=decode, adopt_batch=args.host_input == "none")
 
     def fence():
         torch.cuda.synchronize()
