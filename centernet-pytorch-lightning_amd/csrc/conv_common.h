@@ -7,6 +7,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define CN_MAX_TAPS 16
 #define CN_MAX_CLS 4
+#define CN_MAX_SRC 6
 
 struct ConvGeom {
     const void* x;
@@ -36,6 +37,12 @@ struct ConvGeom {
     const float* res32;   // optional fp32 residual added in the epilogue (pitch res32_ld)
     int res32_ld;
     int epi_tile;         // bf16 output rows are 16-byte aligned vectors: use the LDS-staged epilogue
+    // 1x1 conv over the channel CONCATENATION of nsrc tensors of the same N,H,W (DLA Root, pose_dla_dcn.py:180-188): the K loop
+    // walks the sources one after the other, so torch.cat(x, 1) is never materialised.  nsrc == 0: the single input `x`.
+    int nsrc;
+    const void* xs[CN_MAX_SRC];
+    int xs_c[CN_MAX_SRC];     // channels (= pixel pitch) of each source, multiples of the K slice
+    int xs_k0[CN_MAX_SRC];    // first K index of each source
 };
 
 template <typename T> struct Mma;
@@ -165,7 +172,8 @@ __device__ static inline void conv_epilogue(const ConvGeom& g, f32x16_t (&acc)[N
 // rounding is identical to the direct path.  Block tile = (WGM*MI*32) pixels x (WGN*NJ*32) channels, 256 threads.
 // `ot` needs WGM*32*(BN+4) floats and must not be read by anyone else (caller barriers before the call).
 static inline bool conv_epi_tile_ok(const ConvGeom& g, int dtype) {
-    return dtype == CN_BF16 && !g.y_f32 && g.res32 == nullptr && (g.Co & 7) == 0 && (g.y_ld & 7) == 0 &&
+    // Co == y_ld: this epilogue only writes channels < Co, the activation's zero padding (Co = 40 -> y_ld = 48) is the direct one's job
+    return dtype == CN_BF16 && !g.y_f32 && g.res32 == nullptr && (g.Co & 7) == 0 && g.Co == g.y_ld &&
            (g.res == nullptr || (g.res_ld & 7) == 0) && (((uintptr_t)g.y | (uintptr_t)g.res) & 15) == 0;
 }
 template <int MI, int NJ, int WGM, int WGN, int NT = 256, typename PixFn>

@@ -83,10 +83,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         const int c0 = (step - t * cpt) * BK;
         const int dh = g.dh[cls][t], dw = g.dw[cls][t];
         const int wofs = (int)g.wt[cls][t] * g.Ci + c0 + vcol;
+        // channel concatenation of several sources (1x1 only: one tap, c0 = K index): pick the source this slice lies in —
+        // wave-uniform scalar work, the slice never straddles two sources
+        const T* Xs = X;
+        int ld = g.x_ld, cin = c0;
+        if (g.nsrc > 0) {
+            int sidx = 0;
+#pragma unroll
+            for (int q = 1; q < CN_MAX_SRC; ++q) sidx += (q < g.nsrc && c0 >= g.xs_k0[q]) ? 1 : 0;
+            Xs = reinterpret_cast<const T*>(g.xs[sidx]);
+            ld = g.xs_c[sidx];
+            cin = c0 - g.xs_k0[sidx];
+        }
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             const int ih = a_ihb[p] + dh, iw = a_iwb[p] + dw;
-            qa[p] = ldg16_masked(X, ((a_img[p] + (int64_t)ih * g.W + iw) * g.x_ld + c0 + vcol) * (int64_t)sizeof(T),
+            qa[p] = ldg16_masked(Xs, ((a_img[p] + (int64_t)ih * g.W + iw) * ld + cin + vcol) * (int64_t)sizeof(T),
                                  (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W);
         }
 #pragma unroll
@@ -469,6 +481,51 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     return CN_OK;
 }
 
+// 1x1 / stride 1 conv over the channel concatenation of up to CN_MAX_SRC NHWC tensors (each contiguous: pitch = its channel count)
+extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
+                                  int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
+                                  const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
+                                  int dtype, void* stream) {
+    const void* xs[CN_MAX_SRC] = {x0, x1, x2, x3, x4, x5};
+    const int cs[CN_MAX_SRC] = {c0, c1, c2, c3, c4, c5};
+    CN_CHECK_ARG(nsrc >= 1 && nsrc <= CN_MAX_SRC && wp && y && N > 0 && H > 0 && W > 0 && Co > 0 && y_ld >= Co,
+                 "cn_conv1x1_cat_fwd: bad args");
+    CN_CHECK_ARG(dtype == CN_F32 || dtype == CN_BF16, "cn_conv1x1_cat_fwd: bad dtype %d", dtype);
+    ConvGeom g;
+    memset(&g, 0, sizeof(g));
+    int k = 0, div = 64;
+    for (int i = 0; i < nsrc; ++i) {
+        CN_CHECK_ARG(xs[i] && (((uintptr_t)xs[i]) & 15) == 0 && cs[i] > 0 && cs[i] % 16 == 0,
+                     "cn_conv1x1_cat_fwd: source %d must be a 16-byte aligned tensor with a multiple of 16 channels", i);
+        g.xs[i] = xs[i]; g.xs_c[i] = cs[i]; g.xs_k0[i] = k;
+        k += cs[i];
+        while (cs[i] % div) div >>= 1;          // the K slice has to divide every source
+    }
+    CN_CHECK_ARG((((uintptr_t)wp | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "cn_conv1x1_cat_fwd: pointers must be 16-byte aligned");
+    g.nsrc = nsrc;
+    g.x = xs[0]; g.w = wp; g.bias = bias; g.res = residual; g.y = y;
+    g.N = N; g.H = H; g.W = W; g.Ci = k; g.x_ld = cs[0]; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld; g.res_ld = res_ld;
+    g.ktot = k; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu;
+    const int ncls = build_geom(g, 1, 1, 1, 0, 0);
+    // tile choice of dispatch_igemm with the K slice bounded by the smallest source granule
+    ConvGeom gp = g;
+    gp.Ci = div;                                // pick_tile() only looks at divisibility
+    int bn, bk;
+    pick_tile(div, Co, dtype, &bn, &bk);
+    hipStream_t st = (hipStream_t)stream;
+#define CN_IGC(T_, BN_, BK_) launch_igemm<T_, BN_, BK_>(g, ncls, st)
+    if (dtype == CN_BF16) {
+        if (bn == 128) { if (bk >= 32) CN_IGC(bf16_t, 128, 32); else CN_IGC(bf16_t, 128, 16); }
+        else if (bn == 64) { if (bk == 64) CN_IGC(bf16_t, 64, 64); else if (bk == 32) CN_IGC(bf16_t, 64, 32); else CN_IGC(bf16_t, 64, 16); }
+        else { if (bk == 64) CN_IGC(bf16_t, 32, 64); else if (bk == 32) CN_IGC(bf16_t, 32, 32); else CN_IGC(bf16_t, 32, 16); }
+    } else {
+        if (bn == 128) CN_IGC(float, 128, 16); else if (bn == 64) CN_IGC(float, 64, 16); else CN_IGC(float, 32, 16);
+    }
+#undef CN_IGC
+    CN_LAUNCH_CHECK("cn_conv1x1_cat_fwd");
+    return CN_OK;
+}
+
 // dom / dx_far of the DCNv2 backward, fused into the GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2: [9*Ci][Co_pad16])
 extern "C" int cn_dcn_bwd_dom_slabs(int Ci, int dy_ld, int dtype) {
     static const bool disabled = getenv("CN_DISABLE_DOM_TILE") != nullptr;
@@ -675,6 +732,28 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
         const float v = dwp[(int64_t)a * taps * inner_pad + (int64_t)t * inner_pad + b];
         dw[i] = accumulate ? dw[i] + v : v;
     }
+}
+
+// 1x1 weights, column block: dw[a][col0 + b] (+)= dwp[a][b] for b < B, dw rows of length dw_ld
+__global__ __launch_bounds__(256) void unpack_wgrad_cols_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int A, int B,
+                                                                int inner_pad, int dw_ld, int accumulate) {
+    const int64_t total = (int64_t)A * B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i % B), a = (int)(i / B);
+        const float v = dwp[(int64_t)a * inner_pad + b];
+        float* d = dw + (int64_t)a * dw_ld + b;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+extern "C" int cn_unpack_wgrad_cols(const float* dwp, float* dw, int A, int B, int inner_pad, int dw_ld, int accumulate, void* stream) {
+    CN_CHECK_ARG(dwp && dw && A > 0 && B > 0 && inner_pad >= B && dw_ld >= B, "cn_unpack_wgrad_cols: bad args");
+    int64_t total = (int64_t)A * B;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(unpack_wgrad_cols_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dwp, dw, A, B, inner_pad, dw_ld, accumulate);
+    CN_LAUNCH_CHECK("cn_unpack_wgrad_cols");
+    return CN_OK;
 }
 
 extern "C" int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, int accumulate,

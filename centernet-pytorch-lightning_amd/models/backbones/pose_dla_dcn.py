@@ -48,7 +48,7 @@ class Root(nn.Module):
         self.residual = residual
 
     def forward(self, *xs):
-        return hnn.conv_bn_act(self.conv, self.bn, ops.concat(list(xs)), xs[0] if self.residual else None, True)
+        return hnn.cat_conv_bn_act(self.conv, self.bn, list(xs), xs[0] if self.residual else None, True)
 
 
 class Tree(nn.Module):

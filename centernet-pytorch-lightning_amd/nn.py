@@ -104,6 +104,24 @@ def conv_bn_act_skip(conv, bn, x):
     return conv_bn_act(conv, bn, x), x
 
 
+def cat_conv_bn_act(conv, bn, xs, residual=None, relu=True):
+    """conv1x1(cat(xs, channel)) -> BN -> (+residual) -> ReLU without building the concatenation (DLA Root).  Falls back to
+    concat + conv for anything that is not a bias-free 1x1 / stride-1 conv over 16-channel-aligned sources."""
+    ok = (conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None and 1 <= len(xs) <= 6
+          and all(t.shape[-1] % 16 == 0 for t in xs))
+    if not ok or len(xs) == 1:
+        return conv_bn_act(conv, bn, ops.concat(list(xs)), residual, relu)
+    grad = torch.is_grad_enabled() and (conv.weight.requires_grad or any(t.requires_grad for t in xs))
+    if bn.training or grad:
+        return bn(ops.conv1x1_cat(xs, conv.weight), residual, relu)
+    s, b = bn.folded()                              # eval: BN folded into the packed weights, one launch
+    key = ("cat", xs[0].dtype, conv.weight._version, ops.WeightsEpoch.value, s.data_ptr(), s._version)
+    if conv._cache.get("k") != key:
+        conv._cache = {"k": key, "wp": ops.pack_weight(conv.weight, 1, xs[0].dtype, s), "b": b}
+    return ops.conv1x1_cat_raw([t.contiguous() for t in xs], conv._cache["wp"], conv._cache["b"], residual,
+                               conv.weight.shape[0], relu)
+
+
 def conv_bn_act(conv, bn, x, residual=None, relu=True):
     """conv -> BN -> (+residual) -> ReLU.  One fused kernel in eval/no-grad mode."""
     if bn.training:

@@ -352,6 +352,81 @@ class Conv2dFn(Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+def _cat_args(xs):
+    """(x0..x5, c0..c5, nsrc) of cn_conv1x1_cat_fwd"""
+    if len(xs) > 6:
+        raise RuntimeError("conv1x1_cat: at most 6 sources")
+    ptrs = list(xs) + [None] * (6 - len(xs))
+    chans = [int(t.shape[-1]) for t in xs] + [0] * (6 - len(xs))
+    return (*ptrs, *chans, len(xs))
+
+
+def conv1x1_cat_raw(xs, wp, bias, residual, Co, relu):
+    """y = act(conv1x1(cat(xs, channel)) + bias + residual) without the concatenated tensor (one launch)"""
+    N, H, W, _ = xs[0].shape
+    cp = rup(Co, 16)
+    y = torch.empty((N, H, W, cp), dtype=xs[0].dtype, device=xs[0].device)
+    call("cn_conv1x1_cat_fwd", *_cat_args(xs), wp, bias, residual, y, N, H, W, Co, cp,
+         residual.shape[-1] if residual is not None else 0, int(relu), dtype_code(xs[0].dtype))
+    return y
+
+
+class Conv1x1CatFn(Function):
+    """1x1 conv over torch.cat(xs, 1) (DLA Root, pose_dla_dcn.py:180-188) with the concatenation never materialised: the forward
+    GEMM walks the sources in its K loop; each source's data gradient is its own GEMM over the matching ROWS of the packed
+    data-gradient operand and its weight gradient lands in the matching COLUMNS of weight.grad (no split copies either).
+    weight fp32 [Co, sum C_s, 1, 1]; every C_s a multiple of 16."""
+
+    @staticmethod
+    def forward(ctx, weight, *xs):
+        Co = weight.shape[0]
+        xs = tuple(t.contiguous() for t in xs)
+        assert sum(t.shape[-1] for t in xs) == weight.shape[1], "Root conv: channel counts of the children do not add up"
+        y = conv1x1_cat_raw(xs, pack_weight(weight, 1, xs[0].dtype), None, None, Co, False)
+        ctx.save_for_backward(weight, *xs)
+        ctx.order = SideGrads.next_order()
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, *xs = ctx.saved_tensors
+        Co, Ct = weight.shape[:2]
+        N, H, W, _ = xs[0].shape
+        dy = dy.contiguous()
+        dt = xs[0].dtype
+        chans = [t.shape[-1] for t in xs]
+        offs = [sum(chans[:i]) for i in range(len(xs))]
+        dw = None
+        if ctx.needs_input_grad[0]:
+            side = SideGrads.usable(weight)
+            if not side:
+                dw = torch.zeros((Co, Ct), dtype=torch.float32, device=dy.device)
+
+            def wgrads(into):
+                for x, c, k0 in zip(xs, chans, offs):
+                    dwp, _ = _wgrad(x, dy, Co, 1, 1, 1, 0, False)               # [rup32(Co)][c]
+                    call("cn_unpack_wgrad_cols", dwp, into.view(Co, Ct)[:, k0:], Co, c, c, Ct, int(into is weight.grad))
+            if side:
+                def side_work():
+                    wgrads(weight.grad)
+                    GradReady.note(weight)
+                SideGrads.submit(side_work, dy, *xs, claims=(weight,))
+            else:
+                wgrads(dw)
+                dw = dw.view(Co, Ct, 1, 1)
+        dxs = [None] * len(xs)
+        if any(ctx.needs_input_grad[1:]):
+            wpd = pack_weight(weight, 0, dt)          # rows = input channel (of the concatenation), k = rup(Co, 16)
+            for i, (c, k0) in enumerate(zip(chans, offs)):
+                if ctx.needs_input_grad[1 + i]:
+                    dxs[i] = _igemm(dy, wpd[k0:k0 + c], None, None, c, 1, 1, 1, 0, True, False, H, W)
+        return (dw, *dxs)
+
+
+def conv1x1_cat(xs, weight):
+    return Conv1x1CatFn.apply(weight, *xs)
+
+
 class ConvTranspose2dFn(Function):
     """nn.ConvTranspose2d(Ci,Co,4,stride=2,padding=1,bias=False) — msra_resnet.py:178-187.  weight [Ci,Co,KH,KW]."""
 

@@ -61,6 +61,9 @@ int cn_pack_weight_batch(const void* table, int n_entries, int n_blocks, int dty
 /* inverse of mode 1 for gradients: dw[a][b][t] (+)= dwp[a][t*inner_pad + b] (fp32 -> fp32); accumulate != 0 adds into dw
  * (used to deposit gradients straight into the flat gradient buffer from a side stream) */
 int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, int accumulate, void* stream);
+/* column block of a 1x1 weight gradient: dw[a][b] (+)= dwp[a][b], b < B, with dw pointing at the block's first column and
+ * dw_ld the full row length (the per-source weight gradients of cn_conv1x1_cat_fwd) */
+int cn_unpack_wgrad_cols(const float* dwp, float* dw, int A, int B, int inner_pad, int dw_ld, int accumulate, void* stream);
 
 /* Implicit-GEMM convolution, NHWC.  y[n,oh,ow,co] = act(bias[co] + res[..] + sum_{t,ci} xg * Wp[co][t*Ci+ci])
  *   transposed == 0: xg = x[n, oh*stride - pad + kh, ow*stride - pad + kw, ci]       (nn.Conv2d)
@@ -146,6 +149,15 @@ int cn_dwdeconv_bwd_input(const void* dy, const float* w, void* dx, int N, int H
                           int pad, int OH, int OW, int dtype, void* stream);
 int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp32 [C,k,k] */, int N, int H, int W,
                            int C, int k, int stride, int pad, int OH, int OW, int dtype, void* stream);
+
+/* 1x1 / stride-1 convolution over the channel CONCATENATION of nsrc (<= 6) NHWC tensors of the same N,H,W — DLA's Root:
+ * `conv(torch.cat(x, 1))`, pose_dla_dcn.py:180-188 — without materialising the concatenation: the K loop of the implicit GEMM
+ * walks the sources.  x_i: contiguous [N,H,W,c_i] (c_i a multiple of 16; unused slots NULL / 0); wp = cn_pack_weight mode 1 of
+ * the [Co, sum c_i, 1, 1] weight; epilogue (bias, residual, relu) as cn_conv2d_fwd. */
+int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
+                       int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
+                       const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
+                       int dtype, void* stream);
 
 /* ---- DCNv2 (DCN.dcn_v2.DCN, pose_dla_dcn.py:441-449) --------------------- */
 /* om = conv_offset_mask(x) as NHWC FP32 [P][om_ld] in both compute modes — sampling coordinates stay exact —

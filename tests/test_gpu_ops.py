@@ -283,6 +283,32 @@ def test_dcnv2(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 9, 11, (64, 64), 64), (1, 8, 8, (128, 128, 64, 128), 128), (2, 5, 7, (512, 512, 256), 512),
+                                 (1, 6, 6, (16, 48, 32), 40), (2, 16, 16, (256, 256, 128, 256, 16, 32), 256)])
+def test_conv1x1_over_concatenation_without_cat(cfg, dt):
+    """DLA Root (pose_dla_dcn.py:180-188): conv1x1(torch.cat(children, 1)) with the K loop walking the children — forward, each
+    child's data gradient and the column blocks of the weight gradient against torch's cat + conv2d."""
+    N, H, W, chans, Co = cfg
+    xs = [rng.t_normal(8, f"x{i}{cfg}", (N, c, H, W)) for i, c in enumerate(chans)]
+    w = rng.t_normal(8, f"w{cfg}", (Co, sum(chans), 1, 1), 0, (2.0 / sum(chans)) ** 0.5)
+    xr = [rnd(x, dt).requires_grad_(True) for x in xs]
+    wr = rnd(w, dt).requires_grad_(True)
+    yr = F.conv2d(torch.cat(xr, 1), wr)
+    gy = rng.t_normal(8, f"g{cfg}", tuple(yr.shape))
+    yr.backward(rnd(gy, dt))
+    xg = [to_nhwc(x, dt).requires_grad_(True) for x in xs]
+    wg = w.to(DEV).requires_grad_(True)
+    y = ops().conv1x1_cat(xg, wg)
+    assert y.shape[-1] == (Co + 15) // 16 * 16 and float(y[..., Co:].abs().max() if y.shape[-1] > Co else 0) == 0.0
+    close(to_nchw(y[..., :Co]), yr, dt, "cat conv fwd")
+    gyp = torch.zeros(N, y.shape[-1], H, W); gyp[:, :Co] = gy
+    y.backward(to_nhwc(gyp, dt))
+    for i, (a, b) in enumerate(zip(xg, xr)):
+        close(to_nchw(a.grad), b.grad, dt, f"cat conv dx[{i}]")
+    close(wg.grad, wr.grad, dt, "cat conv dw")
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("chans", [(16, 16), (64, 64), (128, 128)])      # gather kernel, 64-channel tile path, LDS-resident tile kernel
 def test_dcn_border_known_answers_through_the_c_abi(chans, dt):
     """DCNv2 is parity-unpinned (its source is not under /root/reference), so the HIP forward is held to the same HAND-computed
