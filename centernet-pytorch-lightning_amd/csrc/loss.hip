@@ -25,8 +25,39 @@ __global__ __launch_bounds__(256) void sigmoid_clamp_bwd_kernel(const float* __r
     }
 }
 
+// 16-byte form of the streaming loss kernels (n % 4 == 0, 16-byte aligned, gt not broadcast): same per-element arithmetic, four
+// elements per lane per access — the scalar forms ran at 3.4-3.6 TB/s on the 335 MB class heat map.
+__global__ __launch_bounds__(256) void sigmoid_clamp_fwd_vec_kernel(float4* __restrict__ x, float4* __restrict__ y, int64_t n4, float lo) {
+    const float hi = 1.f - lo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = x[i];
+        float* e = &v.x;
+        float4 c;
+        float* ce = &c.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = 1.f / (1.f + expf(-e[j]));
+            e[j] = sg;
+            ce[j] = fminf(fmaxf(sg, lo), hi);
+        }
+        x[i] = v;
+        y[i] = c;
+    }
+}
+
+static inline bool loss_vec_ok(const void* a, const void* b, const void* c, int64_t n) {
+    return n % 4 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0);
+}
+
 extern "C" int cn_sigmoid_clamp_fwd(float* x, float* y, int64_t n, float lo, void* stream) {
     CN_CHECK_ARG(x && y && n > 0, "cn_sigmoid_clamp_fwd: bad args");
+    if (loss_vec_ok(x, y, nullptr, n)) {
+        int64_t g4 = (n / 4 + 255) / 256;
+        hipLaunchKernelGGL(sigmoid_clamp_fwd_vec_kernel, dim3((int)(g4 > 8192 ? 8192 : g4)), dim3(256), 0, (hipStream_t)stream,
+                           (float4*)x, (float4*)y, n / 4, lo);
+        CN_LAUNCH_CHECK("cn_sigmoid_clamp_fwd");
+        return CN_OK;
+    }
     int64_t g = (n + 255) / 256;
     hipLaunchKernelGGL(sigmoid_clamp_fwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, x, y, n, lo);
     CN_LAUNCH_CHECK("cn_sigmoid_clamp_fwd");
@@ -71,6 +102,39 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict_
             const float w = 1.f - g;
             const float w2 = w * w;
             neg += logf(1.f - p) * p * p * (w2 * w2);
+        }
+    }
+    __shared__ float red[3][4];
+    pos = wave_sum(pos); neg = wave_sum(neg); np = wave_sum(np);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = pos; red[1][wv] = neg; red[2][wv] = np; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[blockIdx.x * 3 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        part[blockIdx.x * 3 + 2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void focal_fwd_vec_kernel(const float4* __restrict__ pred, const float4* __restrict__ gt,
+                                                            float* __restrict__ part, int64_t n4) {
+    float pos = 0.f, neg = 0.f, np = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 pv = pred[i], gv = gt[i];
+        const float* pe = &pv.x;
+        const float* ge = &gv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float p = pe[j], g = ge[j];
+            if (g == 1.f) {
+                const float q = 1.f - p;
+                pos += logf(p) * q * q;
+                np += 1.f;
+            } else if (g < 1.f) {
+                const float w = 1.f - g;
+                const float w2 = w * w;
+                neg += logf(1.f - p) * p * p * (w2 * w2);
+            }
         }
     }
     __shared__ float red[3][4];
@@ -147,6 +211,39 @@ __global__ __launch_bounds__(256) void sigmoid_focal_bwd_kernel(const float* __r
     }
 }
 
+__global__ __launch_bounds__(256) void sigmoid_focal_bwd_vec_kernel(const float4* __restrict__ s, const float4* __restrict__ gt,
+                                                                    const float* __restrict__ out4, const float* __restrict__ gout,
+                                                                    float4* __restrict__ dz, int64_t n4, float lo) {
+    const float np = out4[3], hi = 1.f - lo;
+    const float scale = -gout[0] / (np == 0.f ? 1.f : np);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 sv4 = s[i], gv4 = gt[i];
+        const float* se = &sv4.x;
+        const float* ge = &gv4.x;
+        float4 o;
+        float* oe = &o.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sv = se[j], g = ge[j];
+            float d = 0.f;
+            if (sv >= lo && sv <= hi) {
+                const float p = sv;
+                if (g == 1.f) {
+                    const float q = 1.f - p;
+                    d = q * q / p - 2.f * q * logf(p);
+                } else if (g < 1.f) {
+                    const float w = 1.f - g;
+                    const float w2 = w * w;
+                    d = (w2 * w2) * (2.f * p * logf(1.f - p) - p * p / (1.f - p));
+                }
+                d = (d * scale) * p * (1.f - p);
+            }
+            oe[j] = d;
+        }
+        dz[i] = o;
+    }
+}
+
 static int focal_grid(int64_t n) {
     int64_t g = (n + 256 * 8 - 1) / (256 * 8);
     return (int)(g > FOCAL_MAX_BLOCKS ? FOCAL_MAX_BLOCKS : (g < 1 ? 1 : g));
@@ -159,8 +256,12 @@ extern "C" int cn_focal_fwd(const float* pred, const float* gt, float* out4, int
     if (ws_bytes < cn_focal_workspace_bytes(0)) { cn_set_error("cn_focal_fwd: workspace too small"); return CN_EWORKSPACE; }
     const int64_t n = (int64_t)B * C * HW;
     const int grid = focal_grid(n);
-    hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, gt, (float*)ws, n, HW, C, gtB, gtC,
-                       (int)(gtB == B && gtC == C));
+    if (gtB == B && gtC == C && loss_vec_ok(pred, gt, nullptr, n))
+        hipLaunchKernelGGL(focal_fwd_vec_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)pred, (const float4*)gt,
+                           (float*)ws, n / 4);
+    else
+        hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, gt, (float*)ws, n, HW, C, gtB, gtC,
+                           (int)(gtB == B && gtC == C));
     CN_LAUNCH_CHECK("cn_focal_fwd");
     hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, grid, out4);
     CN_LAUNCH_CHECK("cn_focal_fwd(finalize)");
@@ -184,6 +285,13 @@ extern "C" int cn_sigmoid_focal_bwd(const float* x_sig, const float* gt, const f
     CN_CHECK_ARG(x_sig && gt && out4 && gout && dz && B > 0 && C > 0 && HW > 0, "cn_sigmoid_focal_bwd: bad args");
     CN_CHECK_ARG((gtB == B || gtB == 1) && (gtC == C || gtC == 1), "cn_sigmoid_focal_bwd: gt does not broadcast");
     const int64_t n = (int64_t)B * C * HW;
+    if (gtB == B && gtC == C && loss_vec_ok(x_sig, gt, dz, n)) {
+        int64_t g4 = (n / 4 + 255) / 256;
+        hipLaunchKernelGGL(sigmoid_focal_bwd_vec_kernel, dim3((int)(g4 > 8192 ? 8192 : g4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)x_sig, (const float4*)gt, out4, gout, (float4*)dz, n / 4, lo);
+        CN_LAUNCH_CHECK("cn_sigmoid_focal_bwd");
+        return CN_OK;
+    }
     int64_t g = (n + 255) / 256;
     hipLaunchKernelGGL(sigmoid_focal_bwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, x_sig, gt, out4,
                        gout, dz, n, HW, C, gtB, gtC, (int)(gtB == B && gtC == C), lo);
