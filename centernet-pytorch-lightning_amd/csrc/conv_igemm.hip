@@ -538,11 +538,14 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
     CN_CHECK_ARG(dy && wpd2 && x && om && dom && dx_far && N > 0 && H > 0 && W > 0, "cn_dcn_bwd_dom: bad args");
     if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dom: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
     CN_CHECK_ARG(om_ld >= 27 && x_ld >= Ci, "cn_dcn_bwd_dom: bad pitches");
-    CN_CHECK_ARG(dom_slabs == 1 || dom_slabs == cn_dcn_bwd_dom_slabs(Ci, dy_ld, dtype), "cn_dcn_bwd_dom: dom_slabs=%d (ask cn_dcn_bwd_dom_slabs)", dom_slabs);
+    CN_CHECK_ARG(dom_slabs == 1 || dom_slabs == cn_dcn_bwd_dom_slabs(Ci, dy_ld, dtype) ||
+                     (dom_slabs == 0 && Ci == 64 && cn_dcn_bwd_dom_slabs(Ci, dy_ld, dtype) == 1 && dtype == CN_BF16 && (dy_ld == 64 || dy_ld == 128)),
+                 "cn_dcn_bwd_dom: dom_slabs=%d (ask cn_dcn_bwd_dom_slabs; 0 = direct bf16 result, Ci == 64 only)", dom_slabs);
     if (dtype == CN_BF16 && dcn_bwd_dom_tile_launch(dy, wpd2, x, om, dom, dom_slabs, dx_far, far_flag, N, H, W, Ci, Co, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_bwd_dom(tile)");
         return CN_OK;
     }
+    if (dom_slabs == 0) CN_UNSUPPORTED("cn_dcn_bwd_dom: the direct bf16 result needs the tile kernel (CN_DISABLE_DOM_TILE is set?)");
     ConvGeom g;
     memset(&g, 0, sizeof(g));
     g.x = dy; g.w = wpd2; g.y = dom;

@@ -435,6 +435,7 @@ struct DomGeom {
     const bf16_t* dy; const bf16_t* wd2; const bf16_t* x; const float* om; float* dom; float* far; int* far_flag;
     int N, H, W, Ci, Co, dy_ld, x_ld, om_ld;
     int64_t slab;      // elements between the per-channel-block copies of dom (0: one copy, channel blocks meet with atomics)
+    bf16_t* dom16;     // non-null (Ci == 64 only): dom is the FINAL bf16 tensor [P][om_ld], written directly (no fp32 copy + cast pass)
 };
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -673,7 +674,11 @@ __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
                 if (lq == 0 && live) {
                     float* d = g.dom + (int64_t)blockIdx.y * g.slab + (img + (int64_t)h * g.W + w) * g.om_ld;
                     const float vy = sy * mk, vx = sx * mk, vm = sm * mk * (1.f - mk);
-                    if (whole) {
+                    if (g.dom16) {
+                        bf16_t* d16 = g.dom16 + (img + (int64_t)h * g.W + w) * g.om_ld;
+                        d16[2 * tap] = f2bf(vy); d16[2 * tap + 1] = f2bf(vx); d16[18 + tap] = f2bf(vm);
+                        if (tap == 0) for (int c = 27; c < g.om_ld; ++c) d16[c] = 0;
+                    } else if (whole) {
                         d[2 * tap] = vy; d[2 * tap + 1] = vx; d[18 + tap] = vm;
                         if (tap == 0) for (int c = 27; c < g.om_ld; ++c) d[c] = 0.f;     // channel padding
                     }
@@ -701,6 +706,11 @@ bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, con
     g.dy = (const bf16_t*)dy; g.wd2 = (const bf16_t*)wd2; g.x = (const bf16_t*)x; g.om = om; g.dom = dom; g.far = far; g.far_flag = far_flag;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.dy_ld = dy_ld; g.x_ld = x_ld; g.om_ld = om_ld;
     g.slab = (dom_slabs > 1 && dom_slabs == Ci / 64) ? (int64_t)N * H * W * om_ld : 0;
+    g.dom16 = nullptr;
+    if (dom_slabs == 0) {                       // direct bf16 result: only when ONE workgroup column owns every dom row
+        if (Ci != 64) return false;
+        g.dom16 = (bf16_t*)dom;
+    }
     const int ntiles = ((H + DX_TH - 1) / DX_TH) * ((W + DX_TW - 1) / DX_TW) * N;
     int gx = 256 / (Ci / 64);                   // one persistent workgroup per CU
     if (gx < 8) gx = 8;

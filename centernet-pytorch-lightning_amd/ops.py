@@ -868,7 +868,12 @@ class DCNv2Fn(Function):
             dx_far = _far_buffer((N, H, W, Ci), x.device)
             far_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
             slabs = _hip.query("cn_dcn_bwd_dom_slabs", int(Ci), int(dy.shape[-1]), dt)
-            if x.dtype == torch.bfloat16 and slabs == Ci // 64:
+            direct = (x.dtype == torch.bfloat16 and Ci == 64 and slabs == 1 and dy.shape[-1] in (64, 128)
+                      and not _os.environ.get("CN_DISABLE_DOM_TILE"))
+            if direct:
+                # one channel block: the tile kernel writes the final bf16 offset / mask gradient itself
+                slabs, dom32 = 0, torch.empty(om.shape, dtype=x.dtype, device=x.device)
+            elif x.dtype == torch.bfloat16 and slabs == Ci // 64:
                 # tile kernel: one fp32 copy of dom per 64-channel block of x, plain stores (no atomics, nothing to clear)
                 dom32 = torch.empty((slabs,) + tuple(om.shape), dtype=torch.float32, device=x.device)
             else:
@@ -877,7 +882,9 @@ class DCNv2Fn(Function):
                  dy.shape[-1], Ci, om.shape[-1], dt)
             call("cn_dcn_bwd_dx", dy, pack_weight(weight, 0, x.dtype), om, dx_far, far_flag, dx_s, N, H, W, Ci,
                  dy.shape[-1], om.shape[-1], dt)
-            if slabs > 1 or x.dtype != torch.float32:
+            if direct:
+                dom = dom32
+            elif slabs > 1 or x.dtype != torch.float32:
                 dom = torch.empty(om.shape, dtype=x.dtype, device=x.device)
                 call("cn_sum_slabs", dom32, dom, slabs, om.numel(), dt)
             else:

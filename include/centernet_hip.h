@@ -193,7 +193,9 @@ int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int
  * Slabs: with Ci > 64 the offset gradient is summed over 64-channel blocks of x.  Global fp32 atomics for that cost 2.3x
  * the kernel, so the caller may pass dom as S = cn_dcn_bwd_dom_slabs() consecutive copies [S][P][om_ld] (dom_slabs = S):
  * every channel block then writes its own copy with plain stores (all om_ld channels, nothing to clear) and the caller
- * folds them with cn_sum_slabs.  dom_slabs = 1 keeps the single-copy / atomic behaviour. */
+ * folds them with cn_sum_slabs.  dom_slabs = 1 keeps the single-copy / atomic behaviour.  dom_slabs = 0 (bf16, Ci == 64,
+ * cn_dcn_bwd_dom_slabs() == 1): `dom` is the FINAL bf16 tensor [P][om_ld], written directly by the tile kernel — no fp32
+ * copy, no cn_sum_slabs cast pass. */
 int cn_dcn_bwd_dom_slabs(int Ci, int dy_ld, int dtype);
 int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, const float* om, float* dom, int dom_slabs, float* dx_far,
                    int* far_flag, int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, int dtype, void* stream);
