@@ -380,7 +380,13 @@ extern "C" int cn_dcn_wgrad(const void* x, const float* om, const void* dy, floa
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.om = om; g.dwp = dwp;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.om_ld = om_ld; g.ktot = 9 * Ci;
     g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
+    // Co <= 64: all nine taps per workgroup (dY tile read once).  CN_DCN_WGRAD_TAPS3 = three taps per workgroup (blockIdx.z =
+    // kernel row; 48 instead of 144 accumulator registers, three workgroups per CU): 12-28 % faster in isolation (545 -> 480 us on
+    // 64->64 @128^2), but no faster inside the step, where this kernel runs with a background-shaped grid next to the
+    // data-gradient chain (interleaved bench runs: 50.93 vs 50.85 ms) — kept as a switch.
+    static const bool taps3 = getenv("CN_DCN_WGRAD_TAPS3") != nullptr;
     if (Co > 64) launch_dw<128, 64, 3>(g, (hipStream_t)stream);
+    else if (taps3) launch_dw<64, 64, 3>(g, (hipStream_t)stream);
     else launch_dw<64, 64, 9>(g, (hipStream_t)stream);
     CN_LAUNCH_CHECK("cn_dcn_wgrad");
     return CN_OK;
