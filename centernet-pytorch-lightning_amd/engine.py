@@ -348,6 +348,9 @@ class TrainStep:
         self.graph, self.post_step, self.post_out = graph, post_step, None
         use_dist = dist.is_initialized() if distributed is None else distributed
         self.sync = GradSync(self.opt) if use_dist else None
+        # escape hatch: keep the collectives OUT of the captured graph (one all-reduce over the whole flat gradient between the two
+        # graphs, round 1's scheme) if a runtime mishandles captured RCCL kernels; only read in graph mode
+        self._between = bool(os.environ.get("CN_EXCHANGE_BETWEEN_GRAPHS")) and graph
         # weight gradients on a second stream, deposited straight into the flat gradient buffer (they report to the exchange
         # through ops.GradReady, so data parallelism keeps them)
         self.side = SideGrads.enable(side_grads and self.opt.flat_p.is_cuda and not os.environ.get("CN_NO_SIDE"))
@@ -391,7 +394,7 @@ class TrainStep:
         self._begin_packs()
         loss = self.model.training_step(batch, batch_idx)
         self._fork_post_forward()
-        if self.sync is not None:
+        if self.sync is not None and not self._between:
             self.sync.begin()
         SideGrads.active = self.side
         loss.backward()
@@ -399,7 +402,7 @@ class TrainStep:
         self._end_packs()
         self._join_post_forward()
         if self.sync is not None:
-            self.sync.finish()
+            self.sync.allreduce_all() if self._between else self.sync.finish()
         self.opt.step()
         if self.post_step is not None:
             with torch.no_grad():
@@ -448,14 +451,14 @@ class TrainStep:
             self._begin_packs()
             loss = self.model.training_step(static, 0)
             self._fork_post_forward()
-            if self.sync is not None:
+            if self.sync is not None and not self._between:
                 self.sync.begin()
             SideGrads.active = self.side
             loss.backward()
             SideGrads.join()
             self._end_packs()
             self._join_post_forward()
-            if self.sync is not None:
+            if self.sync is not None and not self._between:
                 self.sync.finish()         # the bucketed all-reduces are part of the captured graph
             self._loss = loss.detach()
         for m in self._bns:
@@ -493,6 +496,8 @@ class TrainStep:
                 self._st[k].copy_(v, non_blocking=True)
         self.opt.prepare_step()
         self._g1.replay()
+        if self.sync is not None and self._between:
+            self.sync.allreduce_all()
         self._g2.replay()
         for m in self._bns:
             m._pending += 1

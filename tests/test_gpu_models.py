@@ -285,10 +285,16 @@ assert dist.is_initialized() and dist.get_backend() == "nccl"
 x, tgt = synth.ctdet_batch(97, 2, 128, 128)
 batch = (x.cuda(), {k: v.cuda() for k, v in tgt.items()})
 out = {}
-for graph in (False, True):
+for graph in (False, True, "between"):
     m = CenterNetDetection("res_18", compute_dtype=torch.float32)
     rng.fill_state_dict(m, 97)
     m = m.cuda().train()
+    if graph == "between":                       # escape hatch: collectives outside the captured graph
+        os.environ["CN_EXCHANGE_BETWEEN_GRAPHS"] = "1"
+        step = TrainStep(m, lr=2e-4, graph=True)
+        out["between"] = [float(step(batch)) for _ in range(4)]
+        del os.environ["CN_EXCHANGE_BETWEEN_GRAPHS"]
+        continue
     step = TrainStep(m, lr=2e-4, graph=graph)
     assert step.sync is not None and step.sync.exchange and step.side, "weight gradients stay on the side stream under DP"
     out["graph" if graph else "eager"] = [float(step(batch)) for _ in range(4)]
@@ -322,6 +328,7 @@ def test_rccl_exchange_next_to_graphs(tmp_path):
     assert res["graph"][0] == pytest.approx(res["eager"][0], rel=1e-4)     # the warm-up steps before the capture are rolled back
     assert res["graph"][1] == pytest.approx(res["eager"][1], rel=5e-3)
     assert res["eager"][3] < res["eager"][0]
+    assert res["between"][0] == pytest.approx(res["eager"][0], rel=1e-4) and res["between"][1] == pytest.approx(res["eager"][1], rel=5e-3)
 
 
 _GLOO2_SCRIPT = r"""
