@@ -361,6 +361,7 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
         hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
         return true;
     }
+    if (conv3x3_ws_launch(g, dtype, st)) return true;  // 64 input channels, enough tiles: weight-stationary persistent kernel
     int bn = 32, bnb = (g.Co + 31) / 32;               // same rule as pick_tile(): fewest channel blocks
     for (int c : {64, 128}) {
         int nb = (g.Co + c - 1) / c;

@@ -101,6 +101,55 @@ def test_conv2d_fwd_bwd(cfg, dt):
         close(bg.grad, br.grad, dt, "conv bias grad")
 
 
+WS_CONVS = [  # N,H,W,Co,bias,relu: 64 input channels -> the weight-stationary persistent kernel (conv3x3_ws.hip)
+    (4, 32, 64, 64, True, True),        # one channel block, four tiles per workgroup at 8 workgroups: double-buffered halo
+    (3, 16, 48, 27, True, False),       # the DCN offset conv's 27 -> 32 padded channels (32-channel workgroups)
+    (2, 48, 32, 256, False, True),      # four channel blocks per tile (the head convs)
+    (1, 16, 16, 96, False, False),      # ragged last channel block, a single tile: every halo side is the image border
+]
+
+
+@pytest.mark.parametrize("cfg", WS_CONVS)
+def test_conv3x3_weight_stationary(cfg, monkeypatch):
+    """bf16 3x3/s1 conv with 64 input channels AND its data gradient when Co == 64 (mirrored taps) through conv3x3_ws_kernel,
+    forced onto few workgroups so that every workgroup walks several tiles; compared with torch fp32 on bf16-rounded operands
+    and, bit for bit, with the tile kernel (same bf16 products, fp32 accumulation in a different order: equal after rounding
+    except for rare 1-ulp flips, so the comparison is by tolerance against torch and by a tight bound against the tile kernel)."""
+    N, H, W, Co, bias, relu = cfg
+    dt = torch.bfloat16
+    x = rng.t_normal(3, f"x{cfg}", (N, 64, H, W))
+    w = rng.t_normal(3, f"w{cfg}", (Co, 64, 3, 3), 0, (2.0 / 576) ** 0.5)
+    b = rng.t_normal(3, f"b{cfg}", (Co,), 0, 0.1) if bias else None
+    gy = rng.t_normal(3, f"g{cfg}", (N, Co, H, W))
+    xr, wr = rnd(x, dt).requires_grad_(True), rnd(w, dt).requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, 1, 1)
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(rnd(gy, dt))
+
+    def run():
+        xg = to_nhwc(x, dt).requires_grad_(True)
+        wg = w.to(DEV).requires_grad_(True)
+        y = ops().conv2d(xg, wg, b.to(DEV) if bias else None, 1, 1, relu)
+        gyp = torch.zeros(y.shape, dtype=dt, device=DEV)
+        gyp[..., :Co] = to_nhwc(gy, dt)
+        y.backward(gyp)
+        torch.cuda.synchronize()
+        return y.detach().float().cpu(), xg.grad.detach().float().cpu()
+
+    monkeypatch.setenv("CN_CONV_WS_FORCE", "8")
+    y_ws, dx_ws = run()
+    monkeypatch.delenv("CN_CONV_WS_FORCE")
+    y_tile, dx_tile = run()                          # too few tiles for the size rule: the halo-tile kernel
+    close(y_ws.permute(0, 3, 1, 2)[:, :Co], yr, dt, "ws conv fwd")
+    close(dx_ws.permute(0, 3, 1, 2), xr.grad, dt, "ws conv dgrad")
+    if y_ws.shape[-1] != Co:
+        assert float(y_ws[..., Co:].abs().max()) == 0.0, "channel padding must stay zero"
+    for a_, b_, what in ((y_ws, y_tile, "fwd"), (dx_ws, dx_tile, "dgrad")):
+        s_ = float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 2.0 ** -7 * s_, f"ws vs tile kernel, {what}"   # one bf16 ulp at the top of the range
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 32), (1, 5, 7, 512, 256), (2, 16, 16, 256, 256)])
 def test_conv_transpose_4x4_s2(cfg, dt):

@@ -125,6 +125,26 @@ def bench_dcn():
             del x, om, y, dy, dx, dom
 
 
+def bench_conv():
+    """3x3 / stride 1 convolutions (forward entry point; data gradients are the same kernels with mirrored taps) at the DLA-34
+    shapes, batch 64, random N(0,1) activations.  Each line: this build, then CN_DISABLE-style A/B is done by running the script
+    again with CN_DISABLE_CONV_WS=1 (the switch is read once per process)."""
+    dt = torch.bfloat16
+    shapes = [(128, 64, 256, True), (128, 64, 64, False), (128, 64, 27, False), (128, 256, 64, False), (64, 128, 128, False),
+              (32, 256, 256, False), (16, 512, 512, False), (64, 64, 64, False)]
+    for HW, Ci, Co, relu in shapes:
+        N = 64
+        g = torch.Generator(device="cpu").manual_seed(7)
+        x = torch.randn(N, HW, HW, Ci, device=DEV).to(dt)
+        w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).to(DEV)
+        wp = ops.pack_weight(w, 1, dt)
+        bias = torch.zeros(Co, device=DEV)
+        flops = 2.0 * N * HW * HW * 9 * Ci * Co
+        us, mn = timeit(lambda: ops._igemm(x, wp, bias, None, Co, 3, 3, 1, 1, False, relu, HW, HW), n=15)
+        print(f"conv3x3 {Ci:3d}->{Co:3d} @{HW:3d}^2 bs64  {us:8.1f} us (min {mn:8.1f})  {flops / us / 1e6:7.1f} TF  {flops / us / 2.5e9 * 100:5.1f} % of MFMA peak", flush=True)
+        del x
+
+
 if __name__ == "__main__":
     fams = sys.argv[1:] or ["decode", "bn"]
     print("CN_DISABLE_TOPK_STREAM =", os.environ.get("CN_DISABLE_TOPK_STREAM"))
