@@ -65,6 +65,14 @@ def _kernel_name(hip, name, a, tn):
     if name == "cn_conv2d_fwd":
         N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed, relu, dt, odt = a[:18]
         v = hip.lib().cn_conv2d_variant(Ci, Co, KH, KW, stride, pad, dt)
+        if (v >= 3000000 and tn == "bf16" and Ci == 64 and H % 16 == 0 and W % 16 == 0 and x_ld % 8 == 0 and y_ld % 8 == 0
+                and res_ld % 8 == 0 and not os.environ.get("CN_DISABLE_CONV_WS")):
+            # csrc/conv3x3_ws.hip conv3x3_ws_launch(): 64 input channels and at least four tiles per workgroup
+            bn = 32 if Co <= 32 else 64
+            nblk = -(-Co // bn)
+            cus = torch.cuda.get_device_properties(0).multi_processor_count
+            if N * (H // 16) * (W // 16) * nblk >= 4 * (cus // (8 * nblk)) * 8 * nblk > 0:
+                return f"conv3x3_ws_kernel<{bn}>"
         waves8 = os.environ.get("CN_CONV3X3_WAVES", "0") in ("0", "8")      # csrc/conv3x3.hip launch3(): 8 waves on the 128x64 tile
         if v >= 3000000:
             if v == 3128064 and tn == "bf16" and waves8:
@@ -393,11 +401,11 @@ def main():
                 gbps = 3.0 * mb_img * args.batch / step_s / 1e3
                 step_roof.update({"gbps": round(gbps, 1), "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4),
                                   "bytes_per_image": f"3 x {mb_img} MB unfused bf16 traffic (SURVEY 8d)"})
-        if probe:
+        if probe and probe.ops:
             by = probe.mfma_kernels()
             kern, (fl, tt, n) = max(by.items(), key=lambda kv: kv[1][1])
             ach = fl / tt / 1e12
-            ig = {k: v for k, v in by.items() if k.startswith("conv3x3s1_kernel") or k.startswith("conv_igemm_kernel")}
+            ig = {k: v for k, v in by.items() if k.startswith(("conv3x3s1_kernel", "conv_igemm_kernel", "conv3x3_ws_kernel"))}
             allf = sum(v[0] for v in ig.values()); allt = sum(v[1] for v in ig.values())
             eps = probe.entry_points()
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),

@@ -150,6 +150,42 @@ def test_conv3x3_weight_stationary(cfg, monkeypatch):
         assert float((a_ - b_).abs().max()) <= 2.0 ** -7 * s_, f"ws vs tile kernel, {what}"   # one bf16 ulp at the top of the range
 
 
+@pytest.mark.parametrize("mode", ["residual_add", "residual_add_relu", "relu_mask", "fp32_rows", "mirrored_taps"])
+def test_conv3x3_weight_stationary_epilogues(mode, monkeypatch):
+    """Every epilogue variant of conv3x3_ws_kernel (residual add, + ReLU, ReLU-backward mask, fp32 output rows as the DCN offset
+    conv writes them, mirrored taps of a data gradient) against the halo-tile kernel on the same operands through cn_conv2d_fwd:
+    identical bf16 products and fp32 accumulation in a different order -> at most one output ulp apart."""
+    o = ops()
+    N, H, W, Co = 3, 32, 48, 64 if mode != "fp32_rows" else 27
+    dt = torch.bfloat16
+    x = rng.t_normal(5, f"x{mode}", (N, H, W, 64)).to(dt).to(DEV)
+    w = rng.t_normal(5, f"w{mode}", (Co, 64, 3, 3), 0, (2.0 / 576) ** 0.5).to(DEV)
+    b = rng.t_normal(5, f"b{mode}", (Co,), 0, 0.1).to(DEV)
+    res = rng.t_normal(5, f"r{mode}", (N, H, W, 64)).to(dt).to(DEV)
+    transposed = mode == "mirrored_taps"
+    wp = o.pack_weight(w, 0 if transposed else 1, dt)
+    args = dict(residual_add=(b, res, 0), residual_add_relu=(None, res, 1), relu_mask=(None, res, 2), fp32_rows=(b, None, 0),
+                mirrored_taps=(None, None, 0))[mode]
+
+    def run():
+        y = o._igemm(x, wp, args[0], args[1], Co, 3, 3, 1, 1, transposed, args[2], H, W,
+                     out_dtype=torch.float32 if mode == "fp32_rows" else None)
+        torch.cuda.synchronize()
+        return y.float().cpu()
+
+    monkeypatch.setenv("CN_CONV_WS_FORCE", "8")
+    y_ws = run()
+    monkeypatch.delenv("CN_CONV_WS_FORCE")
+    y_tile = run()
+    assert float(y_tile.abs().max()) > 0.5
+    tol = 1e-5 if mode == "fp32_rows" else 2.0 ** -7
+    assert float((y_ws - y_tile).abs().max()) <= tol * float(y_tile.abs().max()), mode
+    if mode == "fp32_rows":
+        assert float(y_ws[..., Co:].abs().max()) == 0.0
+    if mode == "relu_mask":
+        assert bool(((y_ws == 0) == (y_tile == 0)).all())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 32), (1, 5, 7, 512, 256), (2, 16, 16, 256, 256)])
 def test_conv_transpose_4x4_s2(cfg, dt):
