@@ -42,8 +42,9 @@ extern "C" int ws_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, H
 #endif
 
 // BN: output channels per workgroup, 64 (waves 4 x 2, 64-pixel wave tiles) or 32 (8 x 1, 32 pixels); YF32: fp32 output rows;
-// RES: 0 no residual, 1 y += res, 2 ReLU-backward mask y = res > 0 ? y : 0 (compile-time: the epilogue is branch-free)
-template <int BN, bool YF32, int RES>
+// RES: 0 no residual, 1 y += res, 2 ReLU-backward mask y = res > 0 ? y : 0; RELU: y = max(y, 0) (compile-time: the epilogue
+// is branch-free)
+template <int BN, bool YF32, int RES, bool RELU>
 __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int nblk, int tiles_h, int tiles_w, uint64_t wmap) {
     constexpr int WGN = BN / 32, WGM = 8 / WGN, WM = 256 / WGM, MI = WM / 32;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[WS_LDS];
@@ -225,14 +226,15 @@ __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int
         {
             int lane = tid & 63;
             asm volatile("" : "+v"(lane));      // recomputed per tile: hoisted, the per-lane addressing would pin registers
+            // tile base in scalar registers, 32-bit per-lane byte offsets (a tile spans < 16 rows of the map)
             const int64_t pix0 = ((int64_t)cur.n * g.OH + cur.th * 16) * g.OW + cur.tw * 16;
+            char* const ytile = reinterpret_cast<char*>(g.y) + pix0 * g.y_ld * (YF32 ? 4 : 2);
+            const char* const rtile = reinterpret_cast<const char*>(g.res) + pix0 * g.res_ld * 2;
             const int chl = wn + 8 * (lane >> 5);                      // + 16 qq: the lane's 8 channels of quad pair qq
-            const bf16_t* __restrict__ Rr = reinterpret_cast<const bf16_t*>(g.res);
-            const float lo = g.relu == 1 ? 0.f : -INFINITY;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = wm + i * 32 + (lane & 31);
-                const int64_t px = pix0 + (int64_t)(m >> 4) * g.OW + (m & 15);
+                const unsigned px = (unsigned)((m >> 4) * g.OW + (m & 15));       // pixel inside the tile's 16 rows
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int ch = n0 + chl + 16 * qq;
@@ -246,18 +248,20 @@ __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int
                     if (ch >= g.y_ld) continue;
                     if constexpr (RES != 0) {
                         float rv[8];
-                        Vec16<bf16_t>::load(Rr + px * g.res_ld + ch, rv);
+                        Vec16<bf16_t>::load(reinterpret_cast<const bf16_t*>(rtile + (px * (unsigned)g.res_ld + (unsigned)ch) * 2u), rv);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = RES == 2 ? (rv[e] > 0.f ? v[e] : 0.f) : v[e] + rv[e];
                     }
+                    if constexpr (RELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], lo);
+                        for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, INFINITY);     // max(v, 0) in one instruction
+                    }
                     if constexpr (YF32) {
-                        float* dst = reinterpret_cast<float*>(g.y) + px * g.y_ld + ch;
+                        float* dst = reinterpret_cast<float*>(ytile + (px * (unsigned)g.y_ld + (unsigned)ch) * 4u);
                         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                         *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     } else {
-                        Vec16<bf16_t>::store(reinterpret_cast<bf16_t*>(g.y) + px * g.y_ld + ch, v);
+                        Vec16<bf16_t>::store(reinterpret_cast<bf16_t*>(ytile + (px * (unsigned)g.y_ld + (unsigned)ch) * 2u), v);
                     }
                 }
             }
@@ -316,18 +320,16 @@ bool conv3x3_ws_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     const dim3 gr(grid), bl(WS_NT);
     const int res = g.res == nullptr ? 0 : (g.relu == 2 ? 2 : 1);
     if (g.y_f32 && res != 0) return false;
-#define WS_GO(BN_, F32_, RES_) hipLaunchKernelGGL((conv3x3_ws_kernel<BN_, F32_, RES_>), gr, bl, 0, st, g, nblk, tiles_h, tiles_w, wmap)
-    if (bn == 64) {
-        if (g.y_f32) WS_GO(64, true, 0);
-        else if (res == 0) WS_GO(64, false, 0);
-        else if (res == 1) WS_GO(64, false, 1);
-        else WS_GO(64, false, 2);
-    } else {
-        if (g.y_f32) WS_GO(32, true, 0);
-        else if (res == 0) WS_GO(32, false, 0);
-        else if (res == 1) WS_GO(32, false, 1);
-        else WS_GO(32, false, 2);
-    }
+#define WS_GO(BN_, F32_, RES_, RELU_) hipLaunchKernelGGL((conv3x3_ws_kernel<BN_, F32_, RES_, RELU_>), gr, bl, 0, st, g, nblk, tiles_h, tiles_w, wmap)
+#define WS_PICK(BN_)                                                          \
+    do {                                                                      \
+        if (g.y_f32) { if (g.relu == 1) WS_GO(BN_, true, 0, true); else WS_GO(BN_, true, 0, false); } \
+        else if (res == 0) { if (g.relu == 1) WS_GO(BN_, false, 0, true); else WS_GO(BN_, false, 0, false); } \
+        else if (res == 1) { if (g.relu == 1) WS_GO(BN_, false, 1, true); else WS_GO(BN_, false, 1, false); } \
+        else WS_GO(BN_, false, 2, false);                                     \
+    } while (0)
+    if (bn == 64) WS_PICK(64); else WS_PICK(32);
+#undef WS_PICK
 #undef WS_GO
     return true;
 }
