@@ -60,6 +60,34 @@ def _mfma_flops(name, a):
     return None
 
 
+def _algo_bytes(name, a, es):
+    """Algorithmic HBM bytes of one launch of an MFMA entry point: every operand tensor read once, the result written once
+    (es = bytes per activation element; weights in es, offsets/masks and weight gradients fp32)."""
+    if name == "cn_conv2d_fwd":
+        N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed, relu, dt, odt = a[:18]
+        osz = 4 if (odt != dt and odt == 0) else es
+        return N * H * W * x_ld * es + N * OH * OW * (y_ld * osz + res_ld * es) + Co * Ci * KH * KW * es
+    if name == "cn_conv2d_wgrad":
+        N, H, W, Ci, x_ld, OH, OW, Co, ld, KH, KW = a[:11]
+        return N * H * W * x_ld * es + N * OH * OW * ld * es + Co * Ci * KH * KW * 4
+    if name == "cn_dcn_fwd":
+        N, H, W, Ci, x_ld, Co, y_ld, om_ld = a[:8]
+        return N * H * W * (x_ld * es + om_ld * 4 + y_ld * es) + Co * Ci * 9 * es
+    if name == "cn_dcn_wgrad":
+        N, H, W, Ci, x_ld, Co, dy_ld, om_ld = a[:8]
+        return N * H * W * (x_ld * es + om_ld * 4 + dy_ld * es) + Co * Ci * 9 * 4
+    if name == "cn_dcn_bwd_dom":
+        slabs, N, H, W, Ci, Co, dy_ld, x_ld, om_ld = a[:9]
+        return N * H * W * (dy_ld * es + x_ld * es + om_ld * 4 + om_ld * (4 * slabs if slabs else es)) + Co * Ci * 9 * es
+    if name == "cn_dcn_bwd_dx":
+        N, H, W, Ci, dy_ld, om_ld = a[:6]
+        return N * H * W * (dy_ld * es + om_ld * 4 + Ci * es) + dy_ld * Ci * 9 * es
+    if name == "cn_conv1x1_smallk":
+        npix, K, k_ld, Co = a[:4]
+        return npix * (k_ld + Co) * es
+    return None
+
+
 def _kernel_name(hip, name, a, tn):
     """rocprofv3's name of the kernel template an MFMA entry point dispatches to (mirrors the launch functions in csrc/)."""
     if name == "cn_conv2d_fwd":
@@ -138,14 +166,15 @@ class ConvProbe:
                 f.write(f"{t / steps * 1e3:9.3f} ms/step  {k}\n")
 
     def mfma_kernels(self):
-        """{kernel template: [flops, seconds, launches]} over the MFMA-bound launches"""
+        """{kernel template: [flops, seconds, launches, algorithmic bytes]} over the launches of the MFMA entry points"""
         by = {}
+        es = 2 if self.tn == "bf16" else 4
         for name, sig, e0, e1 in self.ops:
             fl = _mfma_flops(name, sig)
             if fl is None:
                 continue
-            d = by.setdefault(_kernel_name(self.hip, name, sig, self.tn), [0.0, 0.0, 0])
-            d[0] += fl; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+            d = by.setdefault(_kernel_name(self.hip, name, sig, self.tn), [0.0, 0.0, 0, 0.0])
+            d[0] += fl; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1; d[3] += float(_algo_bytes(name, sig, es) or 0)
         return by
 
     def entry_points(self):
@@ -403,22 +432,42 @@ def main():
                                   "bytes_per_image": f"3 x {mb_img} MB unfused bf16 traffic (SURVEY 8d)"})
         if probe and probe.ops:
             by = probe.mfma_kernels()
-            kern, (fl, tt, n) = max(by.items(), key=lambda kv: kv[1][1])
+            kern, (fl, tt, n, nbytes) = max(by.items(), key=lambda kv: kv[1][1])
             ach = fl / tt / 1e12
+            # which roof binds the kernel: its arithmetic intensity (algorithmic flops / algorithmic bytes of its launch mix)
+            # against the ridge peak_flops / peak_bandwidth — below the ridge no implementation can reach the MFMA roof
+            ridge = peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
+            ai = fl / nbytes if nbytes else float("inf")
+            gbps = nbytes / tt / 1e9
+            hbm_bound = ai < ridge
             ig = {k: v for k, v in by.items() if k.startswith(("conv3x3s1_kernel", "conv_igemm_kernel", "conv3x3_ws_kernel"))}
             allf = sum(v[0] for v in ig.values()); allt = sum(v[1] for v in ig.values())
             eps = probe.entry_points()
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+
+            def row(v):
+                r = {"tflops": round(v[0] / v[1] / 1e12, 2), "frac_mfma": round(v[0] / v[1] / 1e12 / peak, 4),
+                     "ms_per_step": round(v[1] / args.probe_steps * 1e3, 3), "launches_per_step": v[2] // args.probe_steps}
+                if v[3]:
+                    r.update({"gbps": round(v[3] / v[1] / 1e9, 1), "frac_hbm": round(v[3] / v[1] / 1e9 / PEAK_HBM_GBPS, 4),
+                              "flop_per_byte": round(v[0] / v[3], 1)})
+                return r
+
+            roof = {"bound": "hbm" if hbm_bound else "mfma",
+                    "achieved": round(gbps, 1) if hbm_bound else round(ach, 2),
+                    "peak": PEAK_HBM_GBPS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round(gbps / PEAK_HBM_GBPS, 4) if hbm_bound else round(ach / peak, 4),
                     "traffic": pmc_traffic(kern),
                     "how": f"HIP events around each launch, {args.probe_steps} eagerly launched step(s) of the same workload right after "
-                           f"the timed region; dominant = largest total time among the MFMA-bound kernel templates of ALL entry points",
+                           f"the timed region; dominant = largest total time among the kernel templates of ALL MFMA entry points; bound = "
+                           f"hbm when the kernel's algorithmic flop/byte ({ai:.0f}) is below the ridge ({ridge:.0f}), else mfma; both "
+                           f"fractions of every template are in mfma_kernels",
                     "kernel": kern,
                     "launches": n, "avg_launch_us": round(tt / n * 1e6, 2), "flop_per_launch": round(fl / n, 1),
+                    "bytes_per_launch": round(nbytes / n, 1), "flop_per_byte": round(ai, 1),
+                    "tflops": round(ach, 2), "frac_mfma": round(ach / peak, 4), "gbps": round(gbps, 1),
+                    "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4),
                     "step": step_roof,
-                    "mfma_kernels": {k: {"tflops": round(v[0] / v[1] / 1e12, 2), "frac": round(v[0] / v[1] / 1e12 / peak, 4),
-                                         "ms_per_step": round(v[1] / args.probe_steps * 1e3, 3),
-                                         "launches_per_step": v[2] // args.probe_steps}
-                                     for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]},
+                    "mfma_kernels": {k: row(v) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]},
                     "all_igemm": {"achieved": round(allf / allt / 1e12, 2), "ms_per_step": round(allt / args.probe_steps * 1e3, 3)},
                     "entry_points_ms_per_step": {k: round(v[1] / args.probe_steps * 1e3, 3)
                                                  for k, v in sorted(eps.items(), key=lambda kv: -kv[1][1])[:24]}}
