@@ -10,6 +10,8 @@ Dataflow notes that matter for parity:
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -51,6 +53,9 @@ class Root(nn.Module):
         return hnn.cat_conv_bn_act(self.conv, self.bn, list(xs), xs[0] if self.residual else None, True)
 
 
+_POOL_TWICE = bool(os.environ.get("CN_DLA_POOL_TWICE"))      # A/B switch: pool a two-level tree's input twice, as the reference does
+
+
 class Tree(nn.Module):
     """pose_dla_dcn.py:191-265."""
 
@@ -76,9 +81,13 @@ class Tree(nn.Module):
         if in_channels != out_channels:
             self.project = nn.Sequential(hnn.Conv2d(in_channels, out_channels, 1), hnn.BatchNorm2d(out_channels))
 
-    def forward(self, x, residual=None, children=None):
+    def forward(self, x, residual=None, children=None, bottom=None):
+        """`bottom`: the caller's own `downsample(x)` when it is the same pooling of the same tensor (an outer tree and its
+        `tree1` are built with the same stride: the reference pools x twice, pose_dla_dcn.py:245-262; sharing the result drops one
+        max-pool forward/backward pair and one full-resolution gradient accumulation per two-level tree — same values)."""
         children = [] if children is None else children
-        bottom = self.downsample(x) if self.downsample is not None else x
+        if bottom is None:
+            bottom = self.downsample(x) if self.downsample is not None else x
         if self.levels == 1:
             residual = hnn.conv_bn_act(self.project[0], self.project[1], bottom, None, False) if self.project else bottom
         elif self.project is not None and self.project[1].training:
@@ -91,7 +100,7 @@ class Tree(nn.Module):
             # joins conv1's data gradient in that kernel's epilogue instead of in an element-wise pass of the autograd engine)
             x1 = self.tree1(x, None if residual is x else residual)
             return self.root(self.tree2(x1), x1, *children)
-        x1 = self.tree1(x)
+        x1 = self.tree1(x, bottom=bottom if self.downsample is not None and not _POOL_TWICE else None)
         children.append(x1)
         return self.tree2(x1, children=children)
 
