@@ -101,6 +101,11 @@ def _kernel_name(hip, name, a, tn):
             cus = torch.cuda.get_device_properties(0).multi_processor_count
             if N * (H // 16) * (W // 16) * nblk >= 4 * (cus // (8 * nblk)) * 8 * nblk > 0:
                 return f"conv3x3_ws_kernel<{bn}>"
+        if (KH == 1 and KW == 1 and stride == 1 and pad == 0 and tn == "bf16" and Ci in (32, 64, 128, 256) and x_ld % 8 == 0
+                and y_ld % 8 == 0 and res_ld % 8 == 0 and N * OH * OW >= 65536 and not os.environ.get("CN_DISABLE_CONV1X1_STREAM")):
+            nj = (min(Co, y_ld) + 31) // 32          # csrc/conv1x1_stream.hip conv1x1_stream_launch()
+            if nj in (1, 2, 3, 4, 8) and not (nj == 8 and Ci > 128) and nj * 32 * (Ci + 8) * 2 <= 72 * 1024 and nj * 16 + Ci // 2 <= 200:
+                return f"conv1x1_stream_kernel<{Ci // 16},{nj}>"
         waves8 = os.environ.get("CN_CONV3X3_WAVES", "0") in ("0", "8")      # csrc/conv3x3.hip launch3(): 8 waves on the 128x64 tile
         if v >= 3000000:
             if v == 3128064 and tn == "bf16" and waves8:

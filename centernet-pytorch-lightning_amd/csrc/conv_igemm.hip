@@ -474,6 +474,10 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
         CN_LAUNCH_CHECK("cn_conv2d_fwd(3x3)");
         return CN_OK;
     }
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && OH == H && OW == W && conv1x1_stream_launch(g, dtype, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_conv2d_fwd(1x1 stream)");
+        return CN_OK;
+    }
     if (dtype == CN_F32) dispatch_igemm<float>(g, ncls, (hipStream_t)stream);
     else if (dtype == CN_BF16) dispatch_igemm<bf16_t>(g, ncls, (hipStream_t)stream);
     else CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);

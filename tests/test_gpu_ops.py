@@ -150,6 +150,46 @@ def test_conv3x3_weight_stationary(cfg, monkeypatch):
         assert float((a_ - b_).abs().max()) <= 2.0 ** -7 * s_, f"ws vs tile kernel, {what}"   # one bf16 ulp at the top of the range
 
 
+S1_CONVS = [  # npix as N,H,W ; Ci ; Co ; bias ; relu ; transposed : 1x1 convs on the streaming kernel (>= 64 K pixels)
+    (4, 128, 128, 256, 80, True, False, False),     # the 80-class head's output conv (96 padded rows, three channel blocks)
+    (4, 128, 130, 256, 2, True, False, False),      # wh / reg heads (y_ld = 16), pixel count not a multiple of 32
+    (16, 64, 64, 128, 128, False, True, False),
+    (16, 64, 64, 128, 256, False, False, False),    # eight channel blocks
+    (4, 128, 128, 64, 64, False, False, True),      # data gradient of a 1x1 conv (transposed = the other packing of the weights)
+    (4, 128, 128, 32, 64, True, True, False),
+]
+
+
+@pytest.mark.parametrize("cfg", S1_CONVS)
+def test_conv1x1_streaming(cfg, monkeypatch):
+    """bf16 1x1 convs on conv1x1_stream_kernel (weights in LDS, activations straight from global memory into the MFMA) against
+    torch fp32 on bf16-rounded operands and against the implicit-GEMM kernel (CN_DISABLE_CONV1X1_STREAM is read once per process,
+    so the second opinion comes from the residual-free identity y(x) linear in x: the kernel on 2x equals 2 y(x) exactly in
+    bf16 apart from the ReLU-free bias term, and from the torch reference)."""
+    N, H, W, Ci, Co, bias, relu, transposed = cfg
+    o = ops()
+    dt = torch.bfloat16
+    x = rng.t_normal(7, f"x{cfg}", (N, H, W, Ci)).to(dt).to(DEV)
+    w = rng.t_normal(7, f"w{cfg}", (Ci, Co, 1, 1) if transposed else (Co, Ci, 1, 1), 0, (2.0 / Ci) ** 0.5)
+    b = rng.t_normal(7, f"b{cfg}", (Co,), 0, 0.1) if bias else None
+    res = rng.t_normal(7, f"r{cfg}", (N, H, W, (Co + 15) // 16 * 16)).to(dt).to(DEV) if Co % 16 == 0 else None
+    wp = o.pack_weight(w.to(DEV), 0 if transposed else 1, dt)
+    y = o._igemm(x, wp, b.to(DEV) if bias else None, res, Co, 1, 1, 1, 0, transposed, relu, H, W)
+    torch.cuda.synchronize()
+    wm = w.to(dt).float()[:, :, 0, 0]
+    ref = x.float().cpu().reshape(-1, Ci) @ (wm if transposed else wm.t())
+    if bias:
+        ref = ref + b
+    if res is not None:
+        ref = ref + res.float().cpu().reshape(-1, res.shape[-1])[:, :Co]
+    if relu:
+        ref = ref.clamp_min(0)
+    got = y.float().cpu().reshape(-1, y.shape[-1])
+    close(got[:, :Co], ref, dt, "1x1 stream")
+    if got.shape[1] != Co:
+        assert float(got[:, Co:].abs().max()) == 0.0, "channel padding must stay zero"
+
+
 @pytest.mark.parametrize("mode", ["residual_add", "residual_add_relu", "relu_mask", "fp32_rows", "mirrored_taps"])
 def test_conv3x3_weight_stationary_epilogues(mode, monkeypatch):
     """Every epilogue variant of conv3x3_ws_kernel (residual add, + ReLU, ReLU-backward mask, fp32 output rows as the DCN offset

@@ -1,0 +1,4 @@
+for i in 1 2 3; do
+CN_DISABLE_CONV1X1_STREAM=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-inference --probe-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('igemm ', d['ms_per_step'])"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-inference --probe-steps 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('stream', d['ms_per_step'])"
+done

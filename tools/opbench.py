@@ -145,6 +145,23 @@ def bench_conv():
         del x
 
 
+def bench_conv1x1():
+    """1x1 / stride 1 convolutions of DLA-34 at batch 64 (forward entry point; the data gradients are 1x1 convs with the other
+    packing).  A/B: CN_DISABLE_CONV1X1_STREAM=1 (read once per process) puts them back on the implicit-GEMM kernel."""
+    dt = torch.bfloat16
+    for HW, Ci, Co in [(128, 256, 80), (128, 256, 2), (64, 128, 128), (128, 64, 64), (32, 256, 256), (64, 64, 128), (128, 32, 64),
+                       (64, 128, 64), (128, 64, 32), (32, 128, 256), (32, 256, 128)]:
+        N = 64
+        g = torch.Generator(device="cpu").manual_seed(9)
+        x = torch.randn(N, HW, HW, Ci, device=DEV).to(dt)
+        w = (torch.randn(Co, Ci, 1, 1, generator=g) * (2.0 / Ci) ** 0.5).to(DEV)
+        wp = ops.pack_weight(w, 1, dt)
+        nbytes = N * HW * HW * (Ci + ops.rup(Co, 16)) * 2
+        us, mn = timeit(lambda: ops._igemm(x, wp, None, None, Co, 1, 1, 1, 0, False, False, HW, HW), n=15)
+        report(f"conv1x1 {Ci:3d}->{Co:3d} @{HW:3d}^2 bs64", us, mn, nbytes)
+        del x
+
+
 if __name__ == "__main__":
     fams = sys.argv[1:] or ["decode", "bn"]
     print("CN_DISABLE_TOPK_STREAM =", os.environ.get("CN_DISABLE_TOPK_STREAM"))
