@@ -160,6 +160,20 @@ def bench_conv1x1():
         us, mn = timeit(lambda: ops._igemm(x, wp, None, None, Co, 1, 1, 1, 0, False, False, HW, HW), n=15)
         report(f"conv1x1 {Ci:3d}->{Co:3d} @{HW:3d}^2 bs64", us, mn, nbytes)
         del x
+    # data gradients of the heads' output convs (256 -> C): dy [P][rup16(C)] -> dx [P][256] masked by the hidden activation
+    for C in (2, 80):
+        N, HW, Ci = 64, 128, 256
+        ld = ops.rup(C, 16)
+        dy = torch.randn(N, HW, HW, ld, device=DEV).to(dt)
+        h = torch.randn(N, HW, HW, Ci, device=DEV).to(dt)
+        w = torch.randn(C, Ci, 1, 1, device=DEV) * 0.05
+        wpd = ops.pack_weight(w, 0, dt)
+        nbytes = N * HW * HW * (ld + 2 * Ci) * 2
+        us, mn = timeit(lambda: ops._igemm(dy, wpd, None, h, Ci, 1, 1, 1, 0, True, 2, HW, HW), n=15)
+        report(f"conv1x1 dgrad {C:2d}->256 @128^2 bs64 via cn_conv2d_fwd", us, mn, nbytes)
+        dx = torch.empty_like(h)
+        us, mn = timeit(lambda: _hip.call("cn_conv1x1_smallk", dy, wpd, h, dx, N * HW * HW, C, ld, Ci, Ci, Ci, 2, _hip.dtype_code(dt)), n=15)
+        report(f"conv1x1 dgrad {C:2d}->256 @128^2 bs64 via cn_conv1x1_smallk", us, mn, nbytes)
 
 
 if __name__ == "__main__":
