@@ -130,7 +130,7 @@ def bench_conv():
     shapes, batch 64, random N(0,1) activations.  Each line: this build, then CN_DISABLE-style A/B is done by running the script
     again with CN_DISABLE_CONV_WS=1 (the switch is read once per process)."""
     dt = torch.bfloat16
-    shapes = [(128, 64, 256, True), (128, 64, 64, False), (128, 64, 27, False), (128, 256, 64, False), (64, 128, 128, False),
+    shapes = [(512, 16, 16, False), (128, 64, 256, True), (128, 64, 64, False), (128, 64, 27, False), (128, 256, 64, False), (64, 128, 128, False),
               (32, 256, 256, False), (16, 512, 512, False), (64, 64, 64, False)]
     for HW, Ci, Co, relu in shapes:
         N = 64
