@@ -190,6 +190,29 @@ def test_conv1x1_streaming(cfg, monkeypatch):
         assert float(got[:, Co:].abs().max()) == 0.0, "channel padding must stay zero"
 
 
+def test_dma_fed_conv_kernels_repeatable_under_contention():
+    """Race screen (tools/ws_stress.py, short form): conv3x3_ws_kernel reads halo tiles that another part of the workgroup
+    wrote by LDS-DMA two tiles earlier; a read that races its data would show up as a rare differing tile.  The same full-size
+    launch, 40 times, next to 512 MB copies on a second stream, must be bit-identical every time."""
+    o = ops()
+    dt = torch.bfloat16
+    x = rng.t_normal(9, "race_x", (16, 128, 128, 64)).to(dt).to(DEV)
+    w = rng.t_normal(9, "race_w", (256, 64, 3, 3), 0, 0.06).to(DEV)
+    wp = o.pack_weight(w, 1, dt)
+    a = torch.randn(64 * 1024 * 1024, device=DEV)
+    b = torch.empty_like(a)
+    side = torch.cuda.Stream()
+    ref = o._igemm(x, wp, None, None, 256, 3, 3, 1, 1, False, True, 128, 128)
+    torch.cuda.synchronize()
+    for i in range(40):
+        if i % 2 == 0:
+            with torch.cuda.stream(side):
+                b.copy_(a)
+        y = o._igemm(x, wp, None, None, 256, 3, 3, 1, 1, False, True, 128, 128)
+        assert torch.equal(y, ref), f"launch {i} differs"
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("mode", ["residual_add", "residual_add_relu", "relu_mask", "fp32_rows", "mirrored_taps"])
 def test_conv3x3_weight_stationary_epilogues(mode, monkeypatch):
     """Every epilogue variant of conv3x3_ws_kernel (residual add, + ReLU, ReLU-backward mask, fp32 output rows as the DCN offset
