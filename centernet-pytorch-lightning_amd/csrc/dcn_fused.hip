@@ -19,6 +19,14 @@
 #define DX_MAXH 8
 #define DX_OVF 256
 
+#ifdef DX_PROBE   // development build only (tools/dx_probe.py): cycle stamps of wave 0 at the phase boundaries of every tap
+__device__ unsigned long long dx_ts[1024 * 9 * 4];
+#define DX_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.y == 0 && blockIdx.x < 1024) dx_ts[(blockIdx.x * 9 + tap) * 4 + (k)] = clock64(); } while (0)
+extern "C" int dx_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dx_ts), sizeof(dx_ts)); }
+#else
+#define DX_STAMP(k) do { } while (0)
+#endif
+
 template <typename T, int BN, int CK>
 __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
     constexpr int BM = DX_TH * DX_TW;
@@ -106,6 +114,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
     int step = 0;                            // (tap, chunk) steps; weight slice `step` lives in buffer step & 1
     for (int tap = 0; tap < 9; ++tap) {
         // ---- 1. hit lists of this tap ----
+        DX_STAMP(0);
         for (int i = tid; i < BM; i += 256) hit_n[i] = 0;
         if (tid == 0) ovf_n = 0;
         __syncthreads();
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
             }
         }
         __syncthreads();
+        DX_STAMP(1);
         if (tap < 8) oload(tap + 1);
         for (int ch = 0; ch < nchunks; ++ch, ++step) {
             const int c0 = ch * CK;
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
             }
             bstore(0);
             __syncthreads();
+            DX_STAMP(2);
             // prefetch the next weight slice while this one is multiplied
             {
                 const int nt = (ch + 1 < nchunks) ? tap : tap + 1, nc = (ch + 1 < nchunks) ? ch + 1 : 0;
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
                     for (int i = 0; i < MI; ++i) acc[j][i] = Mma<T>::mma(fb[j], fa[i], acc[j][i]);
             }
             __syncthreads();             // G tile and hit lists may be overwritten
+            DX_STAMP(3);
         }
     }
 
