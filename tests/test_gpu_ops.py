@@ -213,6 +213,23 @@ def test_dma_fed_conv_kernels_repeatable_under_contention():
     torch.cuda.synchronize()
 
 
+def test_conv1x1_streaming_relu_mask():
+    """ReLU-backward mask epilogue (relu mode 2: y = res > 0 ? y : 0) of the streaming 1x1 kernel, as the data gradient of a 1x1
+    conv behind a deferred ReLU uses it."""
+    o = ops()
+    dt = torch.bfloat16
+    N, H, W, Ci, Co = 4, 128, 128, 64, 128
+    dy = rng.t_normal(8, "s1m_dy", (N, H, W, Co)).to(dt).to(DEV)
+    xact = rng.t_normal(8, "s1m_x", (N, H, W, Ci)).to(dt).to(DEV)
+    w = rng.t_normal(8, "s1m_w", (Co, Ci, 1, 1), 0, 0.1)
+    wpd = o.pack_weight(w.to(DEV), 0, dt)                       # rows = Ci, k = Co: the data-gradient packing
+    dx = o._igemm(dy, wpd, None, xact, Ci, 1, 1, 1, 0, True, 2, H, W)
+    torch.cuda.synchronize()
+    ref = dy.float().cpu().reshape(-1, Co) @ w.to(dt).float()[:, :, 0, 0]
+    ref = torch.where(xact.float().cpu().reshape(-1, Ci) > 0, ref, torch.zeros_like(ref))
+    close(dx.float().cpu().reshape(-1, Ci), ref, dt, "1x1 stream relu mask")
+
+
 @pytest.mark.parametrize("mode", ["residual_add", "residual_add_relu", "relu_mask", "fp32_rows", "mirrored_taps"])
 def test_conv3x3_weight_stationary_epilogues(mode, monkeypatch):
     """Every epilogue variant of conv3x3_ws_kernel (residual add, + ReLU, ReLU-backward mask, fp32 output rows as the DCN offset
