@@ -391,6 +391,36 @@ __global__ __launch_bounds__(256) void nms3x3_kernel(const float* __restrict__ h
     }
 }
 
+// any odd window (utils/decode.py:5-10 with kernel != 3: an option the reference defines and never uses): plain window scan
+__global__ __launch_bounds__(256) void nms_k_kernel(const float* __restrict__ heat, float* __restrict__ out, int64_t total, int H,
+                                                    int W, int r) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const float v = heat[i];
+        float m = v;
+        for (int dy = -r; dy <= r; ++dy) {
+            if ((unsigned)(y + dy) >= (unsigned)H) continue;
+            for (int dx = -r; dx <= r; ++dx) {
+                if ((unsigned)(x + dx) >= (unsigned)W) continue;
+                m = fmaxf(m, heat[i + (int64_t)dy * W + dx]);
+            }
+        }
+        out[i] = v * (m == v ? 1.f : 0.f);
+    }
+}
+
+extern "C" int cn_nms(const float* heat, float* out, int B, int C, int H, int W, int kernel, void* stream) {
+    CN_CHECK_ARG(heat && out && B > 0 && C > 0 && H > 0 && W > 0, "cn_nms: bad args");
+    CN_CHECK_ARG(kernel >= 1 && (kernel & 1) == 1 && kernel <= 31, "cn_nms: kernel %d must be odd (1..31)", kernel);
+    int64_t total = (int64_t)B * C * H * W;
+    int64_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(nms_k_kernel, dim3((int)(g > 32768 ? 32768 : g)), dim3(256), 0, (hipStream_t)stream, heat, out, total, H, W,
+                       (kernel - 1) / 2);
+    CN_LAUNCH_CHECK("cn_nms");
+    return CN_OK;
+}
+
 extern "C" int cn_nms3x3(const float* heat, float* out, int B, int C, int H, int W, void* stream) {
     CN_CHECK_ARG(heat && out && B > 0 && C > 0 && H > 0 && W > 0, "cn_nms3x3: bad args");
     int64_t total = (int64_t)B * C * H * W;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void encode_ctdet_kernel(const float* __restri
                                                            const int* __restrict__ nobj, float* __restrict__ heatmap,
                                                            unsigned char* __restrict__ mask, int64_t* __restrict__ indices,
                                                            float* __restrict__ wh, float* __restrict__ reg, int M, int C, int OH,
-                                                           int OW, float down) {
+                                                           int OW, float down, int msra) {
     const int k = blockIdx.x, b = blockIdx.y;
     __shared__ int s_geo[4];                     // cx, cy, radius, valid
     if (threadIdx.x == 0) {
@@ -58,6 +58,22 @@ __global__ __launch_bounds__(256) void encode_ctdet_kernel(const float* __restri
     __syncthreads();
     if (!s_geo[3]) return;
     const int cx = s_geo[0], cy = s_geo[1], rad = s_geo[2];
+    if (msra) {
+        // draw_msra_gaussian(heatmap[cls], ct_int, radius) (sample/ctdet.py:54, 70; utils/gaussian.py:61-83) with the INTEGER radius
+        // as sigma: a (6 sigma + 1)^2 patch centred on ct_int, dropped entirely when it touches the border (:68, the reference's
+        // swapped w/h names: columns against shape[1], rows against shape[0]), no truncation of small values.  radius 0 is the
+        // reference's 0/0: the centre pixel becomes NaN (np.maximum propagates it; NaN's bit pattern wins the integer max too).
+        const int t = 3 * rad, size = 2 * t + 1;
+        if (cx + t + 1 >= OW || cy + t + 1 >= OH || cx - t < 0 || cy - t < 0) return;
+        const float den = 2.f * (float)(rad * rad);
+        int* hmm = reinterpret_cast<int*>(heatmap + ((int64_t)b * C + cls[(int64_t)b * M + k]) * OH * OW);
+        for (int i = threadIdx.x; i < size * size; i += blockDim.x) {
+            const int dy = i / size - t, dx = i % size - t;
+            const float v = rad == 0 ? __int_as_float(0x7fc00000) : expf(-(float)(dx * dx + dy * dy) / den);
+            atomicMax(hmm + (int64_t)(cy + dy) * OW + cx + dx, __float_as_int(v));
+        }
+        return;
+    }
     const int diam = 2 * rad + 1;
     const float sigma = (float)diam / 6.f;
     const float denom = 2.f * sigma * sigma;
@@ -74,11 +90,12 @@ __global__ __launch_bounds__(256) void encode_ctdet_kernel(const float* __restri
 
 extern "C" int cn_encode_ctdet(const float* boxes, const int* cls, const int* nobj, float* heatmap, unsigned char* mask,
                                int64_t* indices, float* wh, float* reg, int B, int M, int C, int OH, int OW, int down_ratio,
-                               void* stream) {
+                               int gaussian_type, void* stream) {
     CN_CHECK_ARG(boxes && cls && nobj && heatmap && mask && indices && wh && reg, "cn_encode_ctdet: null pointer");
     CN_CHECK_ARG(B > 0 && M > 0 && C > 0 && OH > 0 && OW > 0 && down_ratio > 0 && B <= 65535, "cn_encode_ctdet: bad dims");
+    CN_CHECK_ARG(gaussian_type == 0 || gaussian_type == 1, "cn_encode_ctdet: gaussian_type %d (0 = umich, 1 = msra)", gaussian_type);
     hipLaunchKernelGGL(encode_ctdet_kernel, dim3(M, B), dim3(256), 0, (hipStream_t)stream, boxes, cls, nobj, heatmap, mask, indices,
-                       wh, reg, M, C, OH, OW, (float)down_ratio);
+                       wh, reg, M, C, OH, OW, (float)down_ratio, gaussian_type);
     CN_LAUNCH_CHECK("cn_encode_ctdet");
     return CN_OK;
 }

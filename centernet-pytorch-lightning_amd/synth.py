@@ -54,8 +54,9 @@ def splat_umich(hm, cx, cy, radius):
         np.maximum(sub, g[radius - t:radius + b, radius - l:radius + r], out=sub)
 
 
-def encode_ctdet(boxes, in_h=512, in_w=512, down=4, num_classes=80, max_objs=128):
-    """boxes: list of ([x,y,w,h] in input pixels, class_id). Returns dict of numpy arrays."""
+def encode_ctdet(boxes, in_h=512, in_w=512, down=4, num_classes=80, max_objs=128, gaussian="umich"):
+    """boxes: list of ([x,y,w,h] in input pixels, class_id). Returns dict of numpy arrays.  gaussian "msra": the reference's other
+    option (sample/ctdet.py:53-55) — draw_msra_gaussian with the INTEGER radius as sigma (radius 0 is its 0/0 -> NaN pixel)."""
     oh, ow = in_h // down, in_w // down
     hm = np.zeros((num_classes, oh, ow), np.float32)
     wh = np.zeros((max_objs, 2), np.float32)
@@ -71,7 +72,11 @@ def encode_ctdet(boxes, in_h=512, in_w=512, down=4, num_classes=80, max_objs=128
             rad = max(0, int(gaussian_radius(math.ceil(h), math.ceil(w))))
             ct = np.array([(box[0] + box[2]) / 2, (box[1] + box[3]) / 2], np.float32)
             ci = ct.astype(np.int32)
-            splat_umich(hm[cls], int(ci[0]), int(ci[1]), rad)
+            if gaussian == "msra":
+                with np.errstate(invalid="ignore", divide="ignore"):
+                    splat_msra(hm[cls], int(ci[0]), int(ci[1]), rad)
+            else:
+                splat_umich(hm[cls], int(ci[0]), int(ci[1]), rad)
             wh[k] = (w, h)
             ind[k] = int(ci[1]) * ow + int(ci[0])
             reg[k] = ct - ci

@@ -14,12 +14,15 @@ def _f32c(t):
 
 def _nms(heat, kernel=3):
     """utils/decode.py:5-10."""
-    if kernel != 3:
-        raise NotImplementedError("only the 3x3 pseudo-NMS the reference uses is implemented")
+    if kernel % 2 != 1:
+        raise ValueError("an even window changes the pooled map's size: the reference's `hmax == heat` fails on it too")
     heat = _f32c(heat)
     B, C, H, W = heat.shape
     out = torch.empty_like(heat)
-    call("cn_nms3x3", heat, out, B, C, H, W)
+    if kernel == 3:
+        call("cn_nms3x3", heat, out, B, C, H, W)
+    else:
+        call("cn_nms", heat, out, B, C, H, W, int(kernel))
     return out
 
 

@@ -43,8 +43,40 @@ class RegWeightedL1Loss(nn.Module):
         return ops.GatherL1Fn.apply(output, mask, ind, target)
 
 
+class _NormRegL1Fn(torch.autograd.Function):
+    """Rows gathered by cn_gather_rows; the arithmetic on the [B,N,C] rows (a few thousand elements) and the scatter of their
+    gradient are plain tensor ops — this loss is not on any path the reference's task modules take."""
+
+    @staticmethod
+    def forward(ctx, output, mask, ind, target):
+        from .._hip import call
+        feat = output.contiguous().float()
+        B, C = feat.shape[:2]
+        HW = feat[0, 0].numel()
+        ind = ind.contiguous().long()
+        N = ind.shape[1]
+        pred = torch.empty((B, N, C), dtype=torch.float32, device=feat.device)
+        call("cn_gather_rows", feat, ind, pred, B, C, HW, N)
+        m = mask.unsqueeze(2).expand_as(pred).float()
+        r = pred / (target + 1e-4)
+        den = m.sum() + 1e-4
+        ctx.save_for_backward(r, m, target, ind, den)
+        ctx.shape = feat.shape
+        return (r * m - m).abs().sum() / den
+
+    @staticmethod
+    def backward(ctx, g):
+        r, m, target, ind, den = ctx.saved_tensors
+        B, C = ctx.shape[:2]
+        dpred = g * torch.sign(r * m - m) * m / (target + 1e-4) / den                 # [B,N,C]
+        dfeat = torch.zeros((B, C, r.new_empty(ctx.shape)[0, 0].numel()), dtype=torch.float32, device=r.device)
+        dfeat.scatter_add_(2, ind.unsqueeze(1).expand(B, C, ind.shape[1]), dpred.permute(0, 2, 1).contiguous())
+        return dfeat.view(ctx.shape), None, None, None
+
+
 class NormRegL1Loss(nn.Module):
-    """utils/losses.py:66-78 — never instantiated by the reference's task modules; not part of the hot path."""
+    """utils/losses.py:66-78: L1 between pred / (target + 1e-4) and 1 at the masked object slots (never instantiated by the
+    reference's task modules)."""
 
     def forward(self, output, mask, ind, target):
-        raise NotImplementedError("NormRegL1Loss is unused by the reference (SURVEY.md §2.1 #7) and not implemented")
+        return _NormRegL1Fn.apply(output, mask, ind, target)

@@ -235,10 +235,12 @@ int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uint8_t* mask,
 /* ---- ground-truth encoding (replaces the per-sample host loop of sample/ctdet.py:39-90) -------------- */
 /* boxes fp32 [B][M][4] = COCO (x, y, w, h) in input pixels, cls int32 [B][M], nobj int32 [B] (objects beyond nobj[b] are
  * ignored).  heatmap fp32 [B][C][OH][OW] must be ZEROED by the caller (gaussians are max-splatted into it);
- * mask uint8 [B][M], indices int64 [B][M], wh / reg fp32 [B][M][2] are fully written.  umich gaussians,
- * min_overlap 0.7 (utils/gaussian.py:6-58). */
+ * mask uint8 [B][M], indices int64 [B][M], wh / reg fp32 [B][M][2] are fully written.  gaussian_type 0: umich gaussians
+ * (the reference's default; utils/gaussian.py:28-58), 1: msra (utils/gaussian.py:61-83 with the integer radius as sigma,
+ * sample/ctdet.py:54); radius from gaussian_radius with min_overlap 0.7 (utils/gaussian.py:6-26) in both. */
 int cn_encode_ctdet(const float* boxes, const int* cls, const int* nobj, float* heatmap, unsigned char* mask,
-                    int64_t* indices, float* wh, float* reg, int B, int M, int C, int OH, int OW, int down_ratio, void* stream);
+                    int64_t* indices, float* wh, float* reg, int B, int M, int C, int OH, int OW, int down_ratio,
+                    int gaussian_type, void* stream);
 /* Replaces the host loop of MultiPoseSample.__call__ (sample/multi_pose.py:35-112; draw_msra_gaussian utils/gaussian.py:61-83)
  * for a whole batch.  boxes fp32 [B,M,4] (x,y,w,h, input pixels), keypoints fp32 [B,M,J,3] (x,y,visibility), nobj int32 [B].
  * Outputs (collated layouts of :103-110): heatmap_keypoints fp32 [B,J,OH,OW] (ZEROED by the caller), keypoints fp32 [B,M,2J],
@@ -277,6 +279,8 @@ int cn_pose_merge(const float* dets, const float* meta, float* rows, int* counts
 /* ---- decode (utils/decode.py, decode/ctdet.py, decode/multi_pose.py) -------------------------- */
 /* keep[b,c,h,w] = heat * (maxpool3x3(heat) == heat)   (utils/decode.py:5-10) */
 int cn_nms3x3(const float* heat, float* out, int B, int C, int H, int W, void* stream);
+/* the same with any odd window (utils/decode.py:5 `kernel`; the reference only ever passes the default 3) */
+int cn_nms(const float* heat, float* out, int B, int C, int H, int W, int kernel, void* stream);
 /* per (b,c): top-K of (apply_nms ? nms3x3(heat) : heat) over H*W, descending, ties -> lower index.
  * scores fp32 [B,C,K], inds int32 [B,C,K].  K <= 256.  (utils/decode.py:16, :34) */
 int cn_topk_channel(const float* heat, float* scores, int32_t* inds, int B, int C, int H, int W, int K,

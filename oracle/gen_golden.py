@@ -100,6 +100,33 @@ def gen_encode():
          det_sorted=det[np.argsort(det[:, 0])])
 
 
+def gen_encode_msra():
+    """The reference's other gaussian option for detection targets (sample/ctdet.py:53-55, `gaussian_type="msra"`):
+    draw_msra_gaussian with the integer radius as sigma.  Annotation sets: the reference's own fixture, random boxes, and a set
+    with tiny boxes (radius 0 -> the reference's 0/0 NaN pixel) and boxes whose 3-sigma patch touches the border (dropped)."""
+    import warnings
+    with open("/root/reference/tests/data/coco_annotation.json") as f:
+        sets = [[(a["bbox"], int(a["category_id"]) - 1) for a in json.load(f)]]
+    sets += [synth.random_boxes(91, i) for i in range(2)]
+    sets.append([([100.0, 100.0, 5.0, 5.0], 2), ([200.0, 40.0, 6.0, 9.0], 2), ([2.0, 2.0, 60.0, 60.0], 4), ([430.0, 440.0, 70.0, 60.0], 4),
+                 ([250.0, 250.0, 30.0, 44.0], 7), ([255.0, 251.0, 28.0, 40.0], 7)])
+    kw = {}
+    for i, bl in enumerate(sets):
+        ann = [{"bbox": [float(np.float32(v)) for v in bb], "class_id": int(c)} for bb, c in bl]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, t = CenterDetectionSample(gaussian_type="msra")(torch.zeros(3, 512, 512), ann)
+        hm = t["heatmap"].flatten()
+        nz = torch.nonzero((hm != 0) | torch.isnan(hm)).flatten()
+        kw[f"boxes{i}"] = np.array([a["bbox"] for a in ann], np.float64)
+        kw[f"cls{i}"] = np.array([a["class_id"] for a in ann])
+        kw[f"hm_nz_idx{i}"] = nz
+        kw[f"hm_nz_val{i}"] = hm[nz]
+        for k in ("indices", "width_height", "regression", "regression_mask"):
+            kw[f"{k}{i}"] = t[k]
+    save("encode_msra_fixture.npz", n=len(sets), **kw)
+
+
 def gen_encode_pose():
     """SURVEY 8 f-3 (multi_pose): the reference's MultiPoseSample on synthetic person annotations (boxes + 17 keypoints with
     visibility 0/1/2; some keypoints outside their box, some boxes hanging over the border).
@@ -169,6 +196,18 @@ def gen_losses():
     gt0 = tgt["heatmap"].clone()
     gt0[gt0 == 1] = 0.99
     hm0 = FocalLoss()(sigmoid_clamped(logits.detach().clone()), gt0)
+    # the two options the reference defines but never uses: NormRegL1Loss (utils/losses.py:66-78), _nms with a 5x5 window
+    from CenterNet.utils.losses import NormRegL1Loss
+    from CenterNet.utils.decode import _nms
+    whn = rng.t_normal(seed, "whn", (B, 2, H, W), 0, 5).requires_grad_(True)
+    nrm = NormRegL1Loss()(whn, tgt["regression_mask"], tgt["indices"], tgt["width_height"])
+    nrm.backward()
+    heat5 = torch.sigmoid(rng.t_normal(seed, "heat5", (2, 3, 32, 40)))
+    heat5[0, 1, 4:7, 10:14] = 0.75                        # a plateau: every pixel of it equals its pooled value
+    keep5 = _nms(heat5, 5)
+    save("unused_options.npz", seed=seed, nrm=nrm, dwhn_sum=summary(whn.grad),
+         dwhn_nz=whn.grad.flatten()[whn.grad.flatten() != 0][:64], nms5_nz_idx=torch.nonzero(keep5.flatten()).flatten(),
+         nms5_count=int((keep5 != 0).sum()))
     save("losses.npz", seed=seed, hm=hm, wh=wh, off=off, loss=loss, kp=kp, hm_nopos=hm0,
          dlogits_s=strided(logits.grad), dlogits_sum=summary(logits.grad),
          dwh_sum=summary(whp.grad), dreg_sum=summary(regp.grad),
@@ -443,6 +482,6 @@ def gen_test_step_end():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode", "encode_pose", "decode", "losses", "models", "models101", "hourglass", "pose", "soft_nms", "test_step_end"]
+    which = sys.argv[1:] or ["encode", "encode_msra", "encode_pose", "decode", "losses", "models", "models101", "hourglass", "pose", "soft_nms", "test_step_end"]
     for w in which:
         globals()["gen_" + w]()

@@ -15,9 +15,12 @@ def peak_mask(heat):
     return pooled == heat
 
 
-def nms(heat):
-    """utils/decode.py:5-10."""
-    return heat * peak_mask(heat).float()
+def nms(heat, kernel=3):
+    """utils/decode.py:5-10 (any odd kernel; the reference itself only ever passes the default 3)."""
+    if kernel == 3:
+        return heat * peak_mask(heat).float()
+    pooled = F.max_pool2d(heat, kernel, stride=1, padding=(kernel - 1) // 2)
+    return heat * (pooled == heat).float()
 
 
 def stable_topk(x, k):
@@ -79,6 +82,14 @@ def reg_l1_loss(output, mask, ind, target):
     pred = transpose_and_gather_feat(output, ind)
     m = mask.unsqueeze(2).expand_as(pred).float()
     return F.l1_loss(pred * m, target * m, reduction="sum") / (m.sum() + 1e-4)
+
+
+def norm_reg_l1_loss(output, mask, ind, target):
+    """utils/losses.py:66-78 — L1 between pred / (target + 1e-4) and 1, mask [B,N] bool expanded over channels."""
+    pred = transpose_and_gather_feat(output, ind)
+    m = mask.unsqueeze(2).expand_as(pred).float()
+    pred = pred / (target + 1e-4)
+    return F.l1_loss(pred * m, (target * 0 + 1) * m, reduction="sum") / (m.sum() + 1e-4)
 
 
 def reg_weighted_l1_loss(output, mask, ind, target):

@@ -201,6 +201,30 @@ def test_multi_pose_decode_golden(golden):
     np.testing.assert_array_equal(det2, g["det_nooff"])
 
 
+def test_unused_reference_options_on_device(golden):
+    """NormRegL1Loss (utils/losses.py:66-78) and `_nms(heat, kernel=5)` (utils/decode.py:5) against the reference's outputs."""
+    from centernet_amd.utils.decode import _nms
+    from centernet_amd.utils.losses import NormRegL1Loss
+    g = golden("unused_options.npz")
+    seed = int(g["seed"])
+    _, tgt = synth.ctdet_batch(seed, 2)
+    whn = rng.t_normal(seed, "whn", (2, 2, 128, 128), 0, 5).to(DEV).requires_grad_(True)
+    nrm = NormRegL1Loss()(whn, tgt["regression_mask"].to(DEV), tgt["indices"].to(DEV), tgt["width_height"].to(DEV))
+    nrm.backward()
+    assert nrm.item() == pytest.approx(float(g["nrm"]), rel=1e-5)
+    np.testing.assert_allclose(summary(whn.grad), g["dwhn_sum"], rtol=1e-5)
+    gnz = whn.grad.flatten()
+    np.testing.assert_allclose(gnz[gnz != 0][:64].cpu().numpy(), g["dwhn_nz"], rtol=1e-5)
+    heat5 = torch.sigmoid(rng.t_normal(seed, "heat5", (2, 3, 32, 40)))
+    heat5[0, 1, 4:7, 10:14] = 0.75
+    keep = _nms(heat5.to(DEV), 5)
+    assert np.array_equal(torch.nonzero(keep.flatten()).flatten().cpu().numpy(), g["nms5_nz_idx"])
+    assert torch.equal(keep.cpu()[keep.cpu() != 0], heat5[keep.cpu() != 0])
+    assert torch.equal(_nms(heat5.to(DEV), 3).cpu(), heat5 * (torch.nn.functional.max_pool2d(heat5, 3, 1, 1) == heat5).float())
+    with pytest.raises(ValueError):
+        _nms(heat5.to(DEV), 4)
+
+
 def test_losses_golden_and_grads(golden):
     from centernet_amd.utils.decode import sigmoid_clamped
     from centernet_amd.utils.losses import FocalLoss, RegL1Loss, RegWeightedL1Loss
@@ -283,6 +307,30 @@ def test_encode_ctdet_on_device(golden):
     np.testing.assert_allclose(flat[flat != 0].cpu().numpy(), g["heatmap_nz_val"], rtol=3e-7, atol=1e-7)
     np.testing.assert_allclose(one["width_height"].cpu().numpy(), g["width_height"], rtol=1e-6)
     np.testing.assert_allclose(one["regression"].cpu().numpy(), g["regression"], rtol=1e-5, atol=1e-6)
+
+
+def test_encode_ctdet_msra_on_device(golden):
+    """The reference's other gaussian option for detection targets (sample/ctdet.py:53-55, gaussian_type="msra") through
+    cn_encode_ctdet(gaussian_type=1), against the reference's own outputs (encode_msra_fixture.npz): same support, values within
+    one ulp of expf, the 0/0 NaN pixels of radius-0 objects in the same places, patches touching the border dropped."""
+    from centernet_amd.sample import CenterDetectionSample
+    g = golden("encode_msra_fixture.npz")
+    for i in range(int(g["n"])):
+        ann = [{"bbox": [float(v) for v in bb], "class_id": int(c)} for bb, c in zip(g[f"boxes{i}"], g[f"cls{i}"])]
+        _, t = CenterDetectionSample(gaussian_type="msra")(torch.zeros(3, 512, 512, device=DEV), ann)
+        ref = np.zeros(80 * 128 * 128, np.float32)
+        ref[g[f"hm_nz_idx{i}"]] = g[f"hm_nz_val{i}"]
+        hm = t["heatmap"].flatten().cpu().numpy()
+        assert np.array_equal(np.isnan(hm), np.isnan(ref)), f"set {i}: NaN pixels"
+        ok = ~np.isnan(ref)
+        assert np.array_equal(hm[ok] != 0, ref[ok] != 0), f"set {i}: support"
+        np.testing.assert_allclose(hm[ok], ref[ok], rtol=3e-7, atol=1e-37)
+        assert np.array_equal(t["indices"].cpu().numpy(), g[f"indices{i}"])
+        assert np.array_equal(t["regression_mask"].cpu().numpy(), g[f"regression_mask{i}"])
+        np.testing.assert_allclose(t["width_height"].cpu().numpy(), g[f"width_height{i}"], rtol=1e-6)
+        np.testing.assert_allclose(t["regression"].cpu().numpy(), g[f"regression{i}"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        CenterDetectionSample(gaussian_type="other")
 
 
 def test_encode_multi_pose_on_device(golden):

@@ -32,6 +32,21 @@ def test_encoder_matches_reference_fixture(golden):
         assert np.array_equal(e[k], g[k]), k
 
 
+def test_msra_encoder_matches_reference_fixture(golden):
+    """sample/ctdet.py:53-55 with gaussian_type="msra": the host restatement against the reference's outputs, NaN pixels included."""
+    g = golden("encode_msra_fixture.npz")
+    for i in range(int(g["n"])):
+        boxes = [(list(map(float, b)), int(c)) for b, c in zip(g[f"boxes{i}"], g[f"cls{i}"])]
+        e = synth.encode_ctdet(boxes, gaussian="msra")
+        ref = np.zeros(e["heatmap"].size, np.float32)
+        ref[g[f"hm_nz_idx{i}"]] = g[f"hm_nz_val{i}"]
+        hm = e["heatmap"].reshape(-1)
+        assert np.array_equal(np.isnan(hm), np.isnan(ref))
+        np.testing.assert_allclose(np.nan_to_num(hm), np.nan_to_num(ref), rtol=1e-6, atol=0)
+        for k in ("indices", "width_height", "regression", "regression_mask"):
+            assert np.array_equal(e[k], g[f"{k}{i}"]), k
+
+
 def test_known_answer_encode_decode(golden):
     """reference tests/test_sample_encode_decode.py:35-56 restated on the oracle."""
     g = golden("known_answer.npz")
@@ -66,6 +81,23 @@ def test_decode_bit_exact(golden, tag):
     assert np.array_equal(np.packbits(keep[0, 0].numpy()), g["peak_mask_b0c0"])
     s, i, _, _ = ops_ref.topk_channel(ops_ref.nms(heat), int(g["K"]))
     assert np.array_equal(s[:, :3].numpy(), g["chan_scores"]) and np.array_equal(i[:, :3].numpy(), g["chan_inds"])
+
+
+def test_unused_reference_options(golden):
+    """Two options the reference defines and never uses, pinned by its own outputs: NormRegL1Loss (utils/losses.py:66-78) and the
+    pseudo-NMS with a 5x5 window (utils/decode.py:5)."""
+    g = golden("unused_options.npz")
+    seed = int(g["seed"])
+    _, tgt = synth.ctdet_batch(seed, 2)
+    whn = rng.t_normal(seed, "whn", (2, 2, 128, 128), 0, 5).requires_grad_(True)
+    nrm = ops_ref.norm_reg_l1_loss(whn, tgt["regression_mask"], tgt["indices"], tgt["width_height"])
+    nrm.backward()
+    assert nrm.item() == pytest.approx(float(g["nrm"]), rel=1e-6)
+    np.testing.assert_allclose(summary(whn.grad), g["dwhn_sum"], rtol=1e-6)
+    heat5 = torch.sigmoid(rng.t_normal(seed, "heat5", (2, 3, 32, 40)))
+    heat5[0, 1, 4:7, 10:14] = 0.75
+    keep = ops_ref.nms(heat5, 5)
+    assert np.array_equal(torch.nonzero(keep.flatten()).flatten().numpy(), g["nms5_nz_idx"])
 
 
 def test_losses(golden):
