@@ -42,7 +42,9 @@ class MultiPoseSample:
 
     def __init__(self, down_ratio=4, max_objects=128, gaussian_type="msra", num_joints=17):
         if gaussian_type != "msra":
-            raise NotImplementedError("only the default msra gaussian (sample/multi_pose.py:11, 60-62) is implemented")
+            raise NotImplementedError("only the default msra gaussian (sample/multi_pose.py:11, 60-62): with 'umich' the reference "
+                                      "passes the FLOAT radius to draw_umich_gaussian, which slices with it (TypeError) — "
+                                      "there is no reference behaviour to reproduce")
         self.down_ratio, self.max_objects, self.num_joints = down_ratio, max_objects, num_joints
 
     def __call__(self, img, target):
