@@ -38,19 +38,36 @@ struct __attribute__((aligned(16))) TsShared {
 
 // One histogram pass over the register-resident keys.  PASS0: every key takes part, except that the zeros the pseudo-NMS leaves
 // behind (89 % of a map) are counted with wave ballots (scalar adds) and deposited by one lane.  Otherwise: keys whose resolved
-// bits equal `prefix`.  Plain LDS atomics: lanes that hit the same bin serialise in the LDS (a flat map pays 64 cycles per
-// instruction here — correct, slow, and not a workload); the code per key slot is 7-9 instructions, which is what bounds the
-// common case (an earlier version that aggregated equal bins per wave with ballots cost 45 instructions per slot).
+// bits equal `prefix`.  First pass: plain LDS atomics, 7-9 instructions per key slot, which is what bounds the common case (the
+// select ends after it on any map without large plateaus; aggregating equal bins per wave with ballots there cost 45 instructions
+// per slot in one version and +30 % on realistic maps in another).  Later passes: one round of wave-level aggregation (below).
 template <int NK, bool PASS0>
 __device__ static inline void ts_accumulate(const uint32_t (&key)[NK], uint32_t* hist, uint32_t mask, uint32_t prefix, int shift,
-                                            uint32_t nbm1, int lane) {
+                                            uint32_t nbm1, int lane, bool agg = false) {
     uint32_t nonzero = 0;                       // wave-uniform
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
         const uint32_t k = key[s];
         const bool part = PASS0 ? (k != TS_ZKEY) : ((k & mask) == prefix);
         if (PASS0) nonzero += (uint32_t)__popcll(__ballot(part));
-        if (part) atomicAdd(&hist[(k >> shift) & nbm1], 1u);
+        if (!agg) {
+            if (part) atomicAdd(&hist[(k >> shift) & nbm1], 1u);
+        } else {
+            // `agg` (wave-uniform): most of the map sits in one bin — a plateau, a quantised or a flat map — and every lane of an
+            // instruction would hit the same LDS word: 128 cycles per instruction, all four waves queueing on one bank.  One round
+            // of aggregation: lanes sharing the bin of the wave's first participating lane are counted with a ballot and
+            // deposited by that lane; what is left uses its own atomics.  (More rounds cost more than they save; on maps with a
+            // handful of distinct values the plain atomics are faster, hence the switch.)
+            const uint64_t mp = __ballot(part);
+            if (mp == 0) continue;               // wave-uniform
+            const uint32_t bin = (k >> shift) & nbm1;
+            const int first = __ffsll((long long)mp) - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
+            const bool same = part && bin == b0;
+            const uint32_t ns = (uint32_t)__popcll(__ballot(same));
+            if (lane == first) atomicAdd(&hist[b0], ns);
+            if (part && !same) atomicAdd(&hist[bin], 1u);
+        }
     }
     if (PASS0 && lane == 0) atomicAdd(&hist[TS_ZKEY >> 20], 64u * NK - nonzero);
 }
@@ -97,7 +114,7 @@ template <int NK, typename IdxFn, typename EmitFn>
 __device__ static inline void ts_select(const uint32_t (&key)[NK], IdxFn idx_of, int K, int L, TsShared& sh, EmitFn emit) {
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t prefix = 0, mask = 0, need = (uint32_t)K;
-    bool fits = false;
+    bool fits = false, flat = false;
     // pass 0 is peeled off the loop: inside it the compiler hoists its 64 loop-invariant zero tests out of the loop and keeps
     // their lane masks in (spilled) scalar registers
     auto finish_pass = [&](int shift, int nb) {
@@ -108,9 +125,11 @@ __device__ static inline void ts_select(const uint32_t (&key)[NK], IdxFn idx_of,
         prefix |= bin << shift;
         mask |= (uint32_t)(nb - 1) << shift;
         fits = ((uint32_t)K - need) + cnt <= TS_CAND;
+        flat = cnt > 3u * NK * (TS_THREADS / 4);             // > 3/4 of the keys in one bin: a plateau map
     };
     for (int i = tid; i < 1024; i += TS_THREADS) reinterpret_cast<uint4*>(sh.hist)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    // (first pass: always the plain atomics — a guessed-plateau switch there made flat maps 30 % faster and realistic ones 11 % slower)
     ts_accumulate<NK, true>(key, sh.hist, 0u, 0u, 20, 4095u, lane);
     finish_pass(20, 4096);
 #pragma unroll 1
@@ -119,7 +138,7 @@ __device__ static inline void ts_select(const uint32_t (&key)[NK], IdxFn idx_of,
         const int nb = pass == 2 ? 256 : 4096;
         for (int i = tid; i < nb / 4; i += TS_THREADS) reinterpret_cast<uint4*>(sh.hist)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
-        ts_accumulate<NK, false>(key, sh.hist, mask, prefix, shift, (uint32_t)(nb - 1), lane);
+        ts_accumulate<NK, false>(key, sh.hist, mask, prefix, shift, (uint32_t)(nb - 1), lane, flat);
         finish_pass(shift, nb);
     }
     const uint32_t thr = prefix;     // early exit: lower bound of the crossing bin; otherwise the K-th largest key itself
@@ -130,8 +149,22 @@ __device__ static inline void ts_select(const uint32_t (&key)[NK], IdxFn idx_of,
         for (int i = tid; i < 64; i += TS_THREADS) reinterpret_cast<uint4*>(sh.hist)[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < NK; ++s)
-            if (key[s] == thr) atomicAdd(&sh.hist[(uint32_t)idx_of(s) >> 7], 1u);
+        for (int s = 0; s < NK; ++s) {                    // plateau maps: the same one-round aggregation (a wave's lanes mostly share a row)
+            const bool part = key[s] == thr;
+            if (!flat) {
+                if (part) atomicAdd(&sh.hist[(uint32_t)idx_of(s) >> 7], 1u);
+                continue;
+            }
+            const uint64_t mp = __ballot(part);
+            if (mp == 0) continue;
+            const uint32_t bin = (uint32_t)idx_of(s) >> 7;
+            const int first = __ffsll((long long)mp) - 1;
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
+            const bool same = part && bin == b0;
+            const uint32_t ns = (uint32_t)__popcll(__ballot(same));
+            if (lane == first) atomicAdd(&sh.hist[b0], ns);
+            if (part && !same) atomicAdd(&sh.hist[bin], 1u);
+        }
         __syncthreads();
         ts_find_crossing<false>(sh, nbA, need);
         const uint32_t rowbin = sh.ctl[0], need2 = sh.ctl[1];
