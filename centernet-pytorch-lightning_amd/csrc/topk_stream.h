@@ -114,7 +114,7 @@ template <int NK, typename IdxFn, typename EmitFn>
 __device__ static inline void ts_select(const uint32_t (&key)[NK], IdxFn idx_of, int K, int L, TsShared& sh, EmitFn emit) {
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t prefix = 0, mask = 0, need = (uint32_t)K;
-    bool fits = false, flat = false;
+    bool fits = false, flat = false, constant = false;
     // pass 0 is peeled off the loop: inside it the compiler hoists its 64 loop-invariant zero tests out of the loop and keeps
     // their lane masks in (spilled) scalar registers
     auto finish_pass = [&](int shift, int nb) {
@@ -126,6 +126,7 @@ __device__ static inline void ts_select(const uint32_t (&key)[NK], IdxFn idx_of,
         mask |= (uint32_t)(nb - 1) << shift;
         fits = ((uint32_t)K - need) + cnt <= TS_CAND;
         flat = cnt > 3u * NK * (TS_THREADS / 4);             // > 3/4 of the keys in one bin: a plateau map
+        constant = cnt == (uint32_t)(NK * TS_THREADS);       // every key slot in the bin
     };
     for (int i = tid; i < 1024; i += TS_THREADS) reinterpret_cast<uint4*>(sh.hist)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -143,6 +144,12 @@ __device__ static inline void ts_select(const uint32_t (&key)[NK], IdxFn idx_of,
     }
     const uint32_t thr = prefix;     // early exit: lower bound of the crossing bin; otherwise the K-th largest key itself
     uint32_t idx_thr = 0xffffffffu;
+    if (!fits && constant && L == NK * TS_THREADS) {
+        // all 32 bits are resolved and EVERY slot of a full map holds thr: a constant map (the head maps of an untrained network in
+        // eval mode).  The K lowest flat indices are 0 .. K-1: no index histograms.
+        if (tid < K) emit(tid, thr, (uint32_t)tid);
+        return;
+    }
     if (!fits) {
         // every bit is resolved: thr is the K-th largest key and more elements share it than are needed -> the `need` lowest indices
         const int nbA = (L + 127) >> 7;
