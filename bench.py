@@ -237,7 +237,7 @@ def inference_rate(model, x, steps=20):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=side):       # same stream as the warm-up: its stream-keyed workspaces are reused
         det = infer()
     for _ in range(3):
         g.replay()

@@ -44,7 +44,7 @@ class CenterNet(_Base):
         self.head_conv = 256 if "dla" in arch or "hourglass" in arch else 64
         self.num_stacks = 2 if "hourglass" in arch else 1
         self.padding = 127 if "hourglass" in arch else 31
-        self.backbone = create_model(arch, compute_dtype=compute_dtype)
+        self.backbone = create_model(arch, compute_dtype=compute_dtype, nchw_out=False)     # NHWC handle straight into the heads
         self.down_ratio = 4
 
     @staticmethod

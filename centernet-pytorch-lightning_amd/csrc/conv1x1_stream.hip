@@ -108,16 +108,17 @@ __global__ __launch_bounds__(S1_NT) void conv1x1_stream_kernel(const ConvGeom g,
     }
 }
 
+#define CN_MAX_DEVICES 16
 template <int KS, int NJ>
-static bool s1_go(const ConvGeom& g, int64_t npix, int grid, hipStream_t st) {
+static bool s1_go(const ConvGeom& g, int64_t npix, int grid, int dev, hipStream_t st) {
     const size_t smem = (size_t)NJ * 32 * (KS * 16 + 8) * 2 + (size_t)NJ * 32 * 4;
     const int res = g.res == nullptr ? 0 : (g.relu == 2 ? 2 : 1);
     if (g.y_f32 && res != 0) return false;
 #define S1_GO(F32_, RES_, RELU_)                                                                                         \
     do {                                                                                                                 \
         auto kfn = conv1x1_stream_kernel<KS, NJ, F32_, RES_, RELU_>;                                                     \
-        static bool attr = false;                                                                                        \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        static bool attr[CN_MAX_DEVICES] = {};       /* function attributes are per device */                            \
+        if (!attr[dev]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; } \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(S1_NT), smem, st, g, npix);                                             \
     } while (0)
     if (g.y_f32) { if (g.relu == 1) S1_GO(true, 0, true); else S1_GO(true, 0, false); }
@@ -131,7 +132,7 @@ static bool s1_go(const ConvGeom& g, int64_t npix, int grid, hipStream_t st) {
 // caller guarantees: 1x1 / stride 1 / pad 0 geometry (normal or transposed: one tap, no shift), OH == H, OW == W
 bool conv1x1_stream_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_CONV1X1_STREAM") != nullptr;
-    static int cus = 0;
+    static int cus_of[CN_MAX_DEVICES] = {};       // CU count per device (a single process may drive several)
     if (disabled || dtype != CN_BF16 || g.nsrc != 0 || g.dcn_x != nullptr || g.res32 != nullptr) return false;
     if ((g.x_ld & 7) || (g.y_ld & 7) || (g.res != nullptr && (g.res_ld & 7))) return false;
     if ((reinterpret_cast<uintptr_t>(g.x) | reinterpret_cast<uintptr_t>(g.w) | reinterpret_cast<uintptr_t>(g.y) | reinterpret_cast<uintptr_t>(g.res)) & 15) return false;
@@ -141,19 +142,22 @@ bool conv1x1_stream_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     if (nj * 16 + 2 * (K / 16) * 4 > 200) return false;                    // accumulators + two fragment sets must leave 2 waves per SIMD
     const int64_t npix = (int64_t)g.N * g.OH * g.OW;
     if (npix < 64 * 1024) return false;                                    // small maps: the weight load per workgroup dominates
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return false;
-        cus = v;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CN_MAX_DEVICES) return false;
+    if (cus_of[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return false;
+        cus_of[dev] = v;
     }
+    const int cus = cus_of[dev];
     const int grid = (int)std::min<int64_t>(2 * (int64_t)cus, (npix / 32 + 3) / 4);
 #define S1_K(KS_)                                                                              \
     switch (nj) {                                                                              \
-        case 1: return s1_go<KS_, 1>(g, npix, grid, st);                                       \
-        case 2: return s1_go<KS_, 2>(g, npix, grid, st);                                       \
-        case 3: return s1_go<KS_, 3>(g, npix, grid, st);                                       \
-        case 4: return s1_go<KS_, 4>(g, npix, grid, st);                                       \
-        case 8: if (KS_ <= 8) return s1_go<(KS_ <= 8 ? KS_ : 8), 8>(g, npix, grid, st); return false; \
+        case 1: return s1_go<KS_, 1>(g, npix, grid, dev, st);                                       \
+        case 2: return s1_go<KS_, 2>(g, npix, grid, dev, st);                                       \
+        case 3: return s1_go<KS_, 3>(g, npix, grid, dev, st);                                       \
+        case 4: return s1_go<KS_, 4>(g, npix, grid, dev, st);                                       \
+        case 8: if (KS_ <= 8) return s1_go<(KS_ <= 8 ? KS_ : 8), 8>(g, npix, grid, dev, st); return false; \
         default: return false;                                                                 \
     }
     if (K == 32) { S1_K(2) }

@@ -141,11 +141,13 @@ __global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v[V];
-                Vec16<T>::unpack(xr[t], v);
+                // an out-of-image tap was loaded from the clamped address (n,0,0): zero the DATA, not the weight — 0 * Inf would
+                // otherwise put NaN into every border output of that channel (ConvTranspose2d ignores such taps)
+                const uint4 xv = ok[t] ? xr[t] : make_uint4(0, 0, 0, 0);
+                Vec16<T>::unpack(xv, v);
                 const float* wt = wl + tap[t] * C + cv * V;
-                const float m = ok[t] ? 1.f : 0.f;
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], wt[j] * m, acc[j]);
+                for (int j = 0; j < V; ++j) acc[j] = fmaf(v[j], wt[j], acc[j]);
             }
             if (res) {
                 float r[V];

@@ -254,6 +254,12 @@ class GradSync:
                                        "ops.GradReady.note reported")
         self._pending = []
 
+    def abort(self):
+        """backward raised: drop this pass's bookkeeping so that nothing installed by begin() outlives it"""
+        GradReady.sink = GradReady.claim_sink = None
+        self._pending, self._works = [], []
+        self._seen, self._launched, self._claimed = set(), set(), set()
+
     def allreduce_all(self):
         """Non-overlapped variant (used between the two captured graphs): every bucket, then wait."""
         if not self.exchange:
@@ -397,8 +403,14 @@ class TrainStep:
         if self.sync is not None and not self._between:
             self.sync.begin()
         SideGrads.active = self.side
-        loss.backward()
-        SideGrads.join()
+        try:
+            loss.backward()
+            SideGrads.join()
+        except BaseException:
+            # a failed backward (OOM, kernel error) must not leave this step's deposit sinks installed: a later backward in the
+            # process would report into this GradSync and could launch collectives the other ranks never match
+            self._abort_backward()
+            raise
         self._end_packs()
         self._join_post_forward()
         if self.sync is not None:
@@ -408,6 +420,13 @@ class TrainStep:
             with torch.no_grad():
                 self.post_out = self.post_step()
         return loss.detach()
+
+    def _abort_backward(self):
+        SideGrads.pending, SideGrads.active = [], False
+        GradReady.sink = GradReady.claim_sink = None
+        PackArena.current, self._packs.recording = None, False
+        if self.sync is not None:
+            self.sync.abort()
 
     def _capture(self, batch):
         x, tgt = batch
@@ -446,7 +465,9 @@ class TrainStep:
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # with a process group alive, its watchdog thread polls events while we capture: only police THIS thread's calls
         mode = "thread_local" if (dist.is_initialized() or os.environ.get("CN_CAPTURE_THREAD_LOCAL")) else "global"
-        with torch.cuda.graph(self._g1, capture_error_mode=mode):
+        # capture on the stream the warm-up steps ran on: `_hip.workspace` is keyed by stream, so the capture replays into the
+        # buffers the warm-up sized instead of allocating a second set from the graph's private pool
+        with torch.cuda.graph(self._g1, stream=side, capture_error_mode=mode):
             self.opt.zero_grad()
             self._begin_packs()
             loss = self.model.training_step(static, 0)
@@ -463,7 +484,7 @@ class TrainStep:
             self._loss = loss.detach()
         for m in self._bns:
             m._pending -= 1          # the capture pass ran host code only; nothing executed on the device
-        with torch.cuda.graph(self._g2, pool=self._g1.pool(), capture_error_mode=mode):
+        with torch.cuda.graph(self._g2, pool=self._g1.pool(), stream=side, capture_error_mode=mode):
             self.opt.launch()
             if self.post_step is not None:
                 with torch.no_grad():
@@ -484,9 +505,7 @@ class TrainStep:
                       file=sys.stderr, flush=True)
                 self._g1 = self._g2 = None
                 self.graph = False
-                SideGrads.pending, SideGrads.active = [], False
-                GradReady.sink = GradReady.claim_sink = None
-                PackArena.current, self._packs.recording = None, False
+                self._abort_backward()
                 torch.cuda.synchronize()
                 return self._eager(batch, batch_idx)
         if batch[0] is not self._sx:

@@ -2,11 +2,12 @@
 
 An architecture string is `<family>[_<depth>]`; the family picks a factory, the depth is passed through as `num_layers`.
 Every factory returns a module with `.out_channels` that maps the NCHW fp32 image to a list of feature maps at stride 4 (one
-per stack).  By default the maps are the engine's NHWC activation handles (compute dtype, tagged by `ops.mark_nhwc`) that
-`heads.CenterHead` consumes without a layout change; `create_model(arch, nchw_out=True)` (or `backbone.nchw_out = True`) makes
-the backbone return the reference's own contract instead — `list[Tensor[B, out_channels, H/4, W/4]]`, fp32 NCHW
-(models/__init__.py:14-19) — for consumers outside this package.  `heads.CenterHead` accepts either, so a plain-torch NCHW
-backbone registered in `_model_factory` composes with this package's heads and this package's backbones with plain-torch heads.
+per stack).  `create_model(arch)` keeps the REFERENCE's return contract — `list[Tensor[B, out_channels, H/4, W/4]]`, fp32 NCHW
+(models/__init__.py:14-19) — so a consumer outside this package sees exactly what the reference's backbones return.  The task
+modules of this package (`centernet.CenterNet`) pass `nchw_out=False`: the maps are then the engine's NHWC activation handles
+(compute dtype, tagged by `ops.mark_nhwc`) that `heads.CenterHead` consumes without a layout change.  `heads.CenterHead` accepts
+either, so a plain-torch NCHW backbone registered in `_model_factory` composes with this package's heads and this package's
+backbones with plain-torch heads.
 """
 import torch
 
@@ -30,10 +31,9 @@ def _split_arch(arch):
     return family, (int(depth) if depth else 0)
 
 
-def create_model(arch, compute_dtype=torch.bfloat16, nchw_out=False, **kwargs):
+def create_model(arch, compute_dtype=torch.bfloat16, nchw_out=True, **kwargs):
     """`"res_18"` -> family "res", num_layers 18.  Unknown families raise KeyError like the reference's dict lookup."""
     family, depth = _split_arch(arch)
     model = _model_factory[family](num_layers=depth, compute_dtype=compute_dtype, **kwargs)
-    if nchw_out:
-        model.nchw_out = True
+    model.nchw_out = bool(nchw_out)
     return model

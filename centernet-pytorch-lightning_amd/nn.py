@@ -106,9 +106,9 @@ def conv_bn_act_skip(conv, bn, x):
 
 def cat_conv_bn_act(conv, bn, xs, residual=None, relu=True):
     """conv1x1(cat(xs, channel)) -> BN -> (+residual) -> ReLU without building the concatenation (DLA Root).  Falls back to
-    concat + conv for anything that is not a bias-free 1x1 / stride-1 conv over 16-channel-aligned sources."""
+    concat + conv for anything that is not a bias-free 1x1 / stride-1 conv over 32-channel-aligned sources."""
     ok = (conv.k == 1 and conv.stride == 1 and conv.padding == 0 and conv.bias is None and 1 <= len(xs) <= 6
-          and all(t.shape[-1] % 16 == 0 for t in xs))
+          and all(t.shape[-1] % 32 == 0 for t in xs))      # the data-gradient GEMM of a source reads rup32(C_s) operand rows
     if not ok or len(xs) == 1:
         return conv_bn_act(conv, bn, ops.concat(list(xs)), residual, relu)
     grad = torch.is_grad_enabled() and (conv.weight.requires_grad or any(t.requires_grad for t in xs))

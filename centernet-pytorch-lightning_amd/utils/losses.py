@@ -61,7 +61,7 @@ class _NormRegL1Fn(torch.autograd.Function):
         r = pred / (target + 1e-4)
         den = m.sum() + 1e-4
         ctx.save_for_backward(r, m, target, ind, den)
-        ctx.shape = feat.shape
+        ctx.shape, ctx.hw = feat.shape, HW
         return (r * m - m).abs().sum() / den
 
     @staticmethod
@@ -69,7 +69,7 @@ class _NormRegL1Fn(torch.autograd.Function):
         r, m, target, ind, den = ctx.saved_tensors
         B, C = ctx.shape[:2]
         dpred = g * torch.sign(r * m - m) * m / (target + 1e-4) / den                 # [B,N,C]
-        dfeat = torch.zeros((B, C, r.new_empty(ctx.shape)[0, 0].numel()), dtype=torch.float32, device=r.device)
+        dfeat = torch.zeros((B, C, ctx.hw), dtype=torch.float32, device=r.device)
         dfeat.scatter_add_(2, ind.unsqueeze(1).expand(B, C, ind.shape[1]), dpred.permute(0, 2, 1).contiguous())
         return dfeat.view(ctx.shape), None, None, None
 

@@ -235,7 +235,7 @@ def test_reference_shaped_seam_nchw_both_ways(golden):
     from centernet_amd.models import create_model, _model_factory
     from centernet_amd.models.heads import CenterHead
     # (a) shape contract of tests/test_models.py on the 512x512 input
-    net = create_model("dla_34", compute_dtype=torch.bfloat16, nchw_out=True).to(DEV).eval()
+    net = create_model("dla_34", compute_dtype=torch.bfloat16).to(DEV).eval()      # public default = the reference contract
     with torch.no_grad():
         y = net(torch.rand(1, 3, 512, 512, device=DEV))
     assert isinstance(y, list) and y[0].shape == (1, 64, 128, 128) and y[0].dtype == torch.float32

@@ -343,12 +343,14 @@ def test_eval_caches_key_on_the_weights_epoch():
 
 
 def test_backbones_expose_the_reference_output_contract_switch():
-    """§8b: `create_model(arch, nchw_out=True)` flips the backbone to the reference's `list[Tensor[B,C,H/4,W/4]]` fp32
-    contract; the default stays the tagged NHWC handle."""
+    """§8b: the PUBLIC default of `create_model(arch)` is the reference's `list[Tensor[B,C,H/4,W/4]]` fp32 contract
+    (models/__init__.py:14-19); the task modules opt into the tagged NHWC handle with `nchw_out=False`."""
     from centernet_amd import ops
+    from centernet_amd.centernet_detection import CenterNetDetection
     from centernet_amd.models import create_model
     for arch in ("res_18", "resdcn_18", "dla_34", "hourglass"):
-        assert create_model(arch).nchw_out is False
-        assert create_model(arch, nchw_out=True).nchw_out is True
+        assert create_model(arch).nchw_out is True
+        assert create_model(arch, nchw_out=False).nchw_out is False
+    assert CenterNetDetection("res_18").backbone.nchw_out is False
     t = torch.zeros(1, 4, 4, 16)
     assert not ops.is_nhwc(t) and ops.is_nhwc(ops.mark_nhwc(t, 3)) and t._cn_nhwc == 3
