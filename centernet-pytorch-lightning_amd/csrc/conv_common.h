@@ -318,6 +318,8 @@ void dcn_bwd_dx_launch(const ConvGeom& g, int dtype, hipStream_t st);
 void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st);
 bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
                          int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st);
+bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
+                       int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st);   // dcn_bm.hip: blend on the matrix cores
 bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, int dom_slabs, float* far, int* far_flag,
                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, hipStream_t st);
 

@@ -595,6 +595,10 @@ extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const 
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld;
     g.ktot = 9 * Ci; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu; g.so = 1; g.sm = 1;
     g.dcn_om = om; g.dcn_omld = om_ld;
+    if (dtype == CN_BF16 && dcn_fwd_bm_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_dcn_fwd(bm)");
+        return CN_OK;
+    }
     if (!(dtype == CN_BF16 && dcn_fwd_tile_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, (hipStream_t)stream)))
         dcn_fwd_launch(g, dtype, (hipStream_t)stream);
     CN_LAUNCH_CHECK("cn_dcn_fwd");

@@ -1,0 +1,332 @@
+// DCNv2 with the bilinear blend ON THE MATRIX CORES ("blend-matrix" formulation; bf16, 64-channel blocks of x).
+//
+//   S_k[p][ci] = sum_q Bm_k[p][q] * x[q][ci]        Bm_k: 4 non-zeros per row = bilinear weights * mask of (pixel p, tap k)
+//   y[p][co]   = bias[co] + sum_k sum_ci W_k[co][ci] * S_k[p][ci]                                  
+//
+// The gather kernels (dcn_fused.hip) blend on the VALU: per (pixel, tap, 8 channels) 4 L2 gathers, 32 bf16 unpacks, 32 FMAs, 4
+// converts — ~580 VALU instructions per thread and tap against ~20 MFMAs; PMC and instruction counts say they are bound by that
+// stream.  Here the blend is a second MFMA: one WAVE owns a 4x8 group of output pixels and keeps the x WINDOW that
+// group can sample (12 rows x 16 columns: +-4 pixels, i.e. offsets up to |d| <= 3 px for every tap) as TRANSPOSED MFMA
+// fragments in registers for all nine taps (loaded once per group with ds_read_b64_tr_b16 from the workgroup's halo image in
+// LDS).  One window row = 16 source pixels = the K of one v_mfma_f32_32x32x16_bf16, so per tap and touched window row
+//   S^T[ci][p] += X^T[ci][row r, 16 cols] * Bm^T[row r, 16 cols][p]
+// where a lane builds the 8 bf16 of ITS OWN pixel's blend-matrix row for that window row with a handful of selects (two packed
+// weight pairs, shifted to the corner column once per tap).  S^T comes out of the matrix pipe with lane = pixel, register =
+// channel — exactly the B operand of the contraction y^T[co][p] += W_k^T[co][ci] S^T[ci][p] when W is staged with the matching
+// channel permutation — so the sampled operand never touches LDS, the VALU never unpacks bf16, and fp32 conversion is the
+// matrix pipe's.  The bilinear weights enter the MFMA as bf16 (rel. 2^-9, the same size as the bf16 rounding of S itself);
+// fp32 parity mode keeps the gather kernels.  Samples whose corners leave the window (|offset| > 3 px) are blended by a
+// per-lane VALU fallback into the same registers (exact fp32 weights), so any offset field is handled.
+#include "conv_common.h"
+#include <stdlib.h>
+
+#define BM_TH 8
+#define BM_TW 16
+#define BM_MG 4                          // window margin around a pixel group
+#define BM_WR (BM_TH + 2 * BM_MG)        // 16 window rows per workgroup tile
+#define BM_WC (BM_TW + 2 * BM_MG)        // 24 window columns
+#define BM_GR 12                         // window rows of one 4x8 group
+#define BM_PIXB 128                      // bytes per window pixel in LDS (64 bf16)
+
+struct BmGeom {
+    const bf16_t* x; const float* om; const bf16_t* wp; const float* bias; bf16_t* y;
+    int N, H, W, x_ld, y_ld, om_ld, ktot, Co, relu;
+};
+
+typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
+typedef short s16x8_t_ __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// LDS byte address of (window row, window col, channel c) in the halo image: 128 B per pixel, the two 64-byte halves swapped on
+// every other column PAIR so that the 4 consecutive columns a transposing read touches hit 4 disjoint 16-bank segments
+__device__ static inline int bm_lds_ofs(int wr, int wc, int c) {
+    return (wr * BM_WC + wc) * BM_PIXB + ((((c >> 5) ^ (wc >> 1)) & 1) << 6) + (c & 31) * 2;
+}
+
+template <int NCB>   // 32-channel output blocks (Co = 32 * NCB)
+__global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Xw = smem;                                   // [16][24] pixels x 128 B
+    unsigned char* const Ws = smem + BM_WR * BM_WC * BM_PIXB;         // 2 x [4 k-steps][2 halves][32*NCB co][8] bf16
+    constexpr int WSB = 4 * 2 * 32 * NCB * 16;                        // bytes per weight buffer
+    // byte-permute selectors that place a packed weight pair at 16-bit element c of an 8-element (4-dword) vector, c = -8 .. 14:
+    // dword d = pair (s == 0), pair << 16 (s == 1), pair >> 16 (s == -1) or 0, s = c - 2d   (v_perm_b32; selector 0x0c = 0x00)
+    u32x4v* const Lut = reinterpret_cast<u32x4v*>(Ws + 2 * WSB);      // [23]
+    if (threadIdx.x < 23) {
+        const int c = (int)threadIdx.x - 8;
+        u32x4v sel;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int sft = c - 2 * d;
+            sel[d] = sft == 0 ? 0x03020100u : (sft == 1 ? 0x01000c0cu : (sft == -1 ? 0x0c0c0302u : 0x0c0c0c0cu));
+        }
+        Lut[threadIdx.x] = sel;
+    }
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_w = (g.W + BM_TW - 1) / BM_TW;
+    const int ty0 = (blockIdx.x / tiles_w) * BM_TH, tx0 = (blockIdx.x % tiles_w) * BM_TW;
+    const int n = blockIdx.y;
+    const int64_t img = (int64_t)n * g.H * g.W;
+    const bf16_t* __restrict__ X = g.x + img * g.x_ld;
+    const float* __restrict__ OM = g.om + img * g.om_ld;
+
+    // ---- weight slice of a tap: global (mode-1 pack [co][tap*64 + ci]) -> registers -> LDS in fragment order ----
+    // slot = (s, h, co): 8 bf16 = W[co][ci(s,h,e)], ci = 32*(s>>1) + 16*(s&1) + 8*(e>>2) + 4*h + (e&3)   (the order S^T's registers have)
+    constexpr int WSLOTS = 4 * 2 * 32 * NCB;
+    constexpr int WPT = (WSLOTS + 255) / 256;
+    uint2 wr_[WPT][2];
+    auto wload = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int slot = tid + i * 256;
+            const int co = slot % (32 * NCB), sh = slot / (32 * NCB), h = sh & 1, s = sh >> 1;
+            const int ci0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * h;
+            const bf16_t* p = g.wp + (int64_t)co * g.ktot + tap * 64 + ci0;
+            wr_[i][0] = *reinterpret_cast<const uint2*>(p);
+            wr_[i][1] = *reinterpret_cast<const uint2*>(p + 8);
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int slot = tid + i * 256;
+            *reinterpret_cast<u32x4v*>(Ws + buf * WSB + slot * 16) = u32x4v{wr_[i][0].x, wr_[i][0].y, wr_[i][1].x, wr_[i][1].y};
+        }
+    };
+    wload(0);
+
+    // ---- halo image of the tile: rows ty0-4 .. ty0+11, columns tx0-4 .. tx0+19, zeros outside the image ----
+    {
+        constexpr int NV = BM_WR * BM_WC * 8;     // 16-byte vectors
+#pragma unroll
+        for (int i = 0; i < NV / 256; ++i) {
+            const int v = tid + i * 256;
+            const int pix = v >> 3, q = v & 7;
+            const int wr = pix / BM_WC, wc = pix % BM_WC;
+            const int gy = ty0 - BM_MG + wr, gx = tx0 - BM_MG + wc;
+            const bool ok = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
+            const uint4 val = ldg16_masked(X, (((int64_t)gy * g.W + gx) * g.x_ld + q * 8) * 2, ok);
+            st16(Xw + bm_lds_ofs(wr, wc, q * 8), val);
+        }
+    }
+    wstore(0);
+    __syncthreads();
+    // ---- this wave's pixel group ----
+    const int grow = (wave >> 1) * 4, gcol = (wave & 1) * 8;       // group origin inside the tile == its window origin in the halo image
+    const int nl = lane & 31, hh = lane >> 5;
+    const int gy = ty0 + grow + (nl >> 3), gx = tx0 + gcol + (nl & 7);
+    const bool live = gy < g.H && gx < g.W;
+    // offsets / mask logits of the group's 32 pixels (om_ld == 32: one 128-byte row per pixel): four coalesced 16-byte loads per
+    // lane now, parked in the dead halo image after the fragment loads — the tap loop then has no global load on its critical path
+    // (a per-tap global prefetch made the compiler wait for the weight prefetch as well: vmcnt(0) at every loop top)
+    float4 omr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i, p = idx >> 3, part = idx & 7;
+        const int py_ = ty0 + grow + (p >> 3), px_ = tx0 + gcol + (p & 7);
+        const bool ok = py_ < g.H && px_ < g.W;
+        omr[i] = *reinterpret_cast<const float4*>(OM + ((int64_t)(ok ? py_ : 0) * g.W + (ok ? px_ : 0)) * 32 + part * 4);
+    }
+    wload(1);
+
+    // ---- ... and its window fragments ----
+    bf16x8_t xf[BM_GR][2];
+    {
+        const int r16 = lane & 15, g16 = lane >> 4;
+        typedef __attribute__((address_space(3))) s16x4_t_* lds_ptr;
+        // two base addresses (the swizzle makes the channel-block step +-64 B per lane); rows and the +4-column half are immediates
+        const int wc0 = gcol + 8 * (g16 >> 1) + (r16 >> 2);
+        const unsigned char* const b0 = Xw + bm_lds_ofs(grow, wc0, 16 * (g16 & 1) + 4 * (r16 & 3));
+        const unsigned char* const b1 = Xw + bm_lds_ofs(grow, wc0, 32 + 16 * (g16 & 1) + 4 * (r16 & 3));
+#pragma unroll
+        for (int r = 0; r < BM_GR; ++r)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const unsigned char* p = (mb ? b1 : b0) + r * (BM_WC * BM_PIXB);
+                const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+                const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * BM_PIXB));
+                const s16x8_t_ v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                xf[r][mb] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    }
+
+    __syncthreads();        // every wave holds its fragments: the halo image is dead (re-used as far-sample scratch, 8 KB per wave,
+                            // and from byte 32768 on as the waves' offset tables: [32 px][29] floats each)
+    float* const Om = reinterpret_cast<float*>(Xw + 32768 + wave * (32 * 29 * 4));     // odd pitch: conflict-free per-pixel reads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i, p = idx >> 3, part = idx & 7;
+        float* d = Om + p * 29 + part * 4;
+        if (part < 7) { d[0] = omr[i].x; d[1] = omr[i].y; d[2] = omr[i].z; if (part < 6) d[3] = omr[i].w; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* const orow = Om + nl * 29;
+    float ro[3] = {orow[0], orow[1], orow[18]};
+
+    f32x16_t acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        // ---- geometry of (own pixel, tap): window position of corner 00 and the two packed weight pairs ----
+        const float py = (float)(gy - 1 + ky) + ro[0], px = (float)(gx - 1 + kx) + ro[1];
+        const float m = live ? __builtin_amdgcn_rcpf(1.f + __expf(-ro[2])) : 0.f;      // sigmoid; the product is rounded to bf16 anyway
+        {   // next tap's offsets / mask logit (LDS table)
+            const int nt = tap < 8 ? tap + 1 : 8;
+            ro[0] = orow[2 * nt]; ro[1] = orow[2 * nt + 1]; ro[2] = orow[18 + nt];
+        }
+        const Tap t = make_tap(py, px, g.H, g.W);
+        const float w00 = t.w00 * m, w01 = t.w01 * m, w10 = t.w10 * m, w11 = t.w11 * m;
+        const bool anyw = (w00 != 0.f) | (w01 != 0.f) | (w10 != 0.f) | (w11 != 0.f);
+        const int wr = t.h0 - (ty0 + grow - BM_MG), wc = t.w0 - (tx0 + gcol - BM_MG);  // window coordinates of corner 00
+        const bool inwin = (unsigned)wr <= (unsigned)(BM_GR - 2) && (unsigned)wc <= 14u;
+        const bool far = anyw && !inwin;
+        const uint32_t P0 = (anyw && inwin) ? pk_bf16(w00, w01) : 0u, P1 = (anyw && inwin) ? pk_bf16(w10, w11) : 0u;
+        const int wr_top = (P0 != 0u) ? wr : -1, wr_bot = (P1 != 0u) ? wr + 1 : -1;
+        // 8-element (4-dword) images of the two weight pairs for this lane's column half: pair element a sits at column wc
+        const u32x4v sel = Lut[min(max(wc - 8 * hh + 8, 0), 22)];
+        uint32_t V0[4], V1[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            V0[d] = __builtin_amdgcn_perm(P0, P0, sel[d]);
+            V1[d] = __builtin_amdgcn_perm(P1, P1, sel[d]);
+        }
+        // window rows anybody in the wave samples (wave-wide OR of the lanes' row bits: 4 DPP steps per 16-lane row + 4 readlanes)
+        uint32_t rows = ((P0 != 0u) ? (1u << (wr & 15)) : 0u) | ((P1 != 0u) ? (2u << (wr & 15)) : 0u);
+        rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+        rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+        rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x141, 0xF, 0xF, true);    // row_half_mirror
+        rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x140, 0xF, 0xF, true);    // row_mirror
+        const uint32_t rowmask = (uint32_t)__builtin_amdgcn_readlane((int)rows, 0) | (uint32_t)__builtin_amdgcn_readlane((int)rows, 16) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)rows, 32) | (uint32_t)__builtin_amdgcn_readlane((int)rows, 48);
+
+        // ---- S^T[ci][p] = sum over the touched window rows (K = the row's 16 source columns) ----
+        f32x16_t st[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
+        // the zeros must be real registers: folded into the first MFMA (C = 0) the compiler merges the skip branches below with 32
+        // accumulator copies per row
+        asm volatile("" : "+v"(st[0]), "+v"(st[1]));
+#pragma unroll
+        for (int r = 0; r < BM_GR; ++r) {
+            if (!(rowmask & (1u << r))) continue;                              // wave-uniform: nobody samples this row
+            const bool t0 = wr_top == r, t1 = wr_bot == r;
+            u32x4v b;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) b[d] = t0 ? V0[d] : (t1 ? V1[d] : 0u);
+            const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b);
+            st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[r][0], bf, st[0], 0, 0, 0);
+            st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[r][1], bf, st[1], 0, 0, 0);
+        }
+        // ---- samples that leave the window (rare): exact fp32 VALU blend from global memory.  The lane pair of the pixel writes the
+        //      blended 64-channel row into the wave's slice of the (by now dead) halo image, then adds it to its S^T registers ----
+        if (__builtin_amdgcn_ballot_w64(far) != 0) {
+            float* const F = reinterpret_cast<float*>(Xw + wave * (32 * 64 * 4)) + nl * 64;
+            if (far) {
+                const int hc0 = min(max(t.h0, 0), g.H - 1), hc1 = min(max(t.h0 + 1, 0), g.H - 1);
+                const int wc0 = min(max(t.w0, 0), g.W - 1), wc1 = min(max(t.w0 + 1, 0), g.W - 1);
+                const bf16_t* p00 = X + ((int64_t)hc0 * g.W + wc0) * g.x_ld + 32 * hh;
+                const bf16_t* p01 = X + ((int64_t)hc0 * g.W + wc1) * g.x_ld + 32 * hh;
+                const bf16_t* p10 = X + ((int64_t)hc1 * g.W + wc0) * g.x_ld + 32 * hh;
+                const bf16_t* p11 = X + ((int64_t)hc1 * g.W + wc1) * g.x_ld + 32 * hh;
+#pragma unroll 1
+                for (int q = 0; q < 8; ++q) {          // this lane's half of the row: channels 32*hh + 4q .. +3
+                    const uint2 a = *reinterpret_cast<const uint2*>(p00 + 4 * q), b = *reinterpret_cast<const uint2*>(p01 + 4 * q);
+                    const uint2 cc = *reinterpret_cast<const uint2*>(p10 + 4 * q), d = *reinterpret_cast<const uint2*>(p11 + 4 * q);
+                    float4 o;
+                    o.x = __uint_as_float(a.x << 16) * w00 + __uint_as_float(b.x << 16) * w01 + __uint_as_float(cc.x << 16) * w10 + __uint_as_float(d.x << 16) * w11;
+                    o.y = __uint_as_float(a.x & 0xffff0000u) * w00 + __uint_as_float(b.x & 0xffff0000u) * w01 + __uint_as_float(cc.x & 0xffff0000u) * w10 + __uint_as_float(d.x & 0xffff0000u) * w11;
+                    o.z = __uint_as_float(a.y << 16) * w00 + __uint_as_float(b.y << 16) * w01 + __uint_as_float(cc.y << 16) * w10 + __uint_as_float(d.y << 16) * w11;
+                    o.w = __uint_as_float(a.y & 0xffff0000u) * w00 + __uint_as_float(b.y & 0xffff0000u) * w01 + __uint_as_float(cc.y & 0xffff0000u) * w10 + __uint_as_float(d.y & 0xffff0000u) * w11;
+                    *reinterpret_cast<float4*>(F + 32 * hh + 4 * q) = o;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (far) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(F + 32 * mb + 8 * q + 4 * hh);
+                        st[mb][4 * q] += v.x; st[mb][4 * q + 1] += v.y; st[mb][4 * q + 2] += v.z; st[mb][4 * q + 3] += v.w;
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---- y^T[co][p] += W_k^T[co][ci] S^T[ci][p]: S^T's registers ARE the B operand (k-step s = registers 8*(s&1)..+7 of block s>>1) ----
+        const unsigned char* wb = Ws + (tap & 1) * WSB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4v sb;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) sb[d] = pk_bf16(st[s >> 1][8 * (s & 1) + 2 * d], st[s >> 1][8 * (s & 1) + 2 * d + 1]);
+            const bf16x8_t sf = __builtin_bit_cast(bf16x8_t, sb);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const u32x4v wv = *reinterpret_cast<const u32x4v*>(wb + (((s * 2 + hh) * 32 * NCB) + cb * 32 + nl) * 16);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), sf, acc[cb], 0, 0, 0);
+            }
+        }
+        // next tap's weights: the other buffer was last read in tap-1, a barrier ago
+        wstore((tap + 1) & 1);                // (after tap 8 this writes a buffer nobody reads: branch-free on purpose)
+        __syncthreads();
+        wload(tap < 7 ? tap + 2 : 8);
+    }
+
+    // ---- epilogue: lane = pixel, registers = 4 consecutive channels per (block, quad): bias, ReLU, 8-byte stores ----
+    float4 bv[NCB][4];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bv[cb][q] = g.bias ? *reinterpret_cast<const float4*>(g.bias + 32 * cb + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        bf16_t* yp = g.y + (img + (int64_t)gy * g.W + gx) * g.y_ld;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * cb + 8 * q + 4 * hh;
+                float v[4] = {acc[cb][4 * q] + bv[cb][q].x, acc[cb][4 * q + 1] + bv[cb][q].y, acc[cb][4 * q + 2] + bv[cb][q].z,
+                              acc[cb][4 * q + 3] + bv[cb][q].w};
+                if (g.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                uint2 o;
+                o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
+                *reinterpret_cast<uint2*>(yp + ch) = o;
+            }
+    }
+}
+
+// returns false when the shape is not handled here (caller falls back to the gather / LDS-tile kernels)
+bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
+                       int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr;
+    if (disabled || Ci != 64 || x_ld != 64 || om_ld != 32 || ((uintptr_t)om & 15) || (Co != 64 && Co != 32) || y_ld != Co || ktot != 9 * 64 || N > 65535) return false;
+    if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) return false;
+    if (bias && ((uintptr_t)bias & 15)) return false;
+    BmGeom g;
+    g.x = (const bf16_t*)x; g.om = om; g.wp = (const bf16_t*)wp; g.bias = bias; g.y = (bf16_t*)y;
+    g.N = N; g.H = H; g.W = W; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.Co = Co; g.relu = relu;
+    const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N);
+    if (Co == 64) {
+        const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 64 * 16) + 512;
+        (void)hipFuncSetAttribute((const void*)dcn_fwd_bm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_fwd_bm_kernel<2>, grid, dim3(256), smem, st, g);
+    } else {
+        const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 32 * 16) + 512;
+        (void)hipFuncSetAttribute((const void*)dcn_fwd_bm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_fwd_bm_kernel<1>, grid, dim3(256), smem, st, g);
+    }
+    return true;
+}

@@ -1,0 +1,53 @@
+"""Development check of the blend-matrix DCNv2 kernels (csrc/dcn_bm.hip): cn_dcn_fwd on random inputs at several offset scales
+(zero, sub-pixel, > 3 px = the far fallback) against oracle/dcn_ref.py on the CPU, plus an isolated timing at the bench shape.
+    python tools/dcn_bm_check.py            # uses whatever cn_dcn_fwd dispatches to (CN_DISABLE_DCN_BM=1: the gather kernel)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from centernet_amd import _hip, ops  # noqa: E402
+from oracle.dcn_ref import dcn_v2_conv  # noqa: E402
+
+DEV = "cuda"
+
+
+def check(N, H, W, Ci, Co, sigma, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).bfloat16().float()
+    bias = torch.randn(Co, generator=g) * 0.1
+    off = torch.randn(N, 18, H, W, generator=g) * sigma
+    ml = torch.randn(N, 9, H, W, generator=g)
+    ref = dcn_v2_conv(x, off, torch.sigmoid(ml), w, bias)
+    om = torch.zeros(N, H, W, 32)
+    om[..., :18] = off.permute(0, 2, 3, 1)
+    om[..., 18:27] = ml.permute(0, 2, 3, 1)
+    dt = torch.bfloat16
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    wp = ops.pack_weight(w.to(DEV), 1, dt)
+    y = torch.empty(N, H, W, Co, device=DEV, dtype=dt)
+    _hip.call("cn_dcn_fwd", xg, om.to(DEV), wp, bias.to(DEV), y, N, H, W, Ci, Ci, Co, Co, 32, 0, _hip.dtype_code(dt))
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    rms = ((got - ref) ** 2).mean().sqrt().item()
+    sc = ref.abs().max().item()
+    print(f"N{N} {H}x{W} {Ci}->{Co} sigma {sigma:4.1f}: max err {err:.4f} ({err / sc:.2e} of max {sc:.2f}), rms {rms:.5f} ({rms / ref.std().item():.2e} of std)", flush=True)
+    return err / sc
+
+
+if __name__ == "__main__":
+    print("CN_DISABLE_DCN_BM =", os.environ.get("CN_DISABLE_DCN_BM"))
+    worst = 0.0
+    for (N, H, W, Co) in [(2, 16, 32, 64), (1, 13, 21, 64), (1, 8, 16, 32)]:
+        for sigma in (0.0, 0.5, 1.5, 4.0):
+            worst = max(worst, check(N, H, W, 64, Co, sigma))
+    print("worst rel err", worst)
+    if len(sys.argv) > 1 and sys.argv[1] == "time":
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import opbench
+        os.environ["DCN_SHAPES"] = "1"
+        opbench.bench_dcn()
