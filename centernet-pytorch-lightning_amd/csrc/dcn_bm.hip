@@ -28,6 +28,14 @@
 #define BM_GR 12                         // window rows of one 4x8 group
 #define BM_PIXB 128                      // bytes per window pixel in LDS (64 bf16)
 
+#ifdef BM_PROBE   // development build only (tools/bm_probe.py): cycle stamps of wave 0 of the first workgroups
+__device__ unsigned long long bm_ts[1024 * 32];
+#define BM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) bm_ts[blockIdx.x * 32 + (k)] = clock64(); } while (0)
+extern "C" int bm_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bm_ts), sizeof(bm_ts)); }
+#else
+#define BM_STAMP(k) do { } while (0)
+#endif
+
 struct BmGeom {
     const bf16_t* x; const float* om; const bf16_t* wp; const float* bias; bf16_t* y;
     int N, H, W, x_ld, y_ld, om_ld, ktot, Co, relu;
@@ -63,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
         Lut[threadIdx.x] = sel;
     }
 
+    BM_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_w = (g.W + BM_TW - 1) / BM_TW;
     const int ty0 = (blockIdx.x / tiles_w) * BM_TH, tx0 = (blockIdx.x % tiles_w) * BM_TW;
@@ -94,43 +103,93 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
             *reinterpret_cast<u32x4v*>(Ws + buf * WSB + slot * 16) = u32x4v{wr_[i][0].x, wr_[i][0].y, wr_[i][1].x, wr_[i][1].y};
         }
     };
-    wload(0);
-
-    // ---- halo image of the tile: rows ty0-4 .. ty0+11, columns tx0-4 .. tx0+19, zeros outside the image ----
-    {
-        constexpr int NV = BM_WR * BM_WC * 8;     // 16-byte vectors
-#pragma unroll
-        for (int i = 0; i < NV / 256; ++i) {
-            const int v = tid + i * 256;
-            const int pix = v >> 3, q = v & 7;
-            const int wr = pix / BM_WC, wc = pix % BM_WC;
-            const int gy = ty0 - BM_MG + wr, gx = tx0 - BM_MG + wc;
-            const bool ok = (unsigned)gy < (unsigned)g.H && (unsigned)gx < (unsigned)g.W;
-            const uint4 val = ldg16_masked(X, (((int64_t)gy * g.W + gx) * g.x_ld + q * 8) * 2, ok);
-            st16(Xw + bm_lds_ofs(wr, wc, q * 8), val);
-        }
-    }
-    wstore(0);
-    __syncthreads();
     // ---- this wave's pixel group ----
     const int grow = (wave >> 1) * 4, gcol = (wave & 1) * 8;       // group origin inside the tile == its window origin in the halo image
     const int nl = lane & 31, hh = lane >> 5;
     const int gy = ty0 + grow + (nl >> 3), gx = tx0 + gcol + (nl & 7);
     const bool live = gy < g.H && gx < g.W;
+    // Issue order = the order the loads are needed in (they return in order): offsets / mask logits, the halo image, the first weight
+    // slice, the bias.
     // offsets / mask logits of the group's 32 pixels (om_ld == 32: one 128-byte row per pixel): four coalesced 16-byte loads per
-    // lane now, parked in the dead halo image after the fragment loads — the tap loop then has no global load on its critical path
-    // (a per-tap global prefetch made the compiler wait for the weight prefetch as well: vmcnt(0) at every loop top)
+    // lane, parked in an LDS table of the wave — the tap loop then has no global load on its critical path (a per-tap global
+    // prefetch made the compiler wait for the weight prefetch as well: vmcnt(0) at every loop top)
     float4 omr[4];
+    const int part = lane & 7;                      // which 4 of a pixel's 32 table entries this lane converts (the same for all four loads)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int idx = lane + 64 * i, p = idx >> 3, part = idx & 7;
+        const int p = (lane >> 3) + 8 * i;
         const int py_ = ty0 + grow + (p >> 3), px_ = tx0 + gcol + (p & 7);
         const bool ok = py_ < g.H && px_ < g.W;
         omr[i] = *reinterpret_cast<const float4*>(OM + ((int64_t)(ok ? py_ : 0) * g.W + (ok ? px_ : 0)) * 32 + part * 4);
     }
+    // halo image of the tile: rows ty0-4 .. ty0+11, columns tx0-4 .. tx0+19, zeros outside the image; all twelve loads in flight
+    constexpr int NV = BM_WR * BM_WC * 8 / 256;     // 16-byte vectors per thread
+    uint4 hv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        const int pix = v >> 3, q = v & 7;
+        const int wr = pix / BM_WC, wc = pix % BM_WC;
+        const int hy = ty0 - BM_MG + wr, hx = tx0 - BM_MG + wc;
+        const bool ok = (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
+        hv[i] = ldg16_masked(X, (((int64_t)hy * g.W + hx) * g.x_ld + q * 8) * 2, ok);
+    }
+    wload(0);
+    // the bias is the accumulators' initial value (lane = pixel, register v of block cb = channel 32 cb + 8 (v >> 2) + 4 hh + (v & 3))
+    f32x16_t acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 bv = *reinterpret_cast<const float4*>(g.bias + 32 * cb + 8 * q + 4 * hh);
+            acc[cb][4 * q] = bv.x; acc[cb][4 * q + 1] = bv.y; acc[cb][4 * q + 2] = bv.z; acc[cb][4 * q + 3] = bv.w;
+        }
+
+    // the table holds what a tap needs, finished: entry 2k / 2k+1 = sampling position of tap k RELATIVE TO THE GROUP'S WINDOW ORIGIN
+    // (pixel row + 3 + ky + dy: corner 00 of a zero offset sits in window row 3..8), entry 18+k = sigmoid(mask logit), 0 outside the image.
+    // Lanes with part >= 4 hold (mostly) mask logits, the others positions: one divergent branch for the transcendental work.
+    float* const Om = reinterpret_cast<float*>(Ws + 2 * WSB + 512) + wave * (32 * 29);      // [32 px][29]: odd pitch, conflict-free per-pixel reads
+    {
+        float tv[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = (lane >> 3) + 8 * i;
+            const float v4[4] = {omr[i].x, omr[i].y, omr[i].z, omr[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = part * 4 + j, k = e >> 1, k3 = (k * 11) >> 5;          // k / 3 for k < 9
+                tv[i][j] = v4[j] + (float)((e & 1) ? (p & 7) + 3 + (k - 3 * k3) : (p >> 3) + 3 + k3);
+            }
+        }
+        if (part >= 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = (lane >> 3) + 8 * i;
+                const bool ok = ty0 + grow + (p >> 3) < g.H && tx0 + gcol + (p & 7) < g.W;
+                const float v4[4] = {omr[i].x, omr[i].y, omr[i].z, omr[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (part * 4 + j >= 18) tv[i][j] = ok ? __builtin_amdgcn_rcpf(1.f + __expf(-v4[j])) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* d = Om + ((lane >> 3) + 8 * i) * 29 + part * 4;
+            if (part < 7) { d[0] = tv[i][0]; d[1] = tv[i][1]; d[2] = tv[i][2]; if (part < 6) d[3] = tv[i][3]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        const int pix = v >> 3, q = v & 7;
+        st16(Xw + bm_lds_ofs(pix / BM_WC, pix % BM_WC, q * 8), hv[i]);
+    }
+    wstore(0);
+    __syncthreads();
+    BM_STAMP(1);
     wload(1);
 
-    // ---- ... and its window fragments ----
+    // ---- the group's window fragments ----
     bf16x8_t xf[BM_GR][2];
     {
         const int r16 = lane & 15, g16 = lane >> 4;
@@ -150,43 +209,29 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
                 xf[r][mb] = __builtin_bit_cast(bf16x8_t, v);
             }
     }
-
-    __syncthreads();        // every wave holds its fragments: the halo image is dead (re-used as far-sample scratch, 8 KB per wave,
-                            // and from byte 32768 on as the waves' offset tables: [32 px][29] floats each)
-    float* const Om = reinterpret_cast<float*>(Xw + 32768 + wave * (32 * 29 * 4));     // odd pitch: conflict-free per-pixel reads
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = lane + 64 * i, p = idx >> 3, part = idx & 7;
-        float* d = Om + p * 29 + part * 4;
-        if (part < 7) { d[0] = omr[i].x; d[1] = omr[i].y; d[2] = omr[i].z; if (part < 6) d[3] = omr[i].w; }
-    }
-    __builtin_amdgcn_wave_barrier();
     const float* const orow = Om + nl * 29;
     float ro[3] = {orow[0], orow[1], orow[18]};
-
-    f32x16_t acc[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    BM_STAMP(2);
+    __syncthreads();        // every wave holds its fragments: the halo image is dead (re-used as far-sample scratch, 8 KB per wave)
 
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
         const int ky = tap / 3, kx = tap - 3 * ky;
+        BM_STAMP(4 + 3 * tap);
         // ---- geometry of (own pixel, tap): window position of corner 00 and the two packed weight pairs ----
-        const float py = (float)(gy - 1 + ky) + ro[0], px = (float)(gx - 1 + kx) + ro[1];
-        const float m = live ? __builtin_amdgcn_rcpf(1.f + __expf(-ro[2])) : 0.f;      // sigmoid; the product is rounded to bf16 anyway
-        {   // next tap's offsets / mask logit (LDS table)
+        // (no image-border tests here: the halo image holds zeros outside the image; only the far path below needs them)
+        const float pyr = ro[0], pxr = ro[1], m = ro[2];
+        {   // next tap's entries of the LDS table
             const int nt = tap < 8 ? tap + 1 : 8;
             ro[0] = orow[2 * nt]; ro[1] = orow[2 * nt + 1]; ro[2] = orow[18 + nt];
         }
-        const Tap t = make_tap(py, px, g.H, g.W);
-        const float w00 = t.w00 * m, w01 = t.w01 * m, w10 = t.w10 * m, w11 = t.w11 * m;
-        const bool anyw = (w00 != 0.f) | (w01 != 0.f) | (w10 != 0.f) | (w11 != 0.f);
-        const int wr = t.h0 - (ty0 + grow - BM_MG), wc = t.w0 - (tx0 + gcol - BM_MG);  // window coordinates of corner 00
+        const float fy = floorf(pyr), fx = floorf(pxr);
+        const int wr = (int)fy, wc = (int)fx;                                           // window coordinates of corner 00
+        const float ly = pyr - fy, lx = pxr - fx;
+        const float wa = (1.f - ly) * m, wbt = ly * m;
         const bool inwin = (unsigned)wr <= (unsigned)(BM_GR - 2) && (unsigned)wc <= 14u;
-        const bool far = anyw && !inwin;
-        const uint32_t P0 = (anyw && inwin) ? pk_bf16(w00, w01) : 0u, P1 = (anyw && inwin) ? pk_bf16(w10, w11) : 0u;
+        const bool far = !inwin && m != 0.f;
+        const uint32_t P0 = inwin ? pk_bf16(wa * (1.f - lx), wa * lx) : 0u, P1 = inwin ? pk_bf16(wbt * (1.f - lx), wbt * lx) : 0u;
         const int wr_top = (P0 != 0u) ? wr : -1, wr_bot = (P1 != 0u) ? wr + 1 : -1;
         // 8-element (4-dword) images of the two weight pairs for this lane's column half: pair element a sits at column wc
         const u32x4v sel = Lut[min(max(wc - 8 * hh + 8, 0), 22)];
@@ -205,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
         const uint32_t rowmask = (uint32_t)__builtin_amdgcn_readlane((int)rows, 0) | (uint32_t)__builtin_amdgcn_readlane((int)rows, 16) |
                                  (uint32_t)__builtin_amdgcn_readlane((int)rows, 32) | (uint32_t)__builtin_amdgcn_readlane((int)rows, 48);
 
+        BM_STAMP(5 + 3 * tap);
         // ---- S^T[ci][p] = sum over the touched window rows (K = the row's 16 source columns) ----
         f32x16_t st[2];
 #pragma unroll
@@ -230,8 +276,13 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
         if (__builtin_amdgcn_ballot_w64(far) != 0) {
             float* const F = reinterpret_cast<float*>(Xw + wave * (32 * 64 * 4)) + nl * 64;
             if (far) {
-                const int hc0 = min(max(t.h0, 0), g.H - 1), hc1 = min(max(t.h0 + 1, 0), g.H - 1);
-                const int wc0 = min(max(t.w0, 0), g.W - 1), wc1 = min(max(t.w0 + 1, 0), g.W - 1);
+                const int h0 = wr + (ty0 + grow - BM_MG), w0 = wc + (tx0 + gcol - BM_MG);
+                const bool h0ok = (unsigned)h0 < (unsigned)g.H, h1ok = (unsigned)(h0 + 1) < (unsigned)g.H;
+                const bool w0ok = (unsigned)w0 < (unsigned)g.W, w1ok = (unsigned)(w0 + 1) < (unsigned)g.W;
+                const float w00 = (h0ok && w0ok) ? wa * (1.f - lx) : 0.f, w01 = (h0ok && w1ok) ? wa * lx : 0.f;
+                const float w10 = (h1ok && w0ok) ? wbt * (1.f - lx) : 0.f, w11 = (h1ok && w1ok) ? wbt * lx : 0.f;
+                const int hc0 = min(max(h0, 0), g.H - 1), hc1 = min(max(h0 + 1, 0), g.H - 1);
+                const int wc0 = min(max(w0, 0), g.W - 1), wc1 = min(max(w0 + 1, 0), g.W - 1);
                 const bf16_t* p00 = X + ((int64_t)hc0 * g.W + wc0) * g.x_ld + 32 * hh;
                 const bf16_t* p01 = X + ((int64_t)hc0 * g.W + wc1) * g.x_ld + 32 * hh;
                 const bf16_t* p10 = X + ((int64_t)hc1 * g.W + wc0) * g.x_ld + 32 * hh;
@@ -261,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
             __builtin_amdgcn_wave_barrier();
         }
 
+        BM_STAMP(6 + 3 * tap);
         // ---- y^T[co][p] += W_k^T[co][ci] S^T[ci][p]: S^T's registers ARE the B operand (k-step s = registers 8*(s&1)..+7 of block s>>1) ----
         const unsigned char* wb = Ws + (tap & 1) * WSB;
 #pragma unroll
@@ -281,50 +333,54 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
         wload(tap < 7 ? tap + 2 : 8);
     }
 
-    // ---- epilogue: lane = pixel, registers = 4 consecutive channels per (block, quad): bias, ReLU, 8-byte stores ----
-    float4 bv[NCB][4];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            bv[cb][q] = g.bias ? *reinterpret_cast<const float4*>(g.bias + 32 * cb + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
-        bf16_t* yp = g.y + (img + (int64_t)gy * g.W + gx) * g.y_ld;
+    BM_STAMP(3);
+    // ---- epilogue: lane = pixel, registers = 4 consecutive channels per (block, quad): ReLU, 8-byte stores (the bias was the initial value) ----
+    // ... through the wave's slice of the dead halo image ([32 px][72] bf16), so that a pixel's 128 bytes leave as eight 16-byte lanes
+    {
+        unsigned char* const Y = Xw + wave * 8192;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ch = 32 * cb + 8 * q + 4 * hh;
-                float v[4] = {acc[cb][4 * q] + bv[cb][q].x, acc[cb][4 * q + 1] + bv[cb][q].y, acc[cb][4 * q + 2] + bv[cb][q].z,
-                              acc[cb][4 * q + 3] + bv[cb][q].w};
+                float v[4] = {acc[cb][4 * q], acc[cb][4 * q + 1], acc[cb][4 * q + 2], acc[cb][4 * q + 3]};
                 if (g.relu) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 uint2 o;
                 o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
-                *reinterpret_cast<uint2*>(yp + ch) = o;
+                *reinterpret_cast<uint2*>(Y + nl * 144 + (32 * cb + 8 * q + 4 * hh) * 2) = o;
             }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CPP = 4 * NCB;                 // 16-byte chunks per pixel
+#pragma unroll
+        for (int i = 0; i < 32 * CPP / 64; ++i) {
+            const int idx = lane + 64 * i, p = idx / CPP, ch = idx % CPP;
+            const int oy = ty0 + grow + (p >> 3), ox = tx0 + gcol + (p & 7);
+            const u32x4v o = *reinterpret_cast<const u32x4v*>(Y + p * 144 + ch * 16);
+            if (oy < g.H && ox < g.W) *reinterpret_cast<u32x4v*>(g.y + (img + (int64_t)oy * g.W + ox) * g.y_ld + ch * 8) = o;
+        }
     }
+    BM_STAMP(31);
 }
 
 // returns false when the shape is not handled here (caller falls back to the gather / LDS-tile kernels)
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
                        int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr;
-    if (disabled || Ci != 64 || x_ld != 64 || om_ld != 32 || ((uintptr_t)om & 15) || (Co != 64 && Co != 32) || y_ld != Co || ktot != 9 * 64 || N > 65535) return false;
+    if (disabled || bias == nullptr || Ci != 64 || x_ld != 64 || om_ld != 32 || ((uintptr_t)om & 15) || (Co != 64 && Co != 32) || y_ld != Co || ktot != 9 * 64 || N > 65535) return false;
     if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) return false;
-    if (bias && ((uintptr_t)bias & 15)) return false;
+    if ((uintptr_t)bias & 15) return false;
     BmGeom g;
     g.x = (const bf16_t*)x; g.om = om; g.wp = (const bf16_t*)wp; g.bias = bias; g.y = (bf16_t*)y;
     g.N = N; g.H = H; g.W = W; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.Co = Co; g.relu = relu;
     const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N);
     if (Co == 64) {
-        const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 64 * 16) + 512;
+        const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 64 * 16) + 512 + 4 * 32 * 29 * 4;
         (void)hipFuncSetAttribute((const void*)dcn_fwd_bm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(dcn_fwd_bm_kernel<2>, grid, dim3(256), smem, st, g);
     } else {
-        const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 32 * 16) + 512;
+        const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 32 * 16) + 512 + 4 * 32 * 29 * 4;
         (void)hipFuncSetAttribute((const void*)dcn_fwd_bm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(dcn_fwd_bm_kernel<1>, grid, dim3(256), smem, st, g);
     }
