@@ -613,6 +613,10 @@ extern "C" int cn_dcn_bwd_dx(const void* dy, const void* wpd0, const float* om, 
     if (Ci % 32 != 0 || dy_ld % 16 != 0) CN_UNSUPPORTED("cn_dcn_bwd_dx: Ci=%d must be a multiple of 32, dy_ld=%d of 16", Ci, dy_ld);
     if (N > 65535) CN_UNSUPPORTED("cn_dcn_bwd_dx: batch %d", N);
     if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_dcn_bwd_dx: bad dtype %d", dtype);
+    if (dtype == CN_BF16 && dcn_dx_bm_launch(dy, wpd0, om, dx_far, far_flag, dx, N, H, W, Ci, dy_ld, om_ld, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_dcn_bwd_dx(bm)");
+        return CN_OK;
+    }
     ConvGeom g;
     memset(&g, 0, sizeof(g));
     g.x = dy; g.w = wpd0; g.y = dx;

@@ -386,3 +386,283 @@ bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const flo
     }
     return true;
 }
+
+
+// ================================================================================================ data gradient
+// dx[q][ci] = sum_k sum_co W_k[co][ci] * G_k[q][co],   G_k[q][co] = sum_p Bm_k[p][q] * dY[p][co]        (adjoint of the sampling)
+// Same skeleton with the roles turned round: a wave owns a 4x8 group of DESTINATION pixels q and keeps the dY window of every
+// source p that may reach them (|q - p| <= 3 in both directions, the rule cn_dcn_bwd_dom uses for its dx_far scatter) as
+// transposed fragments in registers.  The blend matrix of a tap is wanted with lane = destination, elements = sources, but is
+// KNOWN per source (the offsets belong to p): per tap the 12x16 window is walked in three passes of 64 sources (one per lane);
+// a lane computes its source's four corners and drops the bf16 weights of those that land in the group into a small LDS tile
+// T[32 q][64 p] (zeroed per pass), which is read back row-wise — no transposition, no hit lists, no list walk, no atomics — as
+// the B operand of G^T[co][q] += dY^T[co][p-row] * T^T.  G^T's registers are again the B operand of the contraction
+// dx^T[ci][q] += W_k[.][ci]^T G^T.  The cost no longer depends on the offset field: the adjoint-gather kernel (dcn_fused.hip)
+// takes 541 us with zero offsets and 955 us with N(0, 0.5 px) offsets on 64->64 @128^2 (one hit per destination and tap vs four).
+// The source geometry of all nine taps (tile-relative sampling position, sigmoid(mask)) is computed once per tile into an LDS
+// table that re-uses the halo image once the fragments are loaded.
+struct DxBmGeom {
+    const bf16_t* dy; const float* om; const bf16_t* wp; float* far; int* far_flag; bf16_t* dx;
+    int N, H, W, dx_ld, ktot;
+};
+
+#define DXB_TR 14                         // table rows / cols: sources within 3 px of the tile
+#define DXB_TC 22
+#define DXB_TBYTES 33280                  // 14 * 22 * 27 floats = 33264, rounded up to 16
+#define DXB_TP 144                        // byte pitch of a T row (64 sources x bf16 + 16: conflict-free 16-byte row reads)
+
+template <int NCB>   // 32-channel blocks of dx (Ci = 32 * NCB); dY has 64 channels
+__global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Yw = smem;                                   // halo image of dY [16][24] x 128 B; later: geometry table | T tiles
+    float* const Tab = reinterpret_cast<float*>(smem);                // [14*22 sources][27]
+    unsigned char* const Tt = smem + DXB_TBYTES;                      // 4 waves x [32 q][DXB_TP]
+    unsigned char* const Ws = smem + DXB_TBYTES + 4 * 32 * DXB_TP;    // 2 weight buffers (behind the halo image: 51712 > 49152)
+    constexpr int WSB = 4 * 2 * 32 * NCB * 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_w = (g.W + BM_TW - 1) / BM_TW;
+    const int ty0 = (blockIdx.x / tiles_w) * BM_TH, tx0 = (blockIdx.x % tiles_w) * BM_TW;
+    const int n = blockIdx.y;
+    const int64_t img = (int64_t)n * g.H * g.W;
+    const bf16_t* __restrict__ DY = g.dy + img * 64;
+    const float* __restrict__ OM = g.om + img * 32;
+
+    constexpr int WSLOTS = 4 * 2 * 32 * NCB;
+    constexpr int WPT = (WSLOTS + 255) / 256;
+    uint2 wr_[WPT][2];
+    auto wload = [&](int tap) {          // wp = mode-0 pack [ci][tap*64 + co]: rows = this kernel's output channels
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int slot = tid + i * 256;
+            const int ci = slot % (32 * NCB), sh = slot / (32 * NCB), h = sh & 1, s = sh >> 1;
+            const int c0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * h;
+            const bf16_t* p = g.wp + (int64_t)ci * g.ktot + tap * 64 + c0;
+            wr_[i][0] = *reinterpret_cast<const uint2*>(p);
+            wr_[i][1] = *reinterpret_cast<const uint2*>(p + 8);
+        }
+    };
+    auto wstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int slot = tid + i * 256;
+            *reinterpret_cast<u32x4v*>(Ws + buf * WSB + slot * 16) = u32x4v{wr_[i][0].x, wr_[i][0].y, wr_[i][1].x, wr_[i][1].y};
+        }
+    };
+
+    const int grow = (wave >> 1) * 4, gcol = (wave & 1) * 8;
+    const int nl = lane & 31, hh = lane >> 5;
+    const int gy = ty0 + grow + (nl >> 3), gx = tx0 + gcol + (nl & 7);
+    const bool live = gy < g.H && gx < g.W;
+
+    // ---- loads, in the order they are needed: halo image of dY, first weight slice, offsets / masks of the 14x22 sources ----
+    constexpr int NV = BM_WR * BM_WC * 8 / 256;
+    uint4 hv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        const int pix = v >> 3, q = v & 7;
+        const int hy = ty0 - BM_MG + pix / BM_WC, hx = tx0 - BM_MG + pix % BM_WC;
+        const bool ok = (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
+        hv[i] = ldg16_masked(DY, (((int64_t)hy * g.W + hx) * 64 + q * 8) * 2, ok);
+    }
+    wload(0);
+    constexpr int NSRC = DXB_TR * DXB_TC, NOM = (NSRC + 31) / 32;     // 308 sources, 32 per pass: thread = (source, 16-byte part)
+    const int part = tid & 7;
+    float4 omr[NOM];
+#pragma unroll
+    for (int i = 0; i < NOM; ++i) {
+        const int src = (tid >> 3) + 32 * i;
+        const int sy = ty0 - 3 + src / DXB_TC, sx = tx0 - 3 + src % DXB_TC;
+        const bool ok = src < NSRC && (unsigned)sy < (unsigned)g.H && (unsigned)sx < (unsigned)g.W && part < 7;
+        omr[i] = *reinterpret_cast<const float4*>(OM + ((int64_t)(ok ? sy : 0) * g.W + (ok ? sx : 0)) * 32 + (part < 7 ? part : 0) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256;
+        const int pix = v >> 3, q = v & 7;
+        st16(Yw + bm_lds_ofs(pix / BM_WC, pix % BM_WC, q * 8), hv[i]);
+    }
+    __syncthreads();
+
+    // ---- the group's dY window as transposed fragments (rows = co) ----
+    bf16x8_t yf[BM_GR][2];
+    {
+        const int r16 = lane & 15, g16 = lane >> 4;
+        typedef __attribute__((address_space(3))) s16x4_t_* lds_ptr;
+        const int wc0 = gcol + 8 * (g16 >> 1) + (r16 >> 2);
+        const unsigned char* const b0 = Yw + bm_lds_ofs(grow, wc0, 16 * (g16 & 1) + 4 * (r16 & 3));
+        const unsigned char* const b1 = Yw + bm_lds_ofs(grow, wc0, 32 + 16 * (g16 & 1) + 4 * (r16 & 3));
+#pragma unroll
+        for (int r = 0; r < BM_GR; ++r)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const unsigned char* p = (mb ? b1 : b0) + r * (BM_WC * BM_PIXB);
+                const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+                const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * BM_PIXB));
+                const s16x8_t_ v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                yf[r][mb] = __builtin_bit_cast(bf16x8_t, v);
+            }
+    }
+    __syncthreads();        // the halo image is dead: geometry table + T tiles + first weight slice go in
+
+    // table entry 2k / 2k+1 of a source: sampling position of tap k relative to the TILE origin (row - ty0 - 1 + ky + dy),
+    // entry 18+k: sigmoid(mask logit), 0 for sources outside the image
+#pragma unroll
+    for (int i = 0; i < NOM; ++i) {
+        const int src = (tid >> 3) + 32 * i;
+        const int sr = src / DXB_TC - 3, sc = src % DXB_TC - 3;               // tile-relative source coordinates
+        const bool inimg = (unsigned)(ty0 + sr) < (unsigned)g.H && (unsigned)(tx0 + sc) < (unsigned)g.W;
+        const float v4[4] = {omr[i].x, omr[i].y, omr[i].z, omr[i].w};
+        float* d = Tab + src * 27 + part * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = part * 4 + j, k = e >> 1, k3 = (k * 11) >> 5;
+            float val = v4[j] + (float)((e & 1) ? sc - 1 + (k - 3 * k3) : sr - 1 + k3);
+            if (part >= 4 && e >= 18) val = inimg ? __builtin_amdgcn_rcpf(1.f + __expf(-v4[j])) : 0.f;
+            if (src < NSRC && e < 27) d[j] = val;
+        }
+    }
+    wstore(0);
+    wload(1);
+    __syncthreads();
+
+    f32x16_t acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+
+    unsigned char* const T = Tt + wave * (32 * DXB_TP);
+    // this lane's source in pass j: group-window row 4j + (lane >> 4), column lane & 15 (window origin = group origin - 4)
+    const int s_col = lane & 15, s_row0 = lane >> 4;
+    const bool col_ok = s_col >= 1 && s_col <= 14;                           // |q - p| <= 3 needs window columns 1..14
+    const int tcol = gcol + s_col - 1;                                       // table column (tile-window column - 1)
+
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        f32x16_t st[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
+        asm volatile("" : "+v"(st[0]), "+v"(st[1]));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // ---- zero the T tile (4608 B), then every source lane drops its corners' weights ----
+#pragma unroll
+            for (int z = 0; z < 5; ++z)
+                if (z < 4 || lane < 32) *reinterpret_cast<u32x4v*>(T + (lane + 64 * z) * 16) = u32x4v{0u, 0u, 0u, 0u};
+            __builtin_amdgcn_wave_barrier();
+            const int s_row = 4 * j + s_row0;                                // group-window row of the source
+            const bool src_ok = col_ok && s_row >= 1 && s_row <= 10;
+            const float* te = Tab + ((grow + s_row - 1) * DXB_TC + tcol) * 27;
+            bool any = false;
+            if (src_ok) {
+                const float pyt = te[2 * tap], pxt = te[2 * tap + 1], m = te[18 + tap];
+                const float fy = floorf(pyt), fx = floorf(pxt);
+                const int y0 = (int)fy - grow, x0 = (int)fx - gcol;           // destination of corner 00, group-local
+                const float ly = pyt - fy, lx = pxt - fx;
+                const float wy[2] = {(1.f - ly) * m, ly * m}, wx[2] = {1.f - lx, lx};
+                const int sy_l = s_row - 4, sx_l = s_col - 4;                 // the source itself, group-local
+#pragma unroll
+                for (int cnr = 0; cnr < 4; ++cnr) {
+                    const int qy = y0 + (cnr >> 1), qx = x0 + (cnr & 1);
+                    const float w = wy[cnr >> 1] * wx[cnr & 1];
+                    const int ddy = qy - sy_l, ddx = qx - sx_l;
+                    const bool hit = (unsigned)qy < 4u && (unsigned)qx < 8u && ddy >= -3 && ddy <= 3 && ddx >= -3 && ddx <= 3 && w > 0.f;
+                    if (hit) {
+                        *reinterpret_cast<bf16_t*>(T + (qy * 8 + qx) * DXB_TP + lane * 2) = f2bf(w);
+                        any = true;
+                    }
+                }
+            }
+            const uint64_t hits = __builtin_amdgcn_ballot_w64(any);
+            __builtin_amdgcn_wave_barrier();
+            // ---- G^T[co][q] += dY^T[co][window row] * T^T   (one MFMA pair per window row that has a hit) ----
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                if (!(hits & (0xFFFFull << (16 * rr)))) continue;
+                const u32x4v b = *reinterpret_cast<const u32x4v*>(T + nl * DXB_TP + (rr * 16 + hh * 8) * 2);
+                const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[4 * j + rr][0], bf, st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[4 * j + rr][1], bf, st[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- dx^T[ci][q] += W_k[.][ci]^T G^T[.][q] ----
+        const unsigned char* wb = Ws + (tap & 1) * WSB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            u32x4v sb;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) sb[d] = pk_bf16(st[s >> 1][8 * (s & 1) + 2 * d], st[s >> 1][8 * (s & 1) + 2 * d + 1]);
+            const bf16x8_t sf = __builtin_bit_cast(bf16x8_t, sb);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const u32x4v wv = *reinterpret_cast<const u32x4v*>(wb + (((s * 2 + hh) * 32 * NCB) + cb * 32 + nl) * 16);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), sf, acc[cb], 0, 0, 0);
+            }
+        }
+        wstore((tap + 1) & 1);
+        __syncthreads();
+        wload(tap < 7 ? tap + 2 : 8);
+    }
+
+    // ---- epilogue: + dx_far (lazy protocol of cn_dcn_bwd_dx: added and restored to zero only when a dom kernel flagged far
+    //      samples), bf16 through the wave's T tile, 16-byte coalesced stores ----
+    const bool use_far = g.far != nullptr && (g.far_flag == nullptr || *g.far_flag != 0);
+    if (use_far && live) {
+        float* fp = g.far + (img + (int64_t)gy * g.W + gx) * (32 * NCB);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4* f4 = reinterpret_cast<float4*>(fp + 32 * cb + 8 * q + 4 * hh);
+                const float4 v = *f4;
+                acc[cb][4 * q] += v.x; acc[cb][4 * q + 1] += v.y; acc[cb][4 * q + 2] += v.z; acc[cb][4 * q + 3] += v.w;
+                if (g.far_flag) *f4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
+    {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 o;
+                o.x = pk_bf16(acc[cb][4 * q], acc[cb][4 * q + 1]); o.y = pk_bf16(acc[cb][4 * q + 2], acc[cb][4 * q + 3]);
+                *reinterpret_cast<uint2*>(T + nl * DXB_TP + (32 * cb + 8 * q + 4 * hh) * 2) = o;
+            }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CPP = 4 * NCB;
+#pragma unroll
+        for (int i = 0; i < 32 * CPP / 64; ++i) {
+            const int idx = lane + 64 * i, p = idx / CPP, ch = idx % CPP;
+            const int oy = ty0 + grow + (p >> 3), ox = tx0 + gcol + (p & 7);
+            const u32x4v o = *reinterpret_cast<const u32x4v*>(T + p * DXB_TP + ch * 16);
+            if (oy < g.H && ox < g.W) *reinterpret_cast<u32x4v*>(g.dx + (img + (int64_t)oy * g.W + ox) * g.dx_ld + ch * 8) = o;
+        }
+    }
+}
+
+// returns false when the shape is not handled here (caller falls back to the adjoint-gather kernel)
+bool dcn_dx_bm_launch(const void* dy, const void* wpd0, const float* om, float* far, int* far_flag, void* dx, int N, int H, int W, int Ci,
+                      int dy_ld, int om_ld, hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_DX_BM") != nullptr;
+    if (disabled || dy_ld != 64 || (Ci != 64 && Ci != 32) || om_ld != 32 || N > 65535) return false;
+    if (((uintptr_t)dy | (uintptr_t)wpd0 | (uintptr_t)dx | (uintptr_t)om | (uintptr_t)far) & 15) return false;
+    DxBmGeom g;
+    g.dy = (const bf16_t*)dy; g.om = om; g.wp = (const bf16_t*)wpd0; g.far = far; g.far_flag = far_flag; g.dx = (bf16_t*)dx;
+    g.N = N; g.H = H; g.W = W; g.dx_ld = Ci; g.ktot = 9 * 64;
+    const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N);
+    if (Ci == 64) {
+        const size_t smem = DXB_TBYTES + 4 * 32 * DXB_TP + 2 * (4 * 2 * 64 * 16);
+        (void)hipFuncSetAttribute((const void*)dcn_dx_bm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_dx_bm_kernel<2>, grid, dim3(256), smem, st, g);
+    } else {
+        const size_t smem = DXB_TBYTES + 4 * 32 * DXB_TP + 2 * (4 * 2 * 32 * 16);
+        (void)hipFuncSetAttribute((const void*)dcn_dx_bm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_dx_bm_kernel<1>, grid, dim3(256), smem, st, g);
+    }
+    return true;
+}

@@ -39,6 +39,42 @@ def check(N, H, W, Ci, Co, sigma, seed=0):
     return err / sc
 
 
+def check_dx(N, H, W, Ci, Co, sigma, seed=0):
+    """sampling-path data gradient (offsets held constant) through cn_dcn_bwd_dom (far samples) + cn_dcn_bwd_dx vs autograd of the oracle"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float().requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).bfloat16().float()
+    off = torch.randn(N, 18, H, W, generator=g) * sigma
+    ml = torch.randn(N, 9, H, W, generator=g)
+    gy = torch.randn(N, Co, H, W, generator=g).bfloat16().float()
+    dcn_v2_conv(x, off, torch.sigmoid(ml), w, None).backward(gy)
+    ref = x.grad
+    om = torch.zeros(N, H, W, 32)
+    om[..., :18] = off.permute(0, 2, 3, 1)
+    om[..., 18:27] = ml.permute(0, 2, 3, 1)
+    dt = torch.bfloat16
+    code = _hip.dtype_code(dt)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    dy = gy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    omg = om.to(DEV)
+    wd = w.to(DEV)
+    far = torch.zeros(N, H, W, Ci, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    slabs = _hip.query("cn_dcn_bwd_dom_slabs", Ci, Co, code)
+    dom = torch.zeros(max(slabs, 1), N, H, W, 32, device=DEV)
+    _hip.call("cn_dcn_bwd_dom", dy, ops.pack_weight(wd, 2, dt), xg, omg, dom, slabs, far, flag, N, H, W, Ci, Co, Co, Ci, 32, code)
+    dx = torch.empty(N, H, W, Ci, device=DEV, dtype=dt)
+    _hip.call("cn_dcn_bwd_dx", dy, ops.pack_weight(wd, 0, dt), omg, far, flag, dx, N, H, W, Ci, Co, 32, code)
+    torch.cuda.synchronize()
+    got = dx.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    rms = ((got - ref) ** 2).mean().sqrt().item()
+    sc = ref.abs().max().item()
+    assert float(far.abs().max()) == 0.0, "dx_far must be left clean"
+    print(f"dx  N{N} {H}x{W} {Ci}<-{Co} sigma {sigma:4.1f}: max err {err:.4f} ({err / sc:.2e} of max {sc:.2f}), rms {rms:.5f} ({rms / ref.std().item():.2e} of std), far flag {int(flag.item())}", flush=True)
+    return err / sc
+
+
 if __name__ == "__main__":
     print("CN_DISABLE_DCN_BM =", os.environ.get("CN_DISABLE_DCN_BM"))
     worst = 0.0
@@ -46,6 +82,11 @@ if __name__ == "__main__":
         for sigma in (0.0, 0.5, 1.5, 4.0):
             worst = max(worst, check(N, H, W, 64, Co, sigma))
     print("worst rel err", worst)
+    worst = 0.0
+    for (N, H, W, Ci) in [(2, 16, 32, 64), (1, 13, 21, 64), (1, 8, 16, 32)]:
+        for sigma in (0.0, 0.5, 1.5, 4.0):
+            worst = max(worst, check_dx(N, H, W, Ci, 64, sigma))
+    print("worst rel err dx", worst)
     if len(sys.argv) > 1 and sys.argv[1] == "time":
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import opbench
