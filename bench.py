@@ -112,18 +112,24 @@ def _kernel_name(hip, name, a, tn):
                 return f"conv3x3s1_kernel<{tn},128,64,8>"
             return f"conv3x3s1_kernel<{tn},{(v - 3000000) // 1000},{v % 1000}>"
         return f"conv_igemm_kernel<{tn},{v // 1000},{v % 1000}>"
-    blk = lambda c: 128 if c % 128 == 0 else (64 if c % 64 == 0 else 32)
-    if name == "cn_dcn_bwd_dx":
-        N, H, W, Ci, dy_ld = a[:5]
-        return f"dcn_bwd_dx_kernel<{tn},{blk(Ci)},{64 if dy_ld % 64 == 0 else (32 if dy_ld % 32 == 0 else 16)}>"
-    if name == "cn_dcn_bwd_dom":
-        return f"dcn_bwd_dom_kernel<{a[6] if a[6] in (64, 128) else 'generic'}>"       # COP = dy_ld
-    if name == "cn_dcn_fwd":
-        N, H, W, Ci, x_ld, Co = a[:6]
-        return f"dcn_fwd[{Ci}->{Co}]"            # gather kernel or LDS-tile kernel by shape (csrc/dcn.hip)
-    if name == "cn_dcn_wgrad":
-        N, H, W, Ci, x_ld, Co = a[:6]
-        return f"dcn_wgrad_kernel[{Ci}->{Co}]"
+    # the four DCNv2 entry points: ask the library which template it dispatches to (cn_dcn_variant mirrors the launch functions), so
+    # that the rows group exactly like rocprofv3's kernel names
+    dcn = {"cn_dcn_fwd": (0, lambda a: (a[3], a[5])), "cn_dcn_wgrad": (1, lambda a: (a[3], a[5])),
+           "cn_dcn_bwd_dom": (2, lambda a: (a[4], a[6])), "cn_dcn_bwd_dx": (3, lambda a: (a[3], a[4]))}
+    if name in dcn and tn == "bf16":
+        entry, pick = dcn[name]
+        Ci, Co = pick(a)
+        v = hip.lib().cn_dcn_variant(entry, int(Ci), int(Co))
+        if entry == 0:
+            return (f"dcn_fwd_bm_kernel<{v - 1000000}>" if v < 2000000 else f"dcn_fwd_tile_kernel<{v - 2000000}>" if v < 3000000
+                    else f"dcn_fwd_kernel<bf16,{(v - 3000000) // 1000},{v % 1000}>")
+        if entry == 1:
+            return f"dcn_wgrad_kernel<{v // 1000000},{v // 1000 % 1000},{v % 1000}>"
+        if entry == 2:
+            return f"dcn_bwd_dom_kernel<{v}>" if v else "conv_igemm_kernel<dom epilogue>"
+        return f"dcn_dx_bm_kernel<{v - 1000000}>" if v < 2000000 else f"dcn_bwd_dx_kernel<bf16,{(v - 3000000) // 1000},{v % 1000}>"
+    if name in dcn:
+        return name + "[f32]"
     if name == "cn_conv2d_wgrad":
         N, H, W, Ci, x_ld, OH, OW, Co, ld, KH, KW, stride = a[:12]
         return f"conv_wgrad[{KH}x{KW}s{stride} {Ci}->{Co}]"
@@ -252,10 +258,25 @@ def inference_rate(model, x, steps=20):
     return dt
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The oracle (torch-CPU restatement of the reference path: same op sequence, pure-torch DCNv2) on the host cores:
-    DLA-34 ctdet train step + decode, fp32, batch 2, 512x512.  Threads are capped at 16: on the 256-thread GPU host
-    torch's intra-op pool gets SLOWER beyond that (measured: 16 threads 0.5 s, 128 threads 11.9 s for the same step)."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(full=False):
+    """the oracle (torch-CPU restatement of the reference path: same op sequence and state_dict, pure-torch
+    DCNv2) on the host cores of the GPU box, fp32, DLA-34 ctdet, 512x512: (a) train step (fwd+loss+bwd+Adam) + ctdet_decode and
+    (b) forward + ctdet_decode, batch 2 and 8, 3 warm-ups, median images/s.  The default run is BOUNDED (about 30 s of CPU work: 5
+    timed iterations at batch 2, 2 at batch 8); --cpu-baseline-full runs >= 5 everywhere and adds ResNet-18.  `value` is leg (a) at
+    batch 2 (the reference's own CPU-runnable configuration, BASELINE.json configs[0] shape).  Threads are capped at 16: on the
+    256-thread GPU host torch's intra-op pool gets SLOWER beyond that (measured: 16 threads 0.5 s, 128 threads 11.9 s per step)."""
+    import statistics
     from centernet_amd import rng, synth
     from oracle import models_ref, ops_ref
     try:
@@ -264,33 +285,83 @@ def cpu_baseline(seconds_budget=20.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
-    m = models_ref.CenterNetRef("dla_34")
-    rng.fill_state_dict(m, 1234)
-    m.train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
-    x, tgt = synth.ctdet_batch(1234, 2)
+    legs, t_all = {}, time.time()
 
-    def one():
-        opt.zero_grad()
-        out = m(x)
-        loss, _ = m.loss(out, tgt)
-        loss.backward()
-        opt.step()
-        with torch.no_grad():
-            ops_ref.ctdet_decode(ops_ref.sigmoid_clamped(out[0]["heatmap"]), out[0]["width_height"], out[0]["regression"])
+    def run(arch, bs, train, n_timed, warm=3):
+        m = models_ref.CenterNetRef(arch)
+        rng.fill_state_dict(m, 1234)
+        m.train(train)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        x, tgt = synth.ctdet_batch(1234, bs)
 
-    t0 = time.time()
-    one()                                   # warm-up (also sizes the sample)
-    warm = time.time() - t0
-    n_max = max(1, min(20, int((seconds_budget - warm) / max(warm, 1e-3))))
-    n, t0 = 0, time.time()
-    while n < n_max and time.time() - t0 < seconds_budget:
-        one()
-        n += 1
-    dt = time.time() - t0
-    return {"value": round(2 * n / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} timed step(s) after 1 warm-up of DLA-34 ctdet train step (fwd+loss+bwd+Adam) + decode, batch 2, "
-                      f"512x512, fp32, torch-CPU oracle (pure-torch DCNv2), {cores} threads, {dt:.1f} s"}
+        def one():
+            if train:
+                opt.zero_grad()
+                out = m(x)
+                loss, _ = m.loss(out, tgt)
+                loss.backward()
+                opt.step()
+            else:
+                with torch.no_grad():
+                    out = m(x)
+            with torch.no_grad():
+                ops_ref.ctdet_decode(ops_ref.sigmoid_clamped(out[0]["heatmap"].detach().clone()), out[0]["width_height"].detach(),
+                                     out[0]["regression"].detach())
+        for _ in range(warm):
+            one()
+        ts = []
+        for _ in range(n_timed):
+            t0 = time.time(); one(); ts.append(time.time() - t0)
+        legs[f"{arch} {'train step + decode' if train else 'forward + decode'} bs={bs}"] = {
+            "images_per_s": round(bs / statistics.median(ts), 3), "timed": n_timed, "warmup": warm}
+
+    n2, n8 = (5, 5) if full else (5, 2)
+    w8 = 3 if full else 1                       # batch 8 warm-ups in the bounded run: 1 (a DLA-34 batch-8 train step is ~5 s)
+    run("dla_34", 2, True, n2)
+    run("dla_34", 2, False, n2)
+    run("dla_34", 8, False, n8, warm=w8)
+    run("dla_34", 8, True, n8, warm=w8)
+    if full:
+        for bs in (2, 8):
+            run("res_18", bs, True, 5)
+            run("res_18", bs, False, 5)
+    dt = time.time() - t_all
+    head = legs["dla_34 train step + decode bs=2"]
+    return {"value": head["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+            "sample": f"median of {head['timed']} timed steps after 3 warm-ups of DLA-34 ctdet train step (fwd+loss+bwd+Adam) + decode, "
+                      f"batch 2, 512x512, fp32, torch-CPU oracle (pure-torch DCNv2), {cores} threads; all legs {dt:.0f} s "
+                      f"({'full plan' if full else 'bounded: batch-8 legs 1 warm-up + 2 timed'})",
+            "legs": legs}
+
+
+def set_trained_offsets(model, seed=4321):
+    """Put every DCN's `conv_offset_mask` into the regime of a trained network: the reference initialises it to zero (every sampling
+    offset 0, every mask 0.5 — the cheapest input of the sampling kernels); here weights ~ N(0, 0.5 / sqrt(9 Ci)) and biases ~
+    U[-0.25, 0.25], i.e. offsets of roughly N(0, 0.5 px) on unit-variance activations, written IN PLACE (the parameters are views of
+    the optimizer's flat buffer, so a captured graph sees them).  Returns the number of layers touched."""
+    from centernet_amd import rng
+    from centernet_amd.ops import WeightsEpoch
+    n = 0
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "conv_offset_mask.weight" in name:
+                p.copy_(rng.t_normal(seed, name, tuple(p.shape), 0.0, 0.5 / (9 * p.shape[1]) ** 0.5).to(p.device))
+                n += 1
+            elif "conv_offset_mask.bias" in name:
+                p.copy_(rng.t_uniform(seed, name, tuple(p.shape), -0.25, 0.25).to(p.device))
+    WeightsEpoch.bump()
+    return n
+
+
+def timed_steps(step, batch, steps, warmup, fence):
+    for _ in range(warmup):
+        step(batch)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(batch)
+    fence()
+    return (time.perf_counter() - t0) / steps, loss
 
 
 def main():
@@ -303,6 +374,11 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="BASELINE.md section 3 in full (>= 5 timed iterations per leg, + ResNet-18): minutes")
+    ap.add_argument("--dcn-offsets", default="init", choices=["init", "trained"],
+                    help="regime of the HEADLINE run: init = the reference's zero-initialised conv_offset_mask (SURVEY 8d; on-spec), trained = "
+                         "offsets of ~N(0, 0.5 px).  The default run measures init as `value` and trained as `trained_offsets`.")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (trained offsets, fp32 rate, exchange overhead)")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-launch HIP-event pass that feeds `roofline`")
     ap.add_argument("--no-inference", action="store_true", help="skip the eval forward + decode sub-measurement (`inference`)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches + backward-overlapped RCCL buckets instead of hipGraph replay")
@@ -320,12 +396,16 @@ def main():
     from centernet_amd.engine import TrainStep, init_distributed
 
     rank, local, world = init_distributed()
+    assert args.gpus == world, (f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as `python -m torch.distributed.run "
+                                f"--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path for the product)"
     dev = torch.device("cuda", local)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(1234 + rank)
 
     model = CenterNetDetection(args.arch, compute_dtype=dt).to(dev).train()
+    if args.dcn_offsets == "trained":
+        set_trained_offsets(model)
     # one synthetic COCO-like batch per rank (different images per rank), resident in HBM before timing starts
     nuniq = min(args.batch, 8)
     x, tgt = synth.ctdet_batch(1234, nuniq, args.size, args.size, start=rank * nuniq)
@@ -420,6 +500,71 @@ def main():
                      "unit": "images/s", "ms_per_batch": round(dt_inf * 1e3, 3), "launch": "hipGraph replay", "dtype": args.dtype,
                      "target": 3000.0}
 
+    # ---- secondary measurements (single GPU only; never `value`) ----
+    extras = {}
+    if world == 1 and not args.no_extras and args.host_input == "none" and args.arch.startswith(("dla", "resdcn")):
+        n_steps = max(3, args.steps // 2)
+        if args.dcn_offsets == "init":
+            # (1) the same replayed graph on TRAINED-regime sampling offsets: the DCN kernels' time depends on the offset field
+            nl = set_trained_offsets(model)
+            dt_tr, _ = timed_steps(step, batch, n_steps, 2, fence)
+            extras["trained_offsets"] = {"value": round(args.batch / dt_tr, 2), "unit": "images/s", "ms_per_step": round(dt_tr * 1e3, 3),
+                                         "steps": n_steps, "dcn_layers": nl,
+                                         "what": "same graph, conv_offset_mask ~ N(0, 0.5/sqrt(9 Ci)) (offsets of about N(0, 0.5 px))"}
+            if probe is not None:
+                p2 = ConvProbe(_hip, tn)
+                side_was, step.side = step.side, False
+                sync_was, step.sync = step.sync, None
+                with p2:
+                    step._eager(batch)
+                    torch.cuda.synchronize()
+                step.side, step.sync = side_was, sync_was
+                extras["trained_offsets"]["dcn_entry_points_ms_per_step"] = {
+                    k: round(v[1] * 1e3, 3) for k, v in p2.entry_points().items() if k.startswith("cn_dcn")}
+        # (2) gradient-exchange overhead on ONE rank: the same step with the bucketed RCCL all-reduces captured into its graph
+        # (CN_FORCE_EXCHANGE: a 1-rank group) against the step above — launch + capture cost of the exchange, not its wire time
+        try:
+            os.environ["CN_FORCE_EXCHANGE"] = "1"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", rank=0, world_size=1)
+            base_ms = (extras["trained_offsets"]["ms_per_step"] if "trained_offsets" in extras else elapsed / args.steps * 1e3)
+            step_x = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_forward=decode, adopt_batch=True, distributed=True)
+            dt_x, _ = timed_steps(step_x, batch, n_steps, 2, fence)
+            extras["exchange_overhead_ms"] = round(dt_x * 1e3 - base_ms, 3)
+            extras["exchange"] = {"ms_per_step": round(dt_x * 1e3, 3), "baseline_ms_per_step": round(base_ms, 3),
+                                  "buckets": len(step_x.sync.buckets), "captured": bool(step_x.graph),
+                                  "what": "1-rank RCCL group (CN_FORCE_EXCHANGE=1): bucketed all-reduce captured into the step's hipGraph"}
+            del step_x
+        except Exception as e:      # noqa: BLE001 - a box without a working RCCL must not lose the headline
+            extras["exchange_overhead_ms"] = None
+            extras["exchange"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        finally:
+            os.environ.pop("CN_FORCE_EXCHANGE", None)
+        # (3) fp32 compute mode (the mode in which the 1e-4 parity of the north star holds), same workload, fewer steps
+        if args.dtype == "bf16":
+            try:
+                torch.cuda.empty_cache()
+                m32 = CenterNetDetection(args.arch, compute_dtype=torch.float32).to(dev).train()
+                cap32 = {}
+                l32 = m32.loss
+
+                def keep32(outputs, target):
+                    r = l32(outputs, target)
+                    cap32["out"] = outputs[-1]
+                    return r
+                m32.loss = keep32
+                dec32 = lambda: ctdet_decode(cap32["out"]["heatmap"].detach(), cap32["out"]["width_height"].detach(),
+                                             reg=cap32["out"]["regression"].detach())
+                s32 = TrainStep(m32, lr=1e-4, graph=not args.no_graph, post_forward=dec32, adopt_batch=True, distributed=False)
+                dt32, _ = timed_steps(s32, batch, 3, 1, fence)
+                extras["fp32"] = {"value": round(args.batch / dt32, 2), "unit": "images/s", "ms_per_step": round(dt32 * 1e3, 3), "steps": 3,
+                                  "what": "compute_dtype=float32 (parity mode: heat maps / losses within 1e-4 of the reference), same workload"}
+                del s32, m32
+            except Exception as e:      # noqa: BLE001
+                extras["fp32"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     if rank == 0:
         total_images = args.batch * world * args.steps
         roof = None
@@ -486,12 +631,18 @@ def main():
                                        f"{args.size}x{args.size}, batch {args.batch}/GPU, {args.dtype} compute / fp32 master weights",
                            "global_batch": args.batch * world, "parallelism": f"dp{world}",
                            "launch": "hipGraph replay (2 graphs/step)" if step.graph else "eager",
+                           "dcn_offsets": ("init: conv_offset_mask zero-initialised like the reference (SURVEY 8d), i.e. sampling offsets are 0 at "
+                                           "step 0 and O(1e-3 px) during the timed steps; `trained_offsets` holds the rate on ~N(0, 0.5 px) offsets")
+                                          if args.dcn_offsets == "init" else "trained: conv_offset_mask ~ N(0, 0.5/sqrt(9 Ci)), offsets ~ N(0, 0.5 px)",
+                           "parity": "bf16 compute / fp32 master weights; decode indices bit-exact vs the reference goldens, fp32 mode 1e-4; DCNv2 "
+                                     "arithmetic pinned to the published algorithm only (the extension is not under /root/reference)",
                            "final_loss": round(float(loss.detach()), 4)},
                 "roofline": roof,
                 "inference": inference,
                 "cpu_baseline": None}
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

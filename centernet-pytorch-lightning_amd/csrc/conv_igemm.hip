@@ -580,6 +580,37 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
     return CN_OK;
 }
 
+// Which kernel template a DCNv2 entry point dispatches to for bf16 activations with the standard pitches (x_ld = Ci, y_ld = dy_ld = Co,
+// om_ld = 32); bench.py names its per-kernel roofline rows with it so that they agree with rocprofv3's kernel names.
+//   entry 0 = cn_dcn_fwd:     1000000 + NCB = dcn_fwd_bm_kernel<NCB>; 2000000 + BN = dcn_fwd_tile_kernel<BN>; 3000000 + BN*1000 + CK = dcn_fwd_kernel<bf16,BN,CK>
+//   entry 1 = cn_dcn_wgrad:   BMW*1000000 + BNW*1000 + TAPS = dcn_wgrad_kernel<BMW,BNW,TAPS>
+//   entry 2 = cn_dcn_bwd_dom: COP = dcn_bwd_dom_kernel<COP> (0: the generic GEMM-epilogue kernel)
+//   entry 3 = cn_dcn_bwd_dx:  1000000 + NCB = dcn_dx_bm_kernel<NCB>; 3000000 + BN*1000 + CK = dcn_bwd_dx_kernel<bf16,BN,CK>
+extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
+    const int co32 = (Co + 31) / 32 * 32;
+    if (entry == 0) {
+        if (dcn_fwd_bm_shape_ok(Ci, Ci, Co, Co, 32)) return 1000000 + Co / 32;
+        if (dcn_fwd_tile_shape_ok(Ci, Ci, Co, Co)) return 2000000 + (Co % 128 == 0 ? 128 : 64);
+        int bn = 32, bw = co32;
+        for (int c : {64, 128}) {
+            const int w = (co32 + c - 1) / c * c;
+            if (w <= bw) { bn = c; bw = w; }
+        }
+        return 3000000 + bn * 1000 + (Ci % 64 == 0 ? 64 : (Ci % 32 == 0 ? 32 : 16));
+    }
+    if (entry == 1) {
+        static const bool taps3 = getenv("CN_DCN_WGRAD_TAPS3") != nullptr;
+        return Co > 64 ? 128064003 : (taps3 ? 64064003 : 64064009);
+    }
+    if (entry == 2) return (Ci % 64 == 0 && cn_dcn_bwd_dom_slabs(128, Co, CN_BF16) == 2) ? Co : 0;   // slabs(128, .) == 2 <=> the tile kernel takes this dy_ld
+    if (entry == 3) {
+        if (dcn_dx_bm_shape_ok(Ci, Co, 32)) return 1000000 + Ci / 32;
+        const int bn = Ci % 128 == 0 ? 128 : (Ci % 64 == 0 ? 64 : 32);
+        return 3000000 + bn * 1000 + (Co % 64 == 0 ? 64 : (Co % 32 == 0 ? 32 : 16));
+    }
+    return -1;
+}
+
 // Fused DCNv2 forward (sampling -> LDS -> MFMA, dcn_fused.hip): y = act(bias + sum_k W_k * mask_k * bilinear_k(x) [+ residual]).
 // wp = cn_pack_weight mode 1 of the layer weight ([Co_pad32][tap*Ci + ci]); om fp32 [P][om_ld]; bias fp32[Co] nullable.
 extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,

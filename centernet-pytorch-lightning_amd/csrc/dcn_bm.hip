@@ -364,11 +364,15 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
     BM_STAMP(31);
 }
 
+bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld) {
+    static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_FWD_BM") != nullptr;
+    return !disabled && Ci == 64 && x_ld == 64 && om_ld == 32 && (Co == 64 || Co == 32) && y_ld == Co;
+}
+
 // returns false when the shape is not handled here (caller falls back to the gather / LDS-tile kernels)
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
                        int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st) {
-    static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr;
-    if (disabled || bias == nullptr || Ci != 64 || x_ld != 64 || om_ld != 32 || ((uintptr_t)om & 15) || (Co != 64 && Co != 32) || y_ld != Co || ktot != 9 * 64 || N > 65535) return false;
+    if (!dcn_fwd_bm_shape_ok(Ci, x_ld, Co, y_ld, om_ld) || bias == nullptr || ((uintptr_t)om & 15) || ktot != 9 * 64 || N > 65535) return false;
     if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) return false;
     if ((uintptr_t)bias & 15) return false;
     BmGeom g;
@@ -645,11 +649,15 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
     }
 }
 
+bool dcn_dx_bm_shape_ok(int Ci, int dy_ld, int om_ld) {
+    static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_DX_BM") != nullptr;
+    return !disabled && dy_ld == 64 && (Ci == 64 || Ci == 32) && om_ld == 32;
+}
+
 // returns false when the shape is not handled here (caller falls back to the adjoint-gather kernel)
 bool dcn_dx_bm_launch(const void* dy, const void* wpd0, const float* om, float* far, int* far_flag, void* dx, int N, int H, int W, int Ci,
                       int dy_ld, int om_ld, hipStream_t st) {
-    static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_DX_BM") != nullptr;
-    if (disabled || dy_ld != 64 || (Ci != 64 && Ci != 32) || om_ld != 32 || N > 65535) return false;
+    if (!dcn_dx_bm_shape_ok(Ci, dy_ld, om_ld) || N > 65535) return false;
     if (((uintptr_t)dy | (uintptr_t)wpd0 | (uintptr_t)dx | (uintptr_t)om | (uintptr_t)far) & 15) return false;
     DxBmGeom g;
     g.dy = (const bf16_t*)dy; g.om = om; g.wp = (const bf16_t*)wpd0; g.far = far; g.far_flag = far_flag; g.dx = (bf16_t*)dx;

@@ -259,15 +259,19 @@ __global__ __launch_bounds__(512) void dcn_fwd_tile_kernel(const FwdTileGeom g) 
 }
 
 // returns false when the shape is not handled by the tile-resident kernel
-bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                         int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st) {
+bool dcn_fwd_tile_shape_ok(int Ci, int x_ld, int Co, int y_ld) {
     static const bool disabled = getenv("CN_DISABLE_DCN_FWD_TILE") != nullptr;
     static const bool forced = getenv("CN_FORCE_DCN_FWD_TILE") != nullptr;
-    if (disabled || Ci % 64 != 0 || Co % 64 != 0 || (x_ld & 7) || (y_ld & 7) || y_ld != Co || relu > 1) return false;
+    if (disabled || Ci % 64 != 0 || Co % 64 != 0 || (x_ld & 7) || (y_ld & 7) || y_ld != Co) return false;
     // measured (MI355X, batch 64): 1.2-2.1x over the global-gather kernel once the halo is re-used by >= 2 channel blocks and 128
     // output channels (230 vs 279 us 128->128@64^2, 100 vs 210 us 512->256@16^2); 64->64@128^2 is LDS + VALU bound here (431 vs
-    // 395 us: 64 KB of corner reads + 64 KB of MFMA operand reads per tap) and stays on the gather kernel.
-    if (!forced && (Ci < 128 || Co < 128)) return false;
+    // 395 us: 64 KB of corner reads + 64 KB of MFMA operand reads per tap) and stays on the gather / blend-matrix kernels.
+    return forced || (Ci >= 128 && Co >= 128);
+}
+
+bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
+                         int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st) {
+    if (!dcn_fwd_tile_shape_ok(Ci, x_ld, Co, y_ld) || relu > 1) return false;
     FwdTileGeom g;
     g.x = (const bf16_t*)x; g.w = (const bf16_t*)wp; g.om = om; g.bias = bias; g.y = (bf16_t*)y;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.relu = relu;

@@ -171,6 +171,10 @@ int cn_dcn_im2col(const void* x, const float* om, void* col, int N, int H, int W
  * channels 0..26 are overwritten. */
 int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_tile, float* dx_far, float* dom,
                   int N, int H, int W, int Ci, int x_ld, int om_ld, int dtype, void* stream);
+/* Which kernel template a DCNv2 entry point dispatches to (bf16, standard pitches): entry 0 = cn_dcn_fwd, 1 = cn_dcn_wgrad,
+ * 2 = cn_dcn_bwd_dom, 3 = cn_dcn_bwd_dx; codes are listed at the definition (csrc/conv_igemm.hip).  Measurement aid: bench.py
+ * names its per-kernel roofline rows with it so that they match rocprofv3's kernel names.  No reference counterpart. */
+int cn_dcn_variant(int entry, int Ci, int Co);
 /* Fused DCNv2 forward: bilinear sampling straight into the MFMA operand tile in LDS — no column tensor in HBM.
  * y = act(bias + sum_k W_k * sigmoid(om[18+k]) * bilinear_k(x)); wp = cn_pack_weight mode 1 ([Co_pad32][tap*Ci + ci]). */
 int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,
