@@ -323,6 +323,9 @@ bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const flo
 bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld);
 bool dcn_dx_bm_shape_ok(int Ci, int dy_ld, int om_ld);
 bool dcn_fwd_tile_shape_ok(int Ci, int x_ld, int Co, int y_ld);
+bool dcn_wgrad_bm_shape_ok(int Ci, int x_ld, int Co, int dy_ld, int om_ld);
+bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
+                         int om_ld, int target_blocks, hipStream_t st);                     // dcn_bm.hip
 bool dcn_dx_bm_launch(const void* dy, const void* wpd0, const float* om, float* far, int* far_flag, void* dx, int N, int H, int W, int Ci,
                       int dy_ld, int om_ld, hipStream_t st);                                // dcn_bm.hip
 bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, int dom_slabs, float* far, int* far_flag,

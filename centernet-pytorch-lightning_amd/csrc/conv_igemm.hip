@@ -583,7 +583,7 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
 // Which kernel template a DCNv2 entry point dispatches to for bf16 activations with the standard pitches (x_ld = Ci, y_ld = dy_ld = Co,
 // om_ld = 32); bench.py names its per-kernel roofline rows with it so that they agree with rocprofv3's kernel names.
 //   entry 0 = cn_dcn_fwd:     1000000 + NCB = dcn_fwd_bm_kernel<NCB>; 2000000 + BN = dcn_fwd_tile_kernel<BN>; 3000000 + BN*1000 + CK = dcn_fwd_kernel<bf16,BN,CK>
-//   entry 1 = cn_dcn_wgrad:   BMW*1000000 + BNW*1000 + TAPS = dcn_wgrad_kernel<BMW,BNW,TAPS>
+//   entry 1 = cn_dcn_wgrad:   1 = dcn_wgrad_bm_kernel; BMW*1000000 + BNW*1000 + TAPS = dcn_wgrad_kernel<BMW,BNW,TAPS>
 //   entry 2 = cn_dcn_bwd_dom: COP = dcn_bwd_dom_kernel<COP> (0: the generic GEMM-epilogue kernel)
 //   entry 3 = cn_dcn_bwd_dx:  1000000 + NCB = dcn_dx_bm_kernel<NCB>; 3000000 + BN*1000 + CK = dcn_bwd_dx_kernel<bf16,BN,CK>
 extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
@@ -600,6 +600,7 @@ extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
     }
     if (entry == 1) {
         static const bool taps3 = getenv("CN_DCN_WGRAD_TAPS3") != nullptr;
+        if (dcn_wgrad_bm_shape_ok(Ci, Ci, Co, Co, 32)) return 1;            // dcn_wgrad_bm_kernel
         return Co > 64 ? 128064003 : (taps3 ? 64064003 : 64064009);
     }
     if (entry == 2) return (Ci % 64 == 0 && cn_dcn_bwd_dom_slabs(128, Co, CN_BF16) == 2) ? Co : 0;   // slabs(128, .) == 2 <=> the tile kernel takes this dy_ld

@@ -371,11 +371,19 @@ static void launch_dw(DcnWgradGeom& g, hipStream_t st) {
     hipLaunchKernelGGL((dcn_wgrad_kernel<BMW, BNW, TAPS>), dim3(gx, co_tiles * g.ci_tiles, TAPS == 9 ? 1 : 3), dim3(256), smem, st, g);
 }
 
+// dcn_bm.hip: blend-matrix sampler, one wave per tap (64 -> 64 layers); false = shape not handled there
+bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
+                         int om_ld, int target_blocks, hipStream_t st);
+
 extern "C" int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
                             int Co, int dy_ld, int om_ld, int dtype, void* stream) {
     CN_CHECK_ARG(x && om && dy && dwp && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "cn_dcn_wgrad: bad args");
     if (dtype != CN_BF16) CN_UNSUPPORTED("cn_dcn_wgrad: bf16 only (fp32 parity mode goes through cn_dcn_im2col + cn_conv2d_wgrad)");
     if (Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) CN_UNSUPPORTED("cn_dcn_wgrad: channel counts must be multiples of 8");
+    if (dcn_wgrad_bm_launch(x, om, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, om_ld, cn_wgrad_target_blocks(), (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_dcn_wgrad(bm)");
+        return CN_OK;
+    }
     DcnWgradGeom g;
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.om = om; g.dwp = dwp;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.om_ld = om_ld; g.ktot = 9 * Ci;

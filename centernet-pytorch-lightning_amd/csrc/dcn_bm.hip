@@ -674,3 +674,272 @@ bool dcn_dx_bm_launch(const void* dy, const void* wpd0, const float* om, float* 
     }
     return true;
 }
+
+
+// ================================================================================================ weight gradient
+// dW_k[co][ci] = sum_p dY[p][co] * S_k[p][ci],  S_k = the sampled operand of the forward pass (never stored: 1.2 GB per layer).
+// The sampler is the forward kernel's (blend matrix x window on the matrix cores) with the operands swapped, S[p][ci] = Bm[p][.] X[.][ci],
+// so that S leaves the matrix pipe with lane = channel, registers = pixels — the B operand of dW[co][ci] += dY^T[co][p] S[p][ci]
+// (A = transposed fragments of the dY tile, pixel order permuted to the accumulator layout).  What makes a fused weight gradient
+// hard is the accumulator: 9 taps x 64 x 64 fp32 = 144 registers per lane in the gather kernel (dcn_wgrad_kernel<64,64,9>).  Here
+// a workgroup is NINE waves and wave t owns tap t: 64 accumulator registers, every wave walks the tile's four pixel groups with
+// its own tap's geometry.  The window fragments are read from the halo image per touched row (a wave touches 4-8 of the 12 rows),
+// which keeps a wave under 170 registers (three waves per SIMD).  Persistent workgroups (one per CU) accumulate over their run of
+// tiles and flush once with fp32 atomics.
+struct WgBmGeom {
+    const bf16_t* x; const bf16_t* dy; const float* om; float* dwp;
+    int N, H, W, ktot, tiles_h, tiles_w, tiles_per_block;
+};
+
+#define WGB_NT 576
+
+__global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Xw = smem;                                   // x halo image [16][24] x 128 B
+    unsigned char* const Yt = smem + BM_WR * BM_WC * BM_PIXB;         // dY tile [8][16] x 128 B (same half swizzle)
+    float* const OmT = reinterpret_cast<float*>(Yt + BM_TH * BM_TW * BM_PIXB);      // [4 groups][32 px][29]
+    u32x4v* const Lut = reinterpret_cast<u32x4v*>(reinterpret_cast<unsigned char*>(OmT) + 4 * 32 * 29 * 4);   // [23]
+    const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+    if (tid < 23) {
+        const int c = tid - 8;
+        u32x4v sel;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int sft = c - 2 * d;
+            sel[d] = sft == 0 ? 0x03020100u : (sft == 1 ? 0x01000c0cu : (sft == -1 ? 0x0c0c0302u : 0x0c0c0c0cu));
+        }
+        Lut[tid] = sel;
+    }
+    const int nl = lane & 31, hh = lane >> 5;
+    const int r16 = lane & 15, g16 = lane >> 4;
+    typedef __attribute__((address_space(3))) s16x4_t_* lds_ptr;
+
+    f32x16_t acc[2][2];                                               // [co block][ci block] of dW_tap
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int64_t t_beg = (int64_t)blockIdx.x * g.tiles_per_block;
+    const int64_t t_end = t_beg + g.tiles_per_block < ntiles ? t_beg + g.tiles_per_block : ntiles;
+
+#pragma unroll 1
+    for (int64_t tile = t_beg; tile < t_end; ++tile) {
+        const int n = (int)(tile / (g.tiles_h * g.tiles_w));
+        const int rt = (int)(tile - (int64_t)n * g.tiles_h * g.tiles_w);
+        const int ty0 = (rt / g.tiles_w) * BM_TH, tx0 = (rt % g.tiles_w) * BM_TW;
+        const int64_t img = (int64_t)n * g.H * g.W;
+        const bf16_t* __restrict__ X = g.x + img * 64;
+        const bf16_t* __restrict__ DY = g.dy + img * 64;
+        const float* __restrict__ OM = g.om + img * 32;
+        __syncthreads();                           // everybody is done with the previous tile's images
+        // ---- staging: x halo (3072 vectors), dY tile (1024), offsets / masks of the 128 pixels (896) ----
+        {
+            constexpr int NH = (BM_WR * BM_WC * 8 + WGB_NT - 1) / WGB_NT;      // 6
+            uint4 hv[NH];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const int v = tid + i * WGB_NT;
+                const int pix = v >> 3, q = v & 7;
+                const int hy = ty0 - BM_MG + pix / BM_WC, hx = tx0 - BM_MG + pix % BM_WC;
+                const bool ok = v < BM_WR * BM_WC * 8 && (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
+                hv[i] = ldg16_masked(X, (((int64_t)hy * g.W + hx) * 64 + q * 8) * 2, ok);
+            }
+            uint4 yv[2];
+            float4 ov[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int v = tid + i * WGB_NT;
+                const int pix = v >> 3, q = v & 7;
+                const int py_ = ty0 + (pix >> 4), px_ = tx0 + (pix & 15);
+                const bool ok = v < 1024 && py_ < g.H && px_ < g.W;
+                yv[i] = ldg16_masked(DY, (((int64_t)py_ * g.W + px_) * 64 + q * 8) * 2, ok);
+                ov[i] = *reinterpret_cast<const float4*>(OM + ((int64_t)(ok ? py_ : 0) * g.W + (ok ? px_ : 0)) * 32 + (q < 7 ? q : 0) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const int v = tid + i * WGB_NT;
+                const int pix = v >> 3, q = v & 7;
+                if (v < BM_WR * BM_WC * 8) st16(Xw + bm_lds_ofs(pix / BM_WC, pix % BM_WC, q * 8), hv[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int v = tid + i * WGB_NT;
+                const int pix = v >> 3, q = v & 7;
+                if (v >= 1024) continue;
+                const int pr = pix >> 4, pc = pix & 15;
+                st16(Yt + pix * BM_PIXB + ((((q >> 2) ^ (pc >> 1)) & 1) << 6) + (q & 3) * 16, yv[i]);
+                // table of the pixel's group: positions relative to the group's window origin, sigmoid(mask) (see the forward kernel)
+                const bool inimg = ty0 + pr < g.H && tx0 + pc < g.W;
+                float* d = OmT + ((((pr >> 2) * 2 + (pc >> 3)) * 32 + (pr & 3) * 8 + (pc & 7)) * 29) + q * 4;
+                const float v4[4] = {ov[i].x, ov[i].y, ov[i].z, ov[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = q * 4 + j, k = e >> 1, k3 = (k * 11) >> 5;
+                    float val = v4[j] + (float)((e & 1) ? (pc & 7) + 3 + (k - 3 * k3) : (pr & 3) + 3 + k3);
+                    if (q >= 4 && e >= 18) val = inimg ? __builtin_amdgcn_rcpf(1.f + __expf(-v4[j])) : 0.f;
+                    if (e < 27) d[j] = val;
+                }
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int grp = 0; grp < 4; ++grp) {
+            const int grow = (grp >> 1) * 4, gcol = (grp & 1) * 8;
+            // ---- geometry of (own pixel, this wave's tap) ----
+            const float* orow = OmT + (grp * 32 + nl) * 29;
+            const float pyr = orow[2 * tap], pxr = orow[2 * tap + 1], m = orow[18 + tap];
+            const float fy = floorf(pyr), fx = floorf(pxr);
+            const int wr = (int)fy, wc = (int)fx;
+            const float ly = pyr - fy, lx = pxr - fx;
+            const float wa = (1.f - ly) * m, wbt = ly * m;
+            const bool inwin = (unsigned)wr <= (unsigned)(BM_GR - 2) && (unsigned)wc <= 14u;
+            const bool far = !inwin && m != 0.f;
+            const uint32_t P0 = inwin ? pk_bf16(wa * (1.f - lx), wa * lx) : 0u, P1 = inwin ? pk_bf16(wbt * (1.f - lx), wbt * lx) : 0u;
+            const int wr_top = (P0 != 0u) ? wr : -1, wr_bot = (P1 != 0u) ? wr + 1 : -1;
+            const u32x4v sel = Lut[min(max(wc - 8 * hh + 8, 0), 22)];
+            uint32_t V0[4], V1[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                V0[d] = __builtin_amdgcn_perm(P0, P0, sel[d]);
+                V1[d] = __builtin_amdgcn_perm(P1, P1, sel[d]);
+            }
+            uint32_t rows = ((P0 != 0u) ? (1u << (wr & 15)) : 0u) | ((P1 != 0u) ? (2u << (wr & 15)) : 0u);
+            rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0xB1, 0xF, 0xF, true);
+            rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x4E, 0xF, 0xF, true);
+            rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x141, 0xF, 0xF, true);
+            rows |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rows, 0x140, 0xF, 0xF, true);
+            uint32_t rowmask = (uint32_t)__builtin_amdgcn_readlane((int)rows, 0) | (uint32_t)__builtin_amdgcn_readlane((int)rows, 16) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)rows, 32) | (uint32_t)__builtin_amdgcn_readlane((int)rows, 48);
+
+            // ---- S[p][ci] = Bm[p][window row] X[window row][ci] over the touched rows (fragments straight from the halo image) ----
+            f32x16_t st[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
+            const int wc0 = gcol + 8 * (g16 >> 1) + (r16 >> 2);
+            const unsigned char* const b0 = Xw + bm_lds_ofs(grow, wc0, 16 * (g16 & 1) + 4 * (r16 & 3));
+            const unsigned char* const b1 = Xw + bm_lds_ofs(grow, wc0, 32 + 16 * (g16 & 1) + 4 * (r16 & 3));
+#pragma unroll 1
+            while (rowmask) {
+                const int r = __builtin_ctz(rowmask);
+                rowmask &= rowmask - 1;
+                const bool t0 = wr_top == r, t1 = wr_bot == r;
+                u32x4v b;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) b[d] = t0 ? V0[d] : (t1 ? V1[d] : 0u);
+                const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b);
+                const int ro_ = r * (BM_WC * BM_PIXB);
+                const s16x4_t_ l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b0 + ro_));
+                const s16x4_t_ h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b0 + ro_ + 4 * BM_PIXB));
+                const s16x4_t_ l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1 + ro_));
+                const s16x4_t_ h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1 + ro_ + 4 * BM_PIXB));
+                const s16x8_t_ x0 = {l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
+                const s16x8_t_ x1 = {l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8_t, x0), st[0], 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8_t, x1), st[1], 0, 0, 0);
+            }
+            // ---- samples that leave the window (rare): pixel by pixel, every lane blends ITS channel of S from global memory (exact fp32
+            //      weights) and applies the rank-1 update dW[.][ci] += dY[p][.] * S[p][ci] to its accumulator columns directly ----
+            uint32_t farmask = (uint32_t)__builtin_amdgcn_ballot_w64(far);      // lanes 0..31 = the group's pixels (32..63 repeat them)
+#pragma unroll 1
+            while (farmask) {
+                const int p = __builtin_ctz(farmask);
+                farmask &= farmask - 1;
+                const float f_ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ly), p));
+                const float f_lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lx), p));
+                const float f_m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), p));
+                const int h0_ = __builtin_amdgcn_readlane(wr, p) + (ty0 + grow - BM_MG), w0_ = __builtin_amdgcn_readlane(wc, p) + (tx0 + gcol - BM_MG);
+                float sv0 = 0.f, sv1 = 0.f;
+#pragma unroll
+                for (int cnr = 0; cnr < 4; ++cnr) {
+                    const int cy = h0_ + (cnr >> 1), cx = w0_ + (cnr & 1);
+                    const bool ok = (unsigned)cy < (unsigned)g.H && (unsigned)cx < (unsigned)g.W;          // wave-uniform
+                    const float w = ok ? ((cnr >> 1) ? f_ly : 1.f - f_ly) * ((cnr & 1) ? f_lx : 1.f - f_lx) * f_m : 0.f;
+                    const bf16_t* xp = X + ((int64_t)(ok ? cy : 0) * g.W + (ok ? cx : 0)) * 64 + nl;
+                    sv0 += w * bf2f(xp[0]);
+                    sv1 += w * bf2f(xp[32]);
+                }
+                const int pc = gcol + (p & 7);
+                const unsigned char* yp = Yt + ((grow + (p >> 3)) * 16 + pc) * BM_PIXB;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int co = 32 * cb + 8 * (v >> 2) + 4 * hh + (v & 3);
+                        const float dyv = bf2f(*reinterpret_cast<const bf16_t*>(yp + ((((co >> 5) ^ (pc >> 1)) & 1) << 6) + (co & 31) * 2));
+                        acc[cb][0][v] += dyv * sv0;
+                        acc[cb][1][v] += dyv * sv1;
+                    }
+            }
+            // ---- dW[co][ci] += dY^T[co][p] S[p][ci]   (K = the group's 32 pixels in the accumulator's row order) ----
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4v sb[2];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) sb[mb][d] = pk_bf16(st[mb][8 * ks + 2 * d], st[mb][8 * ks + 2 * d + 1]);
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    // A fragment: lane = co (16 (g16 & 1) + r16 of block cb), K element e <-> group pixel 16 ks + 8 (e >> 2) + 4 (g16 >> 1) + (e & 3)
+                    s16x4_t_ part[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int pgrp = 16 * ks + 8 * u + 4 * (g16 >> 1) + (r16 >> 2);          // the pixel whose 8-byte chunk this lane addresses
+                        const int pr = grow + (pgrp >> 3), pc = gcol + (pgrp & 7);
+                        const int ch = 32 * cb + 16 * (g16 & 1) + 4 * (r16 & 3);
+                        part[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_ptr)(Yt + (pr * 16 + pc) * BM_PIXB + ((((ch >> 5) ^ (pc >> 1)) & 1) << 6) + (ch & 31) * 2));
+                    }
+                    const s16x8_t_ ya = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        acc[cb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ya), __builtin_bit_cast(bf16x8_t, sb[mb]),
+                                                                              acc[cb][mb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- flush: acc[cb][mb] register v of lane = dW_tap[co = 32 cb + 8 (v >> 2) + 4 hh + (v & 3)][ci = 32 mb + nl] ----
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int co = 32 * cb + 8 * (v >> 2) + 4 * hh + (v & 3), ci = 32 * mb + nl;
+                atomicAdd(g.dwp + (int64_t)co * g.ktot + tap * 64 + ci, acc[cb][mb][v]);
+            }
+}
+
+bool dcn_wgrad_bm_shape_ok(int Ci, int x_ld, int Co, int dy_ld, int om_ld) {
+    static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_WGRAD_BM") != nullptr;
+    return !disabled && Ci == 64 && x_ld == 64 && Co == 64 && dy_ld == 64 && om_ld == 32;
+}
+
+// returns false when the shape is not handled here (caller falls back to dcn_wgrad_kernel)
+bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
+                         int om_ld, int target_blocks, hipStream_t st) {
+    if (!dcn_wgrad_bm_shape_ok(Ci, x_ld, Co, dy_ld, om_ld)) return false;
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)om) & 15) return false;
+    WgBmGeom g;
+    g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.om = om; g.dwp = dwp;
+    g.N = N; g.H = H; g.W = W; g.ktot = 9 * 64;
+    g.tiles_h = (H + BM_TH - 1) / BM_TH; g.tiles_w = (W + BM_TW - 1) / BM_TW;
+    const int64_t ntiles = (int64_t)N * g.tiles_h * g.tiles_w;
+    int64_t want = target_blocks < 256 ? target_blocks : 256;          // one persistent workgroup per CU at most
+    if (want > ntiles) want = ntiles;
+    if (want < 1) want = 1;
+    g.tiles_per_block = (int)((ntiles + want - 1) / want);
+    const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + BM_TH * BM_TW * BM_PIXB + 4 * 32 * 29 * 4 + 512;
+    (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(dcn_wgrad_bm_kernel, dim3(gx), dim3(WGB_NT), smem, st, g);
+    return true;
+}

@@ -75,6 +75,35 @@ def check_dx(N, H, W, Ci, Co, sigma, seed=0):
     return err / sc
 
 
+def check_dw(N, H, W, sigma, seed=0):
+    """weight gradient of the deformable conv (64 -> 64) through cn_dcn_wgrad vs autograd of the oracle"""
+    Ci = Co = 64
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).bfloat16().float().requires_grad_(True)
+    off = torch.randn(N, 18, H, W, generator=g) * sigma
+    ml = torch.randn(N, 9, H, W, generator=g)
+    gy = torch.randn(N, Co, H, W, generator=g).bfloat16().float()
+    dcn_v2_conv(x, off, torch.sigmoid(ml), w, None).backward(gy)
+    ref = w.grad
+    om = torch.zeros(N, H, W, 32)
+    om[..., :18] = off.permute(0, 2, 3, 1)
+    om[..., 18:27] = ml.permute(0, 2, 3, 1)
+    dt = torch.bfloat16
+    code = _hip.dtype_code(dt)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    dy = gy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    dwp = torch.zeros(Co, 9 * Ci, device=DEV)
+    _hip.call("cn_dcn_wgrad", xg, om.to(DEV), dy, dwp, N, H, W, Ci, Ci, Co, Co, 32, code)
+    torch.cuda.synchronize()
+    got = dwp.cpu().view(Co, 9, Ci).permute(0, 2, 1).reshape(Co, Ci, 3, 3)
+    err = (got - ref).abs().max().item()
+    rms = ((got - ref) ** 2).mean().sqrt().item()
+    sc = ref.abs().max().item()
+    print(f"dW  N{N} {H}x{W} sigma {sigma:4.1f}: max err {err:.4f} ({err / sc:.2e} of max {sc:.2f}), rms {rms:.5f} ({rms / ref.std().item():.2e} of std)", flush=True)
+    return err / sc
+
+
 if __name__ == "__main__":
     print("CN_DISABLE_DCN_BM =", os.environ.get("CN_DISABLE_DCN_BM"))
     worst = 0.0
@@ -87,6 +116,11 @@ if __name__ == "__main__":
         for sigma in (0.0, 0.5, 1.5, 4.0):
             worst = max(worst, check_dx(N, H, W, Ci, 64, sigma))
     print("worst rel err dx", worst)
+    worst = 0.0
+    for (N, H, W) in [(2, 16, 32), (1, 13, 21), (3, 24, 48)]:
+        for sigma in (0.0, 0.5, 1.5, 4.0):
+            worst = max(worst, check_dw(N, H, W, sigma))
+    print("worst rel err dW", worst)
     if len(sys.argv) > 1 and sys.argv[1] == "time":
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import opbench
