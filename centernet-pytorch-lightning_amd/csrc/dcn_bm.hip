@@ -688,7 +688,7 @@ bool dcn_dx_bm_launch(const void* dy, const void* wpd0, const float* om, float* 
 // tiles and flush once with fp32 atomics.
 struct WgBmGeom {
     const bf16_t* x; const bf16_t* dy; const float* om; float* dwp;
-    int N, H, W, ktot, tiles_h, tiles_w, tiles_per_block;
+    int N, H, W, Ci, Co, ktot, tiles_h, tiles_w, tiles_per_block;      // blockIdx.y = 64-channel block of x, blockIdx.z = of dY
 };
 
 #define WGB_NT 576
@@ -732,8 +732,8 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
         const int rt = (int)(tile - (int64_t)n * g.tiles_h * g.tiles_w);
         const int ty0 = (rt / g.tiles_w) * BM_TH, tx0 = (rt % g.tiles_w) * BM_TW;
         const int64_t img = (int64_t)n * g.H * g.W;
-        const bf16_t* __restrict__ X = g.x + img * 64;
-        const bf16_t* __restrict__ DY = g.dy + img * 64;
+        const bf16_t* __restrict__ X = g.x + img * g.Ci + 64 * blockIdx.y;      // this workgroup's 64-channel block of x ...
+        const bf16_t* __restrict__ DY = g.dy + img * g.Co + 64 * blockIdx.z;    // ... and of dY: dW[co block][ci block]
         const float* __restrict__ OM = g.om + img * 32;
         __syncthreads();                           // everybody is done with the previous tile's images
         // ---- staging: x halo (3072 vectors), dY tile (1024), offsets / masks of the 128 pixels (896) ----
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
                 const int pix = v >> 3, q = v & 7;
                 const int hy = ty0 - BM_MG + pix / BM_WC, hx = tx0 - BM_MG + pix % BM_WC;
                 const bool ok = v < BM_WR * BM_WC * 8 && (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
-                hv[i] = ldg16_masked(X, (((int64_t)hy * g.W + hx) * 64 + q * 8) * 2, ok);
+                hv[i] = ldg16_masked(X, (((int64_t)hy * g.W + hx) * g.Ci + q * 8) * 2, ok);
             }
             uint4 yv[2];
             float4 ov[2];
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
                 const int pix = v >> 3, q = v & 7;
                 const int py_ = ty0 + (pix >> 4), px_ = tx0 + (pix & 15);
                 const bool ok = v < 1024 && py_ < g.H && px_ < g.W;
-                yv[i] = ldg16_masked(DY, (((int64_t)py_ * g.W + px_) * 64 + q * 8) * 2, ok);
+                yv[i] = ldg16_masked(DY, (((int64_t)py_ * g.W + px_) * g.Co + q * 8) * 2, ok);
                 ov[i] = *reinterpret_cast<const float4*>(OM + ((int64_t)(ok ? py_ : 0) * g.W + (ok ? px_ : 0)) * 32 + (q < 7 ? q : 0) * 4);
             }
 #pragma unroll
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
                     const int cy = h0_ + (cnr >> 1), cx = w0_ + (cnr & 1);
                     const bool ok = (unsigned)cy < (unsigned)g.H && (unsigned)cx < (unsigned)g.W;          // wave-uniform
                     const float w = ok ? ((cnr >> 1) ? f_ly : 1.f - f_ly) * ((cnr & 1) ? f_lx : 1.f - f_lx) * f_m : 0.f;
-                    const bf16_t* xp = X + ((int64_t)(ok ? cy : 0) * g.W + (ok ? cx : 0)) * 64 + nl;
+                    const bf16_t* xp = X + ((int64_t)(ok ? cy : 0) * g.W + (ok ? cx : 0)) * g.Ci + nl;
                     sv0 += w * bf2f(xp[0]);
                     sv1 += w * bf2f(xp[32]);
                 }
@@ -913,14 +913,16 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int co = 32 * cb + 8 * (v >> 2) + 4 * hh + (v & 3), ci = 32 * mb + nl;
-                atomicAdd(g.dwp + (int64_t)co * g.ktot + tap * 64 + ci, acc[cb][mb][v]);
+                const int co = 64 * blockIdx.z + 32 * cb + 8 * (v >> 2) + 4 * hh + (v & 3), ci = 64 * blockIdx.y + 32 * mb + nl;
+                atomicAdd(g.dwp + (int64_t)co * g.ktot + tap * g.Ci + ci, acc[cb][mb][v]);
             }
 }
 
 bool dcn_wgrad_bm_shape_ok(int Ci, int x_ld, int Co, int dy_ld, int om_ld) {
     static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_WGRAD_BM") != nullptr;
-    return !disabled && Ci == 64 && x_ld == 64 && Co == 64 && dy_ld == 64 && om_ld == 32;
+    // every (x block, dY block) pair re-samples: measured ahead of dcn_wgrad_kernel up to 8 pairs (128->64@64^2 319 -> 183 us, 128->128
+    // 395 -> 296, 256->128@32^2 229 -> 175), level with it beyond (256->256 310 vs 287 zero offsets, 313 vs 343 N(0,0.5))
+    return !disabled && Ci % 64 == 0 && x_ld == Ci && Co % 64 == 0 && dy_ld == Co && om_ld == 32 && (Ci / 64) * (Co / 64) <= 8;
 }
 
 // returns false when the shape is not handled here (caller falls back to dcn_wgrad_kernel)
@@ -930,16 +932,18 @@ bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* 
     if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)om) & 15) return false;
     WgBmGeom g;
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.om = om; g.dwp = dwp;
-    g.N = N; g.H = H; g.W = W; g.ktot = 9 * 64;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.ktot = 9 * Ci;
     g.tiles_h = (H + BM_TH - 1) / BM_TH; g.tiles_w = (W + BM_TW - 1) / BM_TW;
     const int64_t ntiles = (int64_t)N * g.tiles_h * g.tiles_w;
-    int64_t want = target_blocks < 256 ? target_blocks : 256;          // one persistent workgroup per CU at most
+    const int par = (Ci / 64) * (Co / 64);                             // channel-block pairs: independent workgroups
+    int64_t want = (target_blocks < 256 ? target_blocks : 256) / par;  // one persistent workgroup per CU at most
+    if (want < 8) want = 8;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     g.tiles_per_block = (int)((ntiles + want - 1) / want);
     const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
     const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + BM_TH * BM_TW * BM_PIXB + 4 * 32 * 29 * 4 + 512;
     (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(dcn_wgrad_bm_kernel, dim3(gx), dim3(WGB_NT), smem, st, g);
+    hipLaunchKernelGGL(dcn_wgrad_bm_kernel, dim3(gx, Ci / 64, Co / 64), dim3(WGB_NT), smem, st, g);
     return true;
 }

@@ -75,9 +75,8 @@ def check_dx(N, H, W, Ci, Co, sigma, seed=0):
     return err / sc
 
 
-def check_dw(N, H, W, sigma, seed=0):
-    """weight gradient of the deformable conv (64 -> 64) through cn_dcn_wgrad vs autograd of the oracle"""
-    Ci = Co = 64
+def check_dw(N, H, W, sigma, seed=0, Ci=64, Co=64):
+    """weight gradient of the deformable conv through cn_dcn_wgrad vs autograd of the oracle"""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).bfloat16().float().requires_grad_(True)
@@ -100,7 +99,7 @@ def check_dw(N, H, W, sigma, seed=0):
     err = (got - ref).abs().max().item()
     rms = ((got - ref) ** 2).mean().sqrt().item()
     sc = ref.abs().max().item()
-    print(f"dW  N{N} {H}x{W} sigma {sigma:4.1f}: max err {err:.4f} ({err / sc:.2e} of max {sc:.2f}), rms {rms:.5f} ({rms / ref.std().item():.2e} of std)", flush=True)
+    print(f"dW  N{N} {H}x{W} {Ci}->{Co} sigma {sigma:4.1f}: max err {err:.4f} ({err / sc:.2e} of max {sc:.2f}), rms {rms:.5f} ({rms / ref.std().item():.2e} of std)", flush=True)
     return err / sc
 
 
@@ -120,6 +119,8 @@ if __name__ == "__main__":
     for (N, H, W) in [(2, 16, 32), (1, 13, 21), (3, 24, 48)]:
         for sigma in (0.0, 0.5, 1.5, 4.0):
             worst = max(worst, check_dw(N, H, W, sigma))
+    for Ci, Co in [(128, 64), (128, 128), (256, 64)]:
+        worst = max(worst, check_dw(2, 16, 32, 1.5, Ci=Ci, Co=Co))
     print("worst rel err dW", worst)
     if len(sys.argv) > 1 and sys.argv[1] == "time":
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
