@@ -364,6 +364,30 @@ def timed_steps(step, batch, steps, warmup, fence):
     return (time.perf_counter() - t0) / steps, loss
 
 
+def dry_run(args, rank, world):
+    """The launch contract without a GPU: RANK / WORLD_SIZE parsing, per-rank batch offsets (`start=rank * nuniq` below is the
+    expression the real run uses), the MAX-over-ranks reduction of the timing and the rank-0-only JSON line."""
+    from centernet_amd import synth
+    nuniq = min(args.batch, 8)
+    x, tgt = synth.ctdet_batch(1234, nuniq, 64, 64, start=rank * nuniq)
+    mine = {"rank": rank, "first_image_index": rank * nuniq, "checksum": round(float(x.double().sum()), 6),
+            "objects": int(tgt["regression_mask"].sum())}
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    per_rank = [mine]
+    if dist.is_initialized():
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec (train step + decode) DLA-34 512\u00d7512 bs=64 at 1/2/4/8 MI355X", "value": None,
+                          "unit": "images/s", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "scaling": "weak", "max_over_ranks": float(t.item()),
+                          "config": {"global_batch": args.batch * world, "parallelism": f"dp{world}"}, "ranks": per_rank}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +402,10 @@ def main():
     ap.add_argument("--dcn-offsets", default="init", choices=["init", "trained"],
                     help="regime of the HEADLINE run: init = the reference's zero-initialised conv_offset_mask (SURVEY 8d; on-spec), trained = "
                          "offsets of ~N(0, 0.5 px).  The default run measures init as `value` and trained as `trained_offsets`.")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: join the process group (gloo on a CPU-only host), build this rank's slice of the synthetic batch at "
+                         "64x64, take the max-over-ranks of a per-rank number and let rank 0 print the JSON line — what "
+                         "tests/test_host.py drives through torch.distributed.run to cover the launch contract without hardware")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (trained offsets, fp32 rate, exchange overhead)")
     ap.add_argument("--no-probe", action="store_true", help="skip the per-launch HIP-event pass that feeds `roofline`")
     ap.add_argument("--no-inference", action="store_true", help="skip the eval forward + decode sub-measurement (`inference`)")
@@ -398,6 +426,8 @@ def main():
     rank, local, world = init_distributed()
     assert args.gpus == world, (f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 as `python -m torch.distributed.run "
                                 f"--nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path for the product)"
     dev = torch.device("cuda", local)
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32

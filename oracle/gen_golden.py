@@ -481,7 +481,58 @@ def gen_test_step_end():
     save("test_step_end.npz", **kw)
 
 
+def gen_pose_models():
+    """C5 pinned to the reference: its DLASeg + a 6-head CenterHead (centernet_multi_pose.py:50-63) and the reference's OWN
+    `CenterNetMultiPose.loss` (centernet_multi_pose.py:97-155), compiled out of the source file with `_ref_method` because the
+    LightningModule file itself cannot be imported here; eval fixture adds the reference's `multi_pose_decode` of the head maps."""
+    import types
+    loss_fn = _ref_method(f"{refshim.REF}/CenterNet/centernet_multi_pose.py", "CenterNetMultiPose", "loss",
+                          {"sigmoid_clamped": sigmoid_clamped, "torch": torch})
+    heads_spec = {"heatmap": 1, "width_height": 2, "regression": 2, "heatmap_keypoints": 17, "keypoints": 34,
+                  "heatmap_keypoints_offset": 2}
+    seed, size, B = 36, 128, 2
+    for train in (False, True):
+        net = pose_dla_dcn.DLASeg("dla34", pretrained=False, down_ratio=4, final_kernel=1, last_level=5)
+        heads = CenterHead(heads_spec, net.out_channels, 256)
+        full = torch.nn.ModuleDict({"backbone": net, "heads": torch.nn.ModuleList([heads])})
+        rng.fill_state_dict(full, seed)
+        full.train(train)
+        x, tgt = synth.pose_batch(seed, B, size, size)
+        feat = net(x)[0]
+        out = heads(feat)
+        raw = {k: v.detach().clone() for k, v in out.items()}
+        me = types.SimpleNamespace(
+            criterion=FocalLoss(), criterion_heatmap_keypoints=FocalLoss(), criterion_keypoints=RegWeightedL1Loss(),
+            criterion_regression=RegL1Loss(), criterion_width_height=RegL1Loss(),
+            hparams=types.SimpleNamespace(hm_weight=1, wh_weight=0.1, off_weight=1, hp_weight=1, hm_hp_weight=1))
+        loss, stats = loss_fn(me, [out], tgt)
+        kw = dict(seed=seed, size=size, train=int(train), feat_s=strided(feat), feat_sum=summary(feat))
+        for k, v in stats.items():
+            kw["stat:" + k] = v
+        for k, v in raw.items():
+            kw[f"{k}_s"], kw[f"{k}_sum"] = strided(v), summary(v)
+        if train:
+            loss.backward()
+            params = dict(full.named_parameters())
+            picks = ["backbone.base.base_layer.0.weight", "backbone.base.level3.tree1.tree1.conv1.weight",
+                     "backbone.ida_up.proj_1.conv.weight", "backbone.ida_up.proj_1.conv.conv_offset_mask.weight",
+                     "backbone.ida_up.up_2.weight", "heads.0.heatmap.fc.2.weight", "heads.0.keypoints.fc.0.weight",
+                     "heads.0.heatmap_keypoints.fc.2.weight", "heads.0.heatmap_keypoints_offset.fc.0.weight"]
+            for n in picks:
+                kw["g:" + n + ":s"], kw["g:" + n + ":sum"] = strided(params[n].grad, 512), summary(params[n].grad)
+        else:
+            # The untrained centre heat map is nearly flat (130 of the 200 top-K scores are EXACT ties): torch.topk's order among them is
+            # unspecified, so only the sorted score column of the reference's decode of its own heat map (stored in full: 8 KB) is
+            # pinned here; the full multi_pose_decode rows are pinned bit-exactly by the tie-free pose_decode.npz.
+            kw["map:heatmap"] = raw["heatmap"]
+            det = multi_pose_decode(out["heatmap"].detach().clone(), out["width_height"].detach(), out["keypoints"].detach().clone(),
+                                    reg=out["regression"].detach(), hm_hp=out["heatmap_keypoints"].detach().clone(),
+                                    hp_offset=out["heatmap_keypoints_offset"].detach(), K=100)
+            kw["det_scores"] = det[..., 4]
+        save(f"dla34_pose_{'train' if train else 'eval'}.npz", **kw)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["encode", "encode_msra", "encode_pose", "decode", "losses", "models", "models101", "hourglass", "pose", "soft_nms", "test_step_end"]
+    which = sys.argv[1:] or ["encode", "encode_msra", "encode_pose", "decode", "losses", "models", "models101", "pose_models", "hourglass", "pose", "soft_nms", "test_step_end"]
     for w in which:
         globals()["gen_" + w]()

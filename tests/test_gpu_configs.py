@@ -1,5 +1,5 @@
-"""GPU: the BASELINE.json configurations at FULL size (C2 ResNet-18 bf16 bs=32 512x512, C5 DLA-34 multi_pose bf16 bs=32
-512x512), whole-network bf16 accuracy against the ORACLE (not against this package's own fp32 run), the reference-shaped
+"""GPU: the BASELINE.json configurations at FULL size (C2 ResNet-18 bf16 bs=32 512x512, C3 DLA-34 ctdet bf16 bs=64 512x512 — the
+headline — and C5 DLA-34 multi_pose bf16 bs=32 512x512), whole-network bf16 accuracy against the ORACLE (not against this package's own fp32 run), the reference-shaped
 backbone <-> head seam (NCHW fp32 in both directions) and the eval -> train -> eval cache regression.
 
 Full-size runs cannot be compared with a CPU run of the whole batch in seconds, so they are held to size-independent
@@ -120,6 +120,63 @@ def test_c2_res18_bf16_bs32_512_full_size():
         _assert_bf16_close(f"C2 eval bf16 vs oracle {k}", out[k], out_ref[k])
 
 
+# ------------------------------------------------------------------------------------------------ C3 (the headline configuration)
+def test_c3_dla34_ctdet_bf16_bs64_512_full_size():
+    """BASELINE config C3 = what bench.py times: DLA-34 ctdet (DCNv2 up path), bf16, batch 64, 512x512 — hipGraph-replayed train
+    steps + ctdet_decode of the step's own head maps (forked after the forward pass, like the bench)."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.engine import TrainStep
+    seed, B, size, K = 44, 64, 512, 100
+    m = _model("dla_34", seed, torch.bfloat16).train()
+    small = synth.ctdet_batch(seed, 4, size, size)
+    batch = _to_dev(_repeat(small, B))
+    kept = {}
+    orig = m.loss
+
+    def loss_and_keep(outputs, target):
+        r = orig(outputs, target)
+        kept["out"] = outputs[-1]
+        return r
+    m.loss = loss_and_keep
+
+    def decode():
+        o = kept["out"]
+        return ctdet_decode(o["heatmap"].detach(), o["width_height"].detach(), reg=o["regression"].detach(), K=K, return_aux=True)
+
+    step = TrainStep(m, lr=1e-4, distributed=False, graph=True, post_forward=decode)
+    l0 = float(step(batch))
+    assert step.graph, "hipGraph capture fell back to eager"
+    l1 = float(step(batch))
+    torch.cuda.synchronize()
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert bool(torch.isfinite(step.opt.flat_g).all()) and float(step.opt.flat_g.abs().max()) > 0, "finite, non-trivial gradients"
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+    dcn_g = [p.grad for n_, p in m.named_parameters() if "conv_offset_mask.weight" in n_]
+    assert len(dcn_g) == 16 and all(float(g_.abs().max()) > 0 for g_ in dcn_g), "every DCN offset conv received a gradient"
+    det, inds, clses = step.post_out
+    assert det.shape == (B, K, 6) and bool(torch.isfinite(det).all())
+    heat = kept["out"]["heatmap"].detach()                  # sigmoid (in place) of this step's head map
+    _peak_properties(heat, det[..., 4], inds, clses, K)
+    assert torch.equal(det[..., 5], clses.float())
+    # the decode of the full batch == the oracle's decode of the same head maps, on the first two images (bit-exact rule)
+    o = {k: v.detach()[:2].cpu() for k, v in kept["out"].items()}
+    det_ref = ops_ref.ctdet_decode(o["heatmap"], o["width_height"], o["regression"], K=K)
+    assert torch.equal(det[:2].cpu(), det_ref), "ctdet_decode bit-exact against the oracle on this step's head maps"
+
+    # 2-image sub-batch, eval mode, against the fp32 torch-CPU oracle with the same weights (sampling offsets are non-zero:
+    # rng.fill_state_dict gives conv_offset_mask small random weights)
+    m2 = _model("dla_34", seed, torch.bfloat16).eval()
+    ref = models_ref.CenterNetRef("dla_34")
+    rng.fill_state_dict(ref, seed)
+    ref.eval()
+    x2 = small[0][:2]
+    with torch.no_grad():
+        out = m2(x2.to(DEV))[0]
+        out_ref = ref(x2)[0]
+    for k in ("heatmap", "width_height", "regression"):
+        _assert_bf16_close(f"C3 eval bf16 vs oracle {k}", out[k], out_ref[k])
+
+
 # ------------------------------------------------------------------------------------------------ C5
 def test_c5_dla34_multi_pose_bf16_bs32_512_full_size():
     """BASELINE config C5: DLA-34 multi_pose (hm + wh + reg + hm_hp + hp_offset + hps heads), bf16, batch 32, 512x512 — one
@@ -185,13 +242,13 @@ def test_c5_dla34_multi_pose_bf16_bs32_512_full_size():
 # ------------------------------------------------------------------------------------------------ bf16 vs the oracle
 @pytest.mark.parametrize("arch,size", [("res_18", 256), ("dla_34", 256)])
 def test_network_bf16_vs_oracle(arch, size):
-    """Whole-network bf16 accuracy against the fp32 torch-CPU ORACLE (same weights, same inputs), training-mode BN:
-    loss within 2 % relative, every head map within the stated bf16 tolerance of `_assert_bf16_close`."""
-    seed = 43
+    """Whole-network bf16 accuracy against the fp32 torch-CPU ORACLE (same weights, same inputs), training-mode BN, batch 16:
+    loss within 2 % relative, every head map within 15 % (worst element) / 4 % (rms) of the scale of `_rel_range_err`."""
+    seed, B = 43, 16
     ref = models_ref.CenterNetRef(arch)
     rng.fill_state_dict(ref, seed)
     ref.train()
-    x, tgt = synth.ctdet_batch(seed, 4, size, size)
+    x, tgt = synth.ctdet_batch(seed, B, size, size)
     out_ref = ref(x)
     raw_ref = {k: v.detach().clone() for k, v in out_ref[0].items()}
     loss_ref, st_ref = ref.loss(out_ref, tgt)
@@ -203,10 +260,11 @@ def test_network_bf16_vs_oracle(arch, size):
     loss.backward()
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
     for k in raw_ref:
-        # training-mode BN re-normalises every layer by the statistics of THIS batch: at the 512-channel levels those are taken over
-        # 4 x 8 x 8 samples, so bf16 rounding noise in a mean / variance moves whole channels — measured 4.5 % rms / 26 % worst
-        # element on the (tiny, sigma = 0.001 init) size and offset maps of DLA-34, against 1-3 % in eval mode (C2 / C5 tests)
-        _assert_bf16_close(f"{arch} train bf16 vs oracle {k}", raw[k], raw_ref[k], max_tol=0.5, rms_tol=8e-2)
+        # training-mode BN re-normalises every layer by the statistics of THIS batch; with batch 16 the deepest level still averages
+        # over 16 x 8 x 8 = 1 024 samples per channel (batch 4 left 256: bf16 noise in a mean / variance then moved whole channels
+        # of DLA-34's sigma = 0.001-initialised size / offset maps by up to 26 % of their range, which is why this test used to
+        # allow 50 %).  Eval mode (C2 / C3 / C5 tests) is held to 6 % / 2 %.
+        _assert_bf16_close(f"{arch} train bf16 vs oracle {k}", raw[k], raw_ref[k], max_tol=0.15, rms_tol=4e-2)
     for k in ("loss", "hm_loss", "wh_loss", "off_loss"):
         rel = abs(float(st[k]) - float(st_ref[k])) / abs(float(st_ref[k]))
         print(f"{arch} train bf16 vs oracle {k}: {float(st[k]):.5f} vs {float(st_ref[k]):.5f} (rel {rel:.2e})")

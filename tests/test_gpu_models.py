@@ -90,6 +90,54 @@ def test_network_fp32_vs_reference_golden(golden, arch, size, train):
             assert np.array_equal(got[..., 5], ref[..., 5]), "decoded classes identical"
 
 
+POSE_HEADS = ("heatmap", "width_height", "regression", "heatmap_keypoints", "keypoints", "heatmap_keypoints_offset")
+POSE_STATS = ("loss", "hm_loss", "kp_loss", "hm_kp_loss", "hm_offset_loss", "wh_loss", "off_loss")
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_pose_network_fp32_vs_reference_golden(golden, train):
+    """C5 pinned to the REFERENCE (not the oracle): DLA-34 + the six multi_pose heads, the reference's own loss body and
+    `multi_pose_decode` (fixture: oracle/gen_golden.py gen_pose_models); HIP fp32 within the north-star 1e-4."""
+    g = golden("dla34_pose_train.npz" if train else "dla34_pose_eval.npz")
+    seed, size = int(g["seed"]), int(g["size"])
+    m = _model("dla_34", seed, torch.float32, task="pose")
+    m.train(train)
+    x, tgt = synth.pose_batch(seed, 2, size, size)
+    xg, tg = x.to(DEV), {k: v.to(DEV) for k, v in tgt.items()}
+    with torch.set_grad_enabled(train):
+        outs = m(xg)
+    out = outs[0]
+    for k in POSE_HEADS:
+        ref_s = g[f"{k}_s"]
+        assert np.abs(strided(out[k]).cpu().numpy() - ref_s).max() < 1e-4 * np.abs(ref_s).max() + 1e-6, k
+        np.testing.assert_allclose(summary(out[k]), g[f"{k}_sum"], rtol=1e-4, atol=1e-4 * float(g[f"{k}_sum"][1]), err_msg=k)
+    raw = {k: v.detach().clone() for k, v in out.items()}
+    with torch.set_grad_enabled(train):
+        loss, st = m.loss(outs, tg)
+    for k in POSE_STATS:
+        assert float(st[k]) == pytest.approx(float(g["stat:" + k]), rel=1e-4), k
+    if train:
+        loss.backward()
+        params = dict(m.named_parameters())
+        for key in g.files:
+            if key.startswith("g:") and key.endswith(":s"):
+                n = key[2:-2]
+                ref = g[key].astype(np.float64)
+                got = strided(params[n].grad, 512).cpu().numpy().astype(np.float64)
+                rel_l2 = np.linalg.norm(got - ref) / max(1e-30, np.linalg.norm(ref))
+                med = np.median(np.abs(got - ref)) / max(1e-30, np.abs(ref).max())
+                assert rel_l2 < 3e-2 and med < 5e-3, f"grad {n}: rel-L2 {rel_l2:.3e}, median err {med:.3e}"   # same rule as the ctdet nets
+    else:
+        # centre scores of the reference's decode of ITS heat map (near-flat, 130 of 200 scores exactly tied: only the sorted score
+        # column is order-proof; full rows are pinned bit-exactly by pose_decode.npz), through the HIP decode on the same map
+        from centernet_amd.decode.multi_pose import multi_pose_decode
+        from centernet_amd.utils.decode import sigmoid_clamped
+        heat = sigmoid_clamped(torch.from_numpy(g["map:heatmap"]).to(DEV))
+        det = multi_pose_decode(heat, raw["width_height"], raw["keypoints"], reg=raw["regression"],
+                                hm_hp=sigmoid_clamped(raw["heatmap_keypoints"]), hp_offset=raw["heatmap_keypoints_offset"], K=100)
+        np.testing.assert_array_equal(det[..., 4].cpu().numpy(), g["det_scores"])
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_hourglass_fp32_vs_reference_golden(golden, train):
     """2-stack Hourglass-104 + one CenterHead per stack against the reference's own modules (fixture from

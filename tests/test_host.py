@@ -354,3 +354,34 @@ def test_backbones_expose_the_reference_output_contract_switch():
     assert CenterNetDetection("res_18").backbone.nchw_out is False
     t = torch.zeros(1, 4, 4, 16)
     assert not ops.is_nhwc(t) and ops.is_nhwc(ops.mark_nhwc(t, 3)) and t._cn_nhwc == 3
+
+
+def _run_bench(nproc, gpus, port):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--dry-run"]
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+
+
+def test_bench_launch_contract_two_processes():
+    """bench.py driven exactly like the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N`), on gloo with `--dry-run` (no GPU here): both ranks join, every rank builds ITS slice of the synthetic batch
+    (different images), the timing reduction takes the max over ranks and ONLY rank 0 prints the JSON line."""
+    import json
+    r = _run_bench(2, 2, 29641)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["dry_run"] is True
+    assert d["max_over_ranks"] == 2.0
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and [x["first_image_index"] for x in d["ranks"]] == [0, 8]
+    assert d["ranks"][0]["checksum"] != d["ranks"][1]["checksum"], "ranks must draw different images"
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    r = _run_bench(2, 4, 29643)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

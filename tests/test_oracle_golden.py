@@ -174,6 +174,44 @@ def test_model_matches_reference_graph(golden, arch, size, train):
         np.testing.assert_allclose(det.detach().numpy(), g["det"], rtol=1e-4, atol=1e-4)
 
 
+POSE_HEADS = ("heatmap", "width_height", "regression", "heatmap_keypoints", "keypoints", "heatmap_keypoints_offset")
+POSE_STATS = ("loss", "hm_loss", "kp_loss", "hm_kp_loss", "hm_offset_loss", "wh_loss", "off_loss")
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_pose_model_matches_reference_graph(golden, train):
+    """C5 (DLA-34 multi_pose, 6 heads) pinned to the reference: its DLASeg + CenterHead and its own `CenterNetMultiPose.loss`
+    body (centernet_multi_pose.py:97-155, compiled from the source by oracle/gen_golden.py gen_pose_models)."""
+    g = golden("dla34_pose_train.npz" if train else "dla34_pose_eval.npz")
+    seed, size = int(g["seed"]), int(g["size"])
+    net = models_ref.CenterNetRef("dla_34", task="pose")
+    rng.fill_state_dict(net, seed)
+    net.train(train)
+    x, tgt = synth.pose_batch(seed, 2, size, size)
+    feat = net.backbone(x)[0]
+    out = net.heads[0](feat)
+    np.testing.assert_allclose(strided(feat).numpy(), g["feat_s"], rtol=1e-4, atol=1e-5)
+    for k in POSE_HEADS:
+        np.testing.assert_allclose(strided(out[k]).numpy(), g[f"{k}_s"], rtol=1e-4, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(summary(out[k]), g[f"{k}_sum"], rtol=1e-4, err_msg=k)
+    raw = {k: v.detach().clone() for k, v in out.items()}
+    loss, st = net.loss([out], tgt)
+    for k in POSE_STATS:
+        assert float(st[k]) == pytest.approx(float(g["stat:" + k]), rel=1e-4), k
+    if train:
+        loss.backward()
+        params = dict(net.named_parameters())
+        for key in g.files:
+            if key.startswith("g:") and key.endswith(":s"):
+                n = key[2:-2]
+                np.testing.assert_allclose(strided(params[n].grad, 512).numpy(), g[key], rtol=2e-3, atol=1e-6, err_msg=n)
+    else:
+        # the centre scores of the reference's decode of its own (near-flat, heavily tied) heat map: sorted values are tie-proof
+        heat = ops_ref.sigmoid_clamped(torch.from_numpy(g["map:heatmap"]))
+        sc = ops_ref.topk(ops_ref.nms(heat), 100)[0]
+        np.testing.assert_array_equal(sc.reshape(2, 100).numpy(), g["det_scores"])
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_hourglass_matches_reference(golden, train):
     """the oracle's Hourglass restatement against the reference's own HourglassNet + 2 CenterHeads."""
