@@ -103,6 +103,40 @@ def check_dw(N, H, W, sigma, seed=0, Ci=64, Co=64):
     return err / sc
 
 
+def check_dom(N, H, W, Ci, sigma, seed=0):
+    """offset / mask gradient (cn_dcn_bwd_dom, dY with 64 channels) vs autograd of the oracle w.r.t. the offsets and mask logits"""
+    Co = 64
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Ci, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5).bfloat16().float()
+    off = (torch.randn(N, 18, H, W, generator=g) * sigma).requires_grad_(True)
+    ml = torch.randn(N, 9, H, W, generator=g).requires_grad_(True)
+    gy = torch.randn(N, Co, H, W, generator=g).bfloat16().float()
+    dcn_v2_conv(x, off, torch.sigmoid(ml), w, None).backward(gy)
+    ref = torch.cat([off.grad, ml.grad], 1).permute(0, 2, 3, 1)           # [N,H,W,27]
+    om = torch.zeros(N, H, W, 32)
+    om[..., :18] = off.detach().permute(0, 2, 3, 1)
+    om[..., 18:27] = ml.detach().permute(0, 2, 3, 1)
+    dt = torch.bfloat16
+    code = _hip.dtype_code(dt)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    dy = gy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    far = torch.zeros(N, H, W, Ci, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    slabs = _hip.query("cn_dcn_bwd_dom_slabs", Ci, Co, code)
+    dom = torch.full((max(slabs, 1), N, H, W, 32), float("nan"), device=DEV) if slabs == Ci // 64 else torch.zeros(1, N, H, W, 32, device=DEV)
+    _hip.call("cn_dcn_bwd_dom", dy, ops.pack_weight(w.to(DEV), 2, dt), xg, om.to(DEV), dom, slabs if slabs == Ci // 64 else 1, far, flag,
+              N, H, W, Ci, Co, Co, Ci, 32, code)
+    torch.cuda.synchronize()
+    got = dom.sum(0).cpu()[..., :27]
+    assert float(dom.sum(0)[..., 27:].abs().max()) == 0.0, "channel padding must be written as zeros"
+    err = (got - ref).abs().max().item()
+    rms = ((got - ref) ** 2).mean().sqrt().item()
+    sc = ref.abs().max().item()
+    print(f"dom N{N} {H}x{W} Ci {Ci} sigma {sigma:4.1f}: max err {err:.4f} ({err / sc:.2e} of max {sc:.2f}), rms {rms:.5f} ({rms / ref.std().item():.2e} of std), far flag {int(flag.item())}", flush=True)
+    return err / sc
+
+
 if __name__ == "__main__":
     print("CN_DISABLE_DCN_BM =", os.environ.get("CN_DISABLE_DCN_BM"))
     worst = 0.0
@@ -122,6 +156,11 @@ if __name__ == "__main__":
     for Ci, Co in [(128, 64), (128, 128), (256, 64)]:
         worst = max(worst, check_dw(2, 16, 32, 1.5, Ci=Ci, Co=Co))
     print("worst rel err dW", worst)
+    worst = 0.0
+    for (N, H, W, Ci) in [(2, 16, 32, 64), (1, 13, 21, 64), (2, 16, 16, 128)]:
+        for sigma in (0.0, 0.5, 1.5, 4.0):
+            worst = max(worst, check_dom(N, H, W, Ci, sigma))
+    print("worst rel err dom", worst)
     if len(sys.argv) > 1 and sys.argv[1] == "time":
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import opbench
