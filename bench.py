@@ -126,6 +126,8 @@ def _kernel_name(hip, name, a, tn):
         if entry == 1:
             return "dcn_wgrad_bm_kernel" if v == 1 else f"dcn_wgrad_kernel<{v // 1000000},{v // 1000 % 1000},{v % 1000}>"
         if entry == 2:
+            if v >= 1000000:
+                return f"dcn_dom_bm_kernel<{v - 1000000}>"
             return f"dcn_bwd_dom_kernel<{v}>" if v else "conv_igemm_kernel<dom epilogue>"
         return f"dcn_dx_bm_kernel<{v - 1000000}>" if v < 2000000 else f"dcn_bwd_dx_kernel<bf16,{(v - 3000000) // 1000},{v % 1000}>"
     if name in dcn:

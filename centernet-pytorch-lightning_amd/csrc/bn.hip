@@ -143,12 +143,15 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
                                                               float* __restrict__ rmean, float* __restrict__ rvar,
                                                               float* __restrict__ smean, float* __restrict__ sinvstd,
                                                               float* __restrict__ coef, float* __restrict__ save_ss,
-                                                              float momentum, float eps) {
+                                                              float momentum, float eps, float* __restrict__ clear) {
     // one wave per channel: lanes stride over the per-workgroup partials, fp64 butterfly
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int b = lane; b < nblk; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    if (clear) {            // statistics sink of a producing kernel (cn_bn_stats_arm): hand it back all-zero
+        for (int b = lane; b < nblk; b += 64) { clear[((int64_t)b * 2) * C + c] = 0.f; clear[((int64_t)b * 2 + 1) * C + c] = 0.f; }
+    }
     s = wave_sum_d(s); q = wave_sum_d(q);
     if (lane != 0) return;
     const double m = s / (double)npix;
@@ -333,12 +336,60 @@ extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, con
                                                    (const float*)nullptr, (const float*)nullptr, part, npix, C, L, 0));
     CN_LAUNCH_CHECK("cn_bn_train_fwd(partial)");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, beta,
-                       running_mean, running_var, save_mean, save_invstd, coef, save_scale_shift, momentum, eps);
+                       running_mean, running_var, save_mean, save_invstd, coef, save_scale_shift, momentum, eps, (float*)nullptr);
     CN_LAUNCH_CHECK("cn_bn_train_fwd(finalize)");
     BnLayout E = ew_layout(npix, C, V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, st,
                                                    (const T*)x, (const T*)residual, (T*)y, coef, coef + C, npix, C, E, relu));
     CN_LAUNCH_CHECK("cn_bn_train_fwd(apply)");
+    return CN_OK;
+}
+
+// ---- statistics sink: the kernel that PRODUCES x accumulates sum x / sum x^2 in its epilogue (N1: conv + BN + ReLU in training) ----
+// cn_bn_stats_arm(part, slots, C) arms the next forward launch of this host thread (cn_conv2d_fwd, cn_conv1x1_cat_fwd, cn_dcn_fwd,
+// cn_stem_conv_fwd): if the kernel it dispatches to has the hook, every workgroup adds the per-channel sums of the values it STORES
+// (after rounding to the output dtype) to row (workgroup % slots) of part[slots][2][C] with fp32 atomics, and cn_bn_stats_taken()
+// returns 1; otherwise nothing is touched and it returns 0 (the caller then lets cn_bn_train_fwd read x itself).  `part` must be
+// all-zero when armed; cn_bn_train_fwd_stats hands it back all-zero.
+static thread_local BnSink bn_sink_armed = {nullptr, 0, 0};
+static thread_local int bn_sink_taken_flag = 0;
+BnSink bn_sink_take() {
+    const BnSink s = bn_sink_armed;
+    bn_sink_armed = BnSink{nullptr, 0, 0};
+    bn_sink_taken_flag = 0;
+    return s;
+}
+void bn_sink_mark_taken() { bn_sink_taken_flag = 1; }
+
+extern "C" int cn_bn_stats_slots(void) { return BN_STAT_SLOTS; }
+extern "C" int cn_bn_stats_arm(float* part, int slots, int C) {
+    CN_CHECK_ARG(part && slots > 0 && slots <= BN_MAX_BLOCKS && C > 0 && C % 8 == 0 && ((uintptr_t)part & 15) == 0, "cn_bn_stats_arm: bad args");
+    bn_sink_armed = BnSink{part, slots, C};
+    bn_sink_taken_flag = 0;
+    return CN_OK;
+}
+extern "C" int cn_bn_stats_taken(void) { return bn_sink_taken_flag; }
+
+// cn_bn_train_fwd with the statistics already in `part` (filled through cn_bn_stats_arm by the kernel that wrote x): finalize
+// (+ running-stat update) and the apply pass only — x is read once instead of twice.  `part` is cleared on the way.
+extern "C" int cn_bn_train_fwd_stats(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                     float* save_scale_shift, float* part, int slots, int64_t npix, int C, float momentum, float eps,
+                                     int relu, int dtype, void* ws, size_t ws_bytes, void* stream) {
+    CN_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && ws && part && npix > 0 && C > 0 && slots > 0 && slots <= BN_MAX_BLOCKS,
+                 "cn_bn_train_fwd_stats: bad args");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0, "cn_bn_train_fwd_stats: C=%d must be a multiple of %d", C, V);
+    if (ws_bytes < cn_bn_workspace_bytes(npix, C)) { cn_set_error("cn_bn_train_fwd_stats: workspace too small"); return CN_EWORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = (float*)ws + (size_t)BN_MAX_BLOCKS * 2 * C;
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, slots, C, npix, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, coef, save_scale_shift, momentum, eps, part);
+    CN_LAUNCH_CHECK("cn_bn_train_fwd_stats(finalize)");
+    BnLayout E = ew_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(scale_shift_act_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, st,
+                                                   (const T*)x, (const T*)residual, (T*)y, coef, coef + C, npix, C, E, relu));
+    CN_LAUNCH_CHECK("cn_bn_train_fwd_stats(apply)");
     return CN_OK;
 }
 

@@ -72,6 +72,12 @@ __device__ static inline uint32_t pk_bf16(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 
+// statistics sink of the training-mode BatchNorm (bn.hip: cn_bn_stats_arm): part[slots][2][C] fp32, all-zero when armed
+#define BN_STAT_SLOTS 128
+struct BnSink { float* part; int slots; int C; };
+BnSink bn_sink_take();            // the sink armed for this host thread's next forward launch (disarms; {nullptr} when none)
+void bn_sink_mark_taken();        // called by a launch function whose kernel accumulates into the sink
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kDtype = CN_F32;

@@ -328,6 +328,9 @@ bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* 
                          int om_ld, int target_blocks, hipStream_t st);                     // dcn_bm.hip
 bool dcn_dx_bm_launch(const void* dy, const void* wpd0, const float* om, float* far, int* far_flag, void* dx, int N, int H, int W, int Ci,
                       int dy_ld, int om_ld, hipStream_t st);                                // dcn_bm.hip
+bool dcn_dom_bm_shape_ok(int Ci, int dy_ld, int x_ld, int om_ld);
+bool dcn_dom_bm_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, int dom_slabs, float* far, int* far_flag,
+                       int N, int H, int W, int Ci, int dy_ld, int x_ld, int om_ld, hipStream_t st);
 bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, const float* om, float* dom, int dom_slabs, float* far, int* far_flag,
                              int N, int H, int W, int Ci, int Co, int dy_ld, int x_ld, int om_ld, hipStream_t st);
 

@@ -545,6 +545,10 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
     CN_CHECK_ARG(dom_slabs == 1 || dom_slabs == cn_dcn_bwd_dom_slabs(Ci, dy_ld, dtype) ||
                      (dom_slabs == 0 && Ci == 64 && cn_dcn_bwd_dom_slabs(Ci, dy_ld, dtype) == 1 && dtype == CN_BF16 && (dy_ld == 64 || dy_ld == 128)),
                  "cn_dcn_bwd_dom: dom_slabs=%d (ask cn_dcn_bwd_dom_slabs; 0 = direct bf16 result, Ci == 64 only)", dom_slabs);
+    if (dtype == CN_BF16 && dcn_dom_bm_launch(dy, wpd2, x, om, dom, dom_slabs, dx_far, far_flag, N, H, W, Ci, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_dcn_bwd_dom(bm)");
+        return CN_OK;
+    }
     if (dtype == CN_BF16 && dcn_bwd_dom_tile_launch(dy, wpd2, x, om, dom, dom_slabs, dx_far, far_flag, N, H, W, Ci, Co, dy_ld, x_ld, om_ld, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_bwd_dom(tile)");
         return CN_OK;
@@ -584,7 +588,7 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
 // om_ld = 32); bench.py names its per-kernel roofline rows with it so that they agree with rocprofv3's kernel names.
 //   entry 0 = cn_dcn_fwd:     1000000 + NCB = dcn_fwd_bm_kernel<NCB>; 2000000 + BN = dcn_fwd_tile_kernel<BN>; 3000000 + BN*1000 + CK = dcn_fwd_kernel<bf16,BN,CK>
 //   entry 1 = cn_dcn_wgrad:   1 = dcn_wgrad_bm_kernel; BMW*1000000 + BNW*1000 + TAPS = dcn_wgrad_kernel<BMW,BNW,TAPS>
-//   entry 2 = cn_dcn_bwd_dom: COP = dcn_bwd_dom_kernel<COP> (0: the generic GEMM-epilogue kernel)
+//   entry 2 = cn_dcn_bwd_dom: 1000000 + COP = dcn_dom_bm_kernel<COP>; COP = dcn_bwd_dom_kernel<COP> (0: the generic GEMM-epilogue kernel)
 //   entry 3 = cn_dcn_bwd_dx:  1000000 + NCB = dcn_dx_bm_kernel<NCB>; 3000000 + BN*1000 + CK = dcn_bwd_dx_kernel<bf16,BN,CK>
 extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
     const int co32 = (Co + 31) / 32 * 32;
@@ -603,6 +607,7 @@ extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
         if (dcn_wgrad_bm_shape_ok(Ci, Ci, Co, Co, 32)) return 1;            // dcn_wgrad_bm_kernel
         return Co > 64 ? 128064003 : (taps3 ? 64064003 : 64064009);
     }
+    if (entry == 2 && dcn_dom_bm_shape_ok(Ci, Co, Ci, 32)) return 1000000 + Co;                        // dcn_dom_bm_kernel<COP>
     if (entry == 2) return (Ci % 64 == 0 && cn_dcn_bwd_dom_slabs(128, Co, CN_BF16) == 2) ? Co : 0;   // slabs(128, .) == 2 <=> the tile kernel takes this dy_ld
     if (entry == 3) {
         if (dcn_dx_bm_shape_ok(Ci, Co, 32)) return 1000000 + Ci / 32;
