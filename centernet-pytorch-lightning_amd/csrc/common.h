@@ -170,6 +170,71 @@ __device__ static inline unsigned wave_sum_u(unsigned v) {
     return v;
 }
 
+// ---- BatchNorm statistics in a producer's epilogue (sink protocol: bn.hip, cn_bn_stats_arm) ----
+// a thread adds the 8 bf16 values it is about to store (packed pairs w) to its running (sum, sum of squares)
+__device__ static inline void bn_stat_add(float (&s0)[8], float (&s1)[8], const uint32_t (&w)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = __uint_as_float(w[i] << 16), b = __uint_as_float(w[i] & 0xffff0000u);
+        s0[2 * i] += a; s1[2 * i] = fmaf(a, a, s1[2 * i]);
+        s0[2 * i + 1] += b; s1[2 * i + 1] = fmaf(b, b, s1[2 * i + 1]);
+    }
+}
+// Workgroup flush: every thread holds (s0, s1) of ONE 8-channel vector, threads with equal tid % CPR hold the same vector (CPR = a
+// power of two <= 64 = channel vectors per row of the workgroup's tile, first channel ch0).  Wave butterfly over the lanes that
+// share a vector, the NT / 64 waves meet in `lds` (>= (NT / 64) * CPR * 16 floats; barriers inside), then one fp32 atomic per
+// (channel, statistic) into row `slot % slots` of part[slots][2][C].  Channels >= ch_lim are dropped.
+template <int CPR, int NT>
+__device__ static inline void bn_stats_flush(float (&s0)[8], float (&s1)[8], float* lds, float* part, int slots, int C, int ch0, int ch_lim,
+                                             unsigned slot, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 32; o >= CPR; o >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] += __shfl_xor(s0[e], o, 64); s1[e] += __shfl_xor(s1[e], o, 64); }
+    }
+    __syncthreads();
+    if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lds[(wave * CPR + lane) * 16 + e] = s0[e]; lds[(wave * CPR + lane) * 16 + 8 + e] = s1[e]; }
+    }
+    __syncthreads();
+    if (tid < CPR * 16) {
+        const int cv = tid >> 4, e = tid & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) v += lds[(w * CPR + cv) * 16 + e];
+        const int ch = ch0 + cv * 8 + (e & 7);
+        if (ch < ch_lim) atomicAdd(part + ((int64_t)(slot % (unsigned)slots) * 2 + (e >> 3)) * C + ch, v);
+    }
+}
+
+// Flush for the 16-channel direct kernels (conv3x3_c16_kernel, stem7_fwd_kernel): lane = (pixel px = lane & 15, channel quad kc =
+// lane >> 4), a lane holds (sum, sum of squares) of channels 4 kc .. 4 kc + 3.  `red`: >= (NT / 64) * 32 floats of LDS.
+template <int NT>
+__device__ static inline void bn_stats_flush_c16(float (&s0)[4], float (&s1)[4], float* red, float* part, int slots, int C, int ch_lim,
+                                                 unsigned slot, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, kc = lane >> 4;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[r] += __shfl_xor(s0[r], o, 64); s1[r] += __shfl_xor(s1[r], o, 64); }
+    }
+    __syncthreads();
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[wave * 32 + 4 * kc + r] = s0[r]; red[wave * 32 + 16 + 4 * kc + r] = s1[r]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) v += red[w * 32 + tid];
+        const int ch = tid & 15;
+        if (ch < ch_lim) atomicAdd(part + ((int64_t)(slot % (unsigned)slots) * 2 + (tid >> 4)) * C + ch, v);
+    }
+}
+
 // dispatch on dtype
 #define CN_DISPATCH_DTYPE(dtype, T, ...)                                                            \
     do {                                                                                            \

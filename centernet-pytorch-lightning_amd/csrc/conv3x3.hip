@@ -213,6 +213,9 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvGeom g) {
             if (4 * kc + r < g.Co) bias4[r] = g.bias[4 * kc + r];
     }
 
+    // BatchNorm statistics of the stored values (sink protocol of bn.hip): this lane's four channels over every pixel it stores
+    const bool stats = g.bn_part != nullptr;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     const int segs = (g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS);
     const int64_t strips = (int64_t)g.N * g.H * segs;
 #pragma unroll 1
@@ -249,8 +252,18 @@ __global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvGeom g) {
                 uint2 o;
                 o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
                 *reinterpret_cast<uint2*>(Y + ((row * g.W) + wq) * g.y_ld + 4 * kc) = o;
+                if (stats) {
+                    const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
+                    const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
+                    s0[0] += a0; s0[1] += a1; s0[2] += a2; s0[3] += a3;
+                    s1[0] = fmaf(a0, a0, s1[0]); s1[1] = fmaf(a1, a1, s1[1]); s1[2] = fmaf(a2, a2, s1[2]); s1[3] = fmaf(a3, a3, s1[3]);
+                }
             }
         }
+    }
+    if (stats) {
+        __shared__ float red[4 * 32];
+        bn_stats_flush_c16<256>(s0, s1, red, g.bn_part, g.bn_slots, g.y_ld, g.Co, blockIdx.x, threadIdx.x);
     }
 }
 
@@ -358,10 +371,14 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
         const int64_t strips = (int64_t)g.N * g.H * ((g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS));
         int64_t blocks = (strips + 3) / 4;
         if (blocks > 4096) blocks = 4096;
+        if (g.bn_part) bn_sink_mark_taken();            // the direct 16-channel kernel has the statistics hook
         hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
         return true;
     }
     if (conv3x3_ws_launch(g, dtype, st)) return true;  // 64 input channels, enough tiles: weight-stationary persistent kernel
+    if (g.bn_part) {                                   // BN statistics sink: the LDS-staged epilogue has the hook
+        if (g.epi_tile) bn_sink_mark_taken(); else const_cast<ConvGeom&>(g).bn_part = nullptr;
+    }
     int bn = 32, bnb = (g.Co + 31) / 32;               // same rule as pick_tile(): fewest channel blocks
     for (int c : {64, 128}) {
         int nb = (g.Co + c - 1) / c;

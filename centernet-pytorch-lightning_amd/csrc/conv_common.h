@@ -40,6 +40,10 @@ struct ConvGeom {
     // 1x1 conv over the channel CONCATENATION of nsrc tensors of the same N,H,W (DLA Root, pose_dla_dcn.py:180-188): the K loop
     // walks the sources one after the other, so torch.cat(x, 1) is never materialised.  nsrc == 0: the single input `x`.
     int nsrc;
+    // BatchNorm statistics sink (training-mode conv + BN, bn.hip: cn_bn_stats_arm): every workgroup adds sum / sum of squares of the
+    // values it stores to part[workgroup % bn_slots][2][y_ld]; only the LDS-staged bf16 epilogue has the hook
+    float* bn_part;
+    int bn_slots;
     const void* xs[CN_MAX_SRC];
     int xs_c[CN_MAX_SRC];     // channels (= pixel pitch) of each source, multiples of the K slice
     int xs_k0[CN_MAX_SRC];    // first K index of each source
@@ -184,6 +188,11 @@ __device__ static inline void conv_epilogue_tile(const ConvGeom& g, f32x16_t (&a
     const int wgm = wave / WGN, wgn = wave % WGN;
     bf16_t* __restrict__ Y = reinterpret_cast<bf16_t*>(g.y);
     const bf16_t* __restrict__ Rr = reinterpret_cast<const bf16_t*>(g.res);
+    // BN statistics of the stored values: a thread visits the same channel vector in every pass (NT is a multiple of CPR)
+    const bool stats = g.bn_part != nullptr;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
 #pragma unroll
     for (int ii = 0; ii < MI; ++ii) {
         if (ii > 0) __syncthreads();
@@ -225,8 +234,16 @@ __device__ static inline void conv_epilogue_tile(const ConvGeom& g, f32x16_t (&a
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            Vec16<bf16_t>::store(Y + px * g.y_ld + ch, v);
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = pk_bf16(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<uint4*>(Y + px * g.y_ld + ch) = make_uint4(w[0], w[1], w[2], w[3]);
+            if (stats) bn_stat_add(s0, s1, w);
         }
+    }
+    if (stats) {
+        static_assert(NT % CPR == 0 && (CPR & (CPR - 1)) == 0 && CPR <= 64, "thread -> channel-vector map of the statistics");
+        bn_stats_flush<CPR, NT>(s0, s1, ot, g.bn_part, g.bn_slots, g.y_ld, n0, g.Co, blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u, tid);
     }
 }
 
@@ -319,7 +336,7 @@ void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st);
 bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
                          int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st);
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                       int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st);   // dcn_bm.hip: blend on the matrix cores
+                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st);   // dcn_bm.hip: blend on the matrix cores
 bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld);
 bool dcn_dx_bm_shape_ok(int Ci, int dy_ld, int om_ld);
 bool dcn_fwd_tile_shape_ok(int Ci, int x_ld, int Co, int y_ld);

@@ -389,6 +389,9 @@ static void launch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
     static const bool no_tile = getenv("CN_DISABLE_EPI_TILE") != nullptr;
     ConvGeom gg = g;
     gg.epi_tile = (!no_tile && conv_epi_tile_ok(g, sizeof(T) == 2 ? CN_BF16 : CN_F32)) ? 1 : 0;
+    if (gg.bn_part) {                                  // BN statistics sink: the LDS-staged epilogue has the hook
+        if (gg.epi_tile) bn_sink_mark_taken(); else gg.bn_part = nullptr;
+    }
     hipLaunchKernelGGL((conv_igemm_kernel<T, BN, BK>), grid, dim3(256), 0, st, gg);
 }
 
@@ -464,6 +467,10 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     CN_CHECK_ARG(!(residual && out_dtype != dtype), "cn_conv2d_fwd: residual needs out_dtype == dtype");
     int ncls = build_geom(g, KH, KW, stride, pad, transposed);
     if (ncls < 0) CN_UNSUPPORTED("cn_conv2d_fwd: kernel %dx%d stride %d not supported", KH, KW, stride);
+    {   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm): honoured by the kernels that have the hook
+        const BnSink sink = bn_sink_take();
+        if (sink.part && dtype == CN_BF16 && out_dtype == dtype && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
+    }
     if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);
     if (transposed && dtype == CN_BF16 && out_dtype == dtype && KH == 3 && KW == 3 && stride == 2 && pad == 1 && ((Ci == 32 && Co == 16) || (Ci == 64 && Co == 32)) &&
         OH == 2 * H && OW == 2 * W && !bias && !residual && !relu && dgrad_s2_c32to16_launch(g, (hipStream_t)stream)) {
@@ -511,6 +518,10 @@ extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2
     g.N = N; g.H = H; g.W = W; g.Ci = k; g.x_ld = cs[0]; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld; g.res_ld = res_ld;
     g.ktot = k; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu;
     const int ncls = build_geom(g, 1, 1, 1, 0, 0);
+    {   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm)
+        const BnSink sink = bn_sink_take();
+        if (sink.part && dtype == CN_BF16 && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
+    }
     // tile choice of dispatch_igemm with the K slice bounded by the smallest source granule
     ConvGeom gp = g;
     gp.Ci = div;                                // pick_tile() only looks at divisibility
@@ -632,7 +643,10 @@ extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const 
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld;
     g.ktot = 9 * Ci; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu; g.so = 1; g.sm = 1;
     g.dcn_om = om; g.dcn_omld = om_ld;
-    if (dtype == CN_BF16 && dcn_fwd_bm_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, (hipStream_t)stream)) {
+    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (the blend-matrix kernel has the hook)
+    const bool sink_ok = sink.part && dtype == CN_BF16 && sink.C == y_ld;
+    if (dtype == CN_BF16 && dcn_fwd_bm_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
+                                              sink.slots, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_fwd(bm)");
         return CN_OK;
     }

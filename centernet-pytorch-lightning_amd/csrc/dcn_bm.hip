@@ -39,6 +39,7 @@ extern "C" int bm_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, H
 struct BmGeom {
     const bf16_t* x; const float* om; const bf16_t* wp; const float* bias; bf16_t* y;
     int N, H, W, x_ld, y_ld, om_ld, ktot, Co, relu;
+    float* bn_part; int bn_slots;        // BatchNorm statistics sink (cn_bn_stats_arm), nullable
 };
 
 typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
@@ -353,13 +354,24 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
             }
         __builtin_amdgcn_wave_barrier();
         constexpr int CPP = 4 * NCB;                 // 16-byte chunks per pixel
+        // BN statistics of the stored values (sink protocol of bn.hip): a lane visits the same 8-channel chunk in every pass
+        const bool stats = g.bn_part != nullptr;
+        float s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
 #pragma unroll
         for (int i = 0; i < 32 * CPP / 64; ++i) {
             const int idx = lane + 64 * i, p = idx / CPP, ch = idx % CPP;
             const int oy = ty0 + grow + (p >> 3), ox = tx0 + gcol + (p & 7);
             const u32x4v o = *reinterpret_cast<const u32x4v*>(Y + p * 144 + ch * 16);
-            if (oy < g.H && ox < g.W) *reinterpret_cast<u32x4v*>(g.y + (img + (int64_t)oy * g.W + ox) * g.y_ld + ch * 8) = o;
+            if (oy < g.H && ox < g.W) {
+                *reinterpret_cast<u32x4v*>(g.y + (img + (int64_t)oy * g.W + ox) * g.y_ld + ch * 8) = o;
+                if (stats) { const uint32_t w[4] = {o[0], o[1], o[2], o[3]}; bn_stat_add(s0, s1, w); }
+            }
         }
+        if (stats)      // (the flush barriers first: every wave is done with its slice of the halo image, which becomes the scratch)
+            bn_stats_flush<CPP, 256>(s0, s1, reinterpret_cast<float*>(Xw), g.bn_part, g.bn_slots, g.y_ld, 0, g.Co,
+                                     blockIdx.x + blockIdx.y * gridDim.x, tid);
     }
     BM_STAMP(31);
 }
@@ -371,13 +383,15 @@ bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld) {
 
 // returns false when the shape is not handled here (caller falls back to the gather / LDS-tile kernels)
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                       int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st) {
+                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st) {
     if (!dcn_fwd_bm_shape_ok(Ci, x_ld, Co, y_ld, om_ld) || bias == nullptr || ((uintptr_t)om & 15) || ktot != 9 * 64 || N > 65535) return false;
     if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) return false;
     if ((uintptr_t)bias & 15) return false;
     BmGeom g;
     g.x = (const bf16_t*)x; g.om = om; g.wp = (const bf16_t*)wp; g.bias = bias; g.y = (bf16_t*)y;
     g.N = N; g.H = H; g.W = W; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.Co = Co; g.relu = relu;
+    g.bn_part = bn_part; g.bn_slots = bn_slots;
+    if (bn_part) bn_sink_mark_taken();
     const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N);
     if (Co == 64) {
         const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 64 * 16) + 512 + 4 * 32 * 29 * 4;

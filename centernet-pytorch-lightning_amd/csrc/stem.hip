@@ -192,7 +192,7 @@ bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
                            int OH, int OW, hipStream_t st);
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
-                      int stride, int OH, int OW, hipStream_t st);
+                      int stride, int OH, int OW, float* bn_part, int bn_slots, hipStream_t st);
 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
                         int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st) {
@@ -221,8 +221,10 @@ extern "C" int cn_stem_conv_fwd(const float* x, const float* w, const float* sca
     CN_CHECK_ARG(x && w && y && N > 0 && Co > 0, "cn_stem_conv_fwd: bad args");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
+    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm)
+    const bool sink_ok = sink.part && dtype == CN_BF16 && sink.C == Co;
     if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H + 6 - 7) / stride + 1 && OW == (W + 6 - 7) / stride + 1 &&
-        stem7_fwd_launch(x, w, scale, bias, relu, y, N, Ci, H, W, Co, stride, OH, OW, (hipStream_t)stream)) {
+        stem7_fwd_launch(x, w, scale, bias, relu, y, N, Ci, H, W, Co, stride, OH, OW, sink_ok ? sink.part : nullptr, sink.slots, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_stem_conv_fwd(mfma)");
         return CN_OK;
     }

@@ -220,7 +220,7 @@ template <int S>
 __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16_t* __restrict__ y,
                                                         int N, int Ci, int H, int W, int Co, int y_ld, int OH, int OW, int tiles_h,
                                                         int tiles_w, int iters, const float* __restrict__ scale, const float* __restrict__ bias,
-                                                        int relu) {
+                                                        int relu, float* __restrict__ bn_part, int bn_slots) {
     constexpr int HH = (C16_TH - 1) * S + 7, HWD = (C16_TW - 1) * S + 8, HP = HH * HWD;   // +1 column: the 8th (masked) kw slot
     constexpr int XV = (HP + 63) / 64;
     __shared__ __attribute__((aligned(16))) uint4 wfrag[ST7_MAXCB * 7 * 64];
@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
         wfrag[f] = make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7]));
     }
 
+    // BatchNorm statistics of the stored values (sink protocol of bn.hip; launched with Co <= 16 only: one channel block)
+    const bool stats = bn_part != nullptr;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     float rx[XV][3];
     auto gload = [&](int64_t tile) {
         const bool tv = tile < ntiles;
@@ -309,19 +312,29 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
                 }
                 if (tv && oh < OH && ow < OW && c0 < Co) {
                     bf16_t* dst = y + (((int64_t)n * OH + oh) * OW + ow) * y_ld + c0;
-                    if (c0 + 4 <= Co) *reinterpret_cast<uint2*>(dst) = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
+                    if (c0 + 4 <= Co) {
+                        const uint2 o = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
+                        *reinterpret_cast<uint2*>(dst) = o;
+                        if (stats) {
+                            const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
+                            const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
+                            s0[0] += a0; s0[1] += a1; s0[2] += a2; s0[3] += a3;
+                            s1[0] = fmaf(a0, a0, s1[0]); s1[1] = fmaf(a1, a1, s1[1]); s1[2] = fmaf(a2, a2, s1[2]); s1[3] = fmaf(a3, a3, s1[3]);
+                        }
+                    }
                     else
                         for (int q = 0; q < 4 && c0 + q < Co; ++q) dst[q] = f2bf(acc[q]);
                 }
             }
         }
     }
+    if (stats) bn_stats_flush_c16<256>(s0, s1, reinterpret_cast<float*>(halo), bn_part, bn_slots, y_ld, Co, blockIdx.x, tid);
 }
 
 // bf16 output, 7x7 / stride 1|2 / pad 3, Ci <= 3, Co a multiple of 4; more than 64 output channels (Hourglass: 128) run as
 // 64-channel chunks over the same image (the 3-channel fp32 input is small next to the output).
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
-                      int stride, int OH, int OW, hipStream_t st) {
+                      int stride, int OH, int OW, float* bn_part, int bn_slots, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
     if (disabled || Ci > 3 || (Co & 3) || (stride != 1 && stride != 2)) return false;
     const int tiles_h = cdiv(OH, C16_TH), tiles_w = cdiv(OW, C16_TW);
@@ -330,6 +343,7 @@ bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const 
     if (blocks > 2048) blocks = 2048;
     const int iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
     constexpr int CHUNK = 16 * ST7_MAXCB;
+    if (bn_part && Co <= 16 && (Co & 3) == 0) bn_sink_mark_taken(); else bn_part = nullptr;     // statistics hook: one channel block only
     for (int c0 = 0; c0 < Co; c0 += CHUNK) {
         const int cc = Co - c0 < CHUNK ? Co - c0 : CHUNK;
         const float* wc = w + (int64_t)c0 * Ci * 49;
@@ -337,9 +351,9 @@ bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const 
         const float* bc = bias ? bias + c0 : nullptr;
         bf16_t* yc = (bf16_t*)y + c0;
         if (stride == 1)
-            hipLaunchKernelGGL(stem7_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, yc, N, Ci, H, W, cc, Co, OH, OW, tiles_h, tiles_w, iters, sc, bc, relu);
+            hipLaunchKernelGGL(stem7_fwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, yc, N, Ci, H, W, cc, Co, OH, OW, tiles_h, tiles_w, iters, sc, bc, relu, bn_part, bn_slots);
         else
-            hipLaunchKernelGGL(stem7_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, yc, N, Ci, H, W, cc, Co, OH, OW, tiles_h, tiles_w, iters, sc, bc, relu);
+            hipLaunchKernelGGL(stem7_fwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, yc, N, Ci, H, W, cc, Co, OH, OW, tiles_h, tiles_w, iters, sc, bc, relu, bn_part, bn_slots);
     }
     return true;
 }

@@ -168,7 +168,7 @@ class DeformConv(nn.Module):
         if not bn.training and not (torch.is_grad_enabled() and (self.conv.weight.requires_grad or x.requires_grad)):
             s, b = bn.folded()
             return self.conv.infer(x, s, b, True)
-        return bn(self.conv(x), None, True)
+        return bn(self.conv(x, bn_stats=bn.training), None, True)
 
 
 class IDAUp(nn.Module):

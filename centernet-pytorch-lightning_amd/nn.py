@@ -31,16 +31,17 @@ class Conv2d(nn.Module):
         co, ci, k, _ = self.weight.shape
         return f"{ci}, {co}, kernel_size={k}, stride={self.stride}, padding={self.padding}, bias={self.bias is not None}"
 
-    def forward(self, x, relu=False, mask_dx=False, defer_relu_bwd=False):
+    def forward(self, x, relu=False, mask_dx=False, defer_relu_bwd=False, bn_stats=False):
+        """bn_stats: the output goes straight into a training-mode BatchNorm2d (ops.BnStats: statistics from the conv epilogue)"""
         if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
-            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu, mask_dx, defer_relu_bwd)
+            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu, mask_dx, defer_relu_bwd, bn_stats=bn_stats)
         return self.infer(x, None, None, None, relu)
 
-    def with_skip(self, x):
+    def with_skip(self, x, bn_stats=False):
         """-> (conv(x), x) for a residual connection around this conv: the skip path's gradient is added in the epilogue of this
         conv's data-gradient kernel (training; otherwise just the pair)."""
         if torch.is_grad_enabled() and x.requires_grad and self.stride == 1:
-            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, False, False, False, True)
+            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, False, False, False, True, bn_stats=bn_stats)
         return self.forward(x), x
 
     def infer(self, x, scale, shift, residual, relu, out_dtype=None):
@@ -99,7 +100,7 @@ class BatchNorm2d(nn.BatchNorm2d):
 def conv_bn_act_skip(conv, bn, x):
     """(ReLU(BN(conv(x))), x) — the first half of a residual block whose identity path is its own input."""
     if bn.training and torch.is_grad_enabled() and x.requires_grad and conv.stride == 1:
-        c, skip = conv.with_skip(x)
+        c, skip = conv.with_skip(x, bn_stats=True)
         return bn(c, None, True), skip
     return conv_bn_act(conv, bn, x), x
 
@@ -113,7 +114,7 @@ def cat_conv_bn_act(conv, bn, xs, residual=None, relu=True):
         return conv_bn_act(conv, bn, ops.concat(list(xs)), residual, relu)
     grad = torch.is_grad_enabled() and (conv.weight.requires_grad or any(t.requires_grad for t in xs))
     if bn.training or grad:
-        return bn(ops.conv1x1_cat(xs, conv.weight), residual, relu)
+        return bn(ops.conv1x1_cat(xs, conv.weight, bn_stats=bn.training), residual, relu)
     s, b = bn.folded()                              # eval: BN folded into the packed weights, one launch
     key = ("cat", xs[0].dtype, conv.weight._version, ops.WeightsEpoch.value, s.data_ptr(), s._version)
     if conv._cache.get("k") != key:
@@ -125,7 +126,7 @@ def cat_conv_bn_act(conv, bn, xs, residual=None, relu=True):
 def conv_bn_act(conv, bn, x, residual=None, relu=True):
     """conv -> BN -> (+residual) -> ReLU.  One fused kernel in eval/no-grad mode."""
     if bn.training:
-        return bn(conv(x), residual, relu)
+        return bn(conv(x, bn_stats=True), residual, relu)      # statistics from the conv kernel's epilogue where it has the hook
     if torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):
         return bn(conv(x), residual, relu)          # eval-mode BN but gradients wanted: unfused affine pass
     s, b = bn.folded()
@@ -141,8 +142,9 @@ class StemConv(nn.Module):
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
 
-    def forward(self, img, dtype):
-        return ops.StemConvFn.apply(img, self.weight, self.stride, self.padding, dtype)
+    def forward(self, img, dtype, bn_stats=False):
+        y = ops.StemConvFn.apply(img, self.weight, self.stride, self.padding, dtype, bn_stats)
+        return ops.BnStats.pop(y) if bn_stats else y
 
     def infer(self, img, dtype, scale, shift, relu):
         """no-grad path with the following eval-mode BN (+ReLU) folded into the kernel's epilogue"""
@@ -152,7 +154,7 @@ class StemConv(nn.Module):
 def stem_bn_act(stem, bn, img, dtype, relu=True):
     """stem conv -> BN -> ReLU; one fused kernel in eval / no-grad mode"""
     if bn.training or (torch.is_grad_enabled() and stem.weight.requires_grad):
-        return bn(stem(img, dtype), None, relu)
+        return bn(stem(img, dtype, bn_stats=bn.training), None, relu)
     s, b = bn.folded()
     return stem.infer(img, dtype, s, b, relu)
 
@@ -202,8 +204,9 @@ class DCN(nn.Module):
 
         self._cache = {}
 
-    def forward(self, x):
-        return ops.DCNv2Fn.apply(x, self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias)
+    def forward(self, x, bn_stats=False):
+        y = ops.DCNv2Fn.apply(x, self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias, bn_stats)
+        return ops.BnStats.pop(y) if bn_stats else y
 
     def infer(self, x, scale, shift, relu):
         """No-grad path with the following BN folded in: offset conv -> sampling -> ONE 1x1 GEMM (+shift, ReLU)."""

@@ -67,6 +67,51 @@ def _far_buffer(shape, device):
     return buf
 
 
+_BN_SINKS = {}
+
+
+class BnStats:
+    """Training-mode conv + BN: the producing kernel accumulates the batch statistics of its output in its epilogue (sink protocol of
+    cn_bn_stats_arm).  One persistent all-zero sink per (channels, device): producer and consumer are ordered on the launch
+    stream, and cn_bn_train_fwd_stats hands the sink back cleared.  `launch` arms the sink right before ONE C-ABI launch and
+    remembers whether the kernel took it; the op wrappers pick that up (`pop`) and tag the output tensor for `batch_norm_act`."""
+    enabled = not _os.environ.get("CN_DISABLE_BN_EPILOGUE_STATS")
+    last = None
+
+    @classmethod
+    def sink(cls, C, device):
+        key = (int(C), str(device))
+        buf = _BN_SINKS.get(key)
+        if buf is None:
+            buf = _BN_SINKS[key] = torch.zeros((int(_hip.query("cn_bn_stats_slots")), 2, int(C)), dtype=torch.float32, device=device)
+        return buf
+
+    @classmethod
+    def launch(cls, want, y, name, *args):
+        cls.last = None
+        if not (want and cls.enabled and y.dtype == torch.bfloat16):
+            return call(name, *args)
+        part = cls.sink(y.shape[-1], y.device)
+        _hip.query("cn_bn_stats_arm", part.data_ptr(), part.shape[0], part.shape[2])
+        call(name, *args)
+        if _hip.query("cn_bn_stats_taken"):
+            cls.last = part
+
+    @classmethod
+    def pop(cls, y):
+        """tag y with the sink its producer filled (None: no hook in that kernel)"""
+        part, cls.last = cls.last, None
+        if part is not None:
+            y._bn_part = part
+        return y
+
+    @classmethod
+    def reset(cls):
+        """after an aborted step: a producer may have filled a sink nobody consumed"""
+        for buf in _BN_SINKS.values():
+            buf.zero_()
+
+
 class GradReady:
     """Deposit notifications for the data-parallel exchange.  Inside a TrainStep most parameter gradients never pass through
     autograd: weight-gradient kernels (side stream) and the BN backward (launch stream) write straight into the flat gradient
@@ -256,14 +301,14 @@ def conv_out(h, k, s, p):
 _SMALLK_WIDTHS = (64, 128, 256, 512, 1024, 2048)
 
 
-def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None):
+def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None, bn_stats=False):
     N, H, W, Ci = x.shape
     cp = rup(Co, 16)
     out_dtype = out_dtype or x.dtype
     y = torch.empty((N, OH, OW, cp), dtype=out_dtype, device=x.device)    # the kernels write the channel padding as zeros
-    call("cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
-         residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
-         dtype_code(x.dtype), dtype_code(out_dtype))
+    BnStats.launch(bn_stats, y, "cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
+                   residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
+                   dtype_code(x.dtype), dtype_code(out_dtype))
     return y
 
 
@@ -283,7 +328,7 @@ class Conv2dFn(Function):
     """nn.Conv2d (+bias, +ReLU) on NHWC.  weight fp32 [Co,Ci,KH,KW]; x channels = rup(Ci,16) (zero padded)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, mask_dx=False, defer_relu_bwd=False, passthrough=False):
+    def forward(ctx, x, weight, bias, stride, pad, relu, mask_dx=False, defer_relu_bwd=False, passthrough=False, bn_stats=False):
         """mask_dx: x is the output of a fused-ReLU producer that was built with defer_relu_bwd=True; this layer's data
         gradient is then masked by (x > 0) in its own epilogue (relu mode 2) and the producer skips its cn_relu_bwd pass.
         passthrough: also return x itself (for a residual connection around this conv): the gradient of that second use
@@ -294,7 +339,7 @@ class Conv2dFn(Function):
         assert Cx == rup(Ci, 16), f"conv input has {Cx} channels, weight expects {Ci}"
         wp = pack_weight(weight, 1, x.dtype)
         OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
-        y = _igemm(x, wp, bias, None, Co, KH, KW, stride, pad, False, relu, OH, OW)
+        y = _igemm(x, wp, bias, None, Co, KH, KW, stride, pad, False, relu, OH, OW, bn_stats=bn_stats)
         ctx.save_for_backward(x, weight, y if (relu and not defer_relu_bwd) else None)
         ctx.cfg = (stride, pad, relu and not defer_relu_bwd, bias is not None)
         ctx.mask_dx = mask_dx
@@ -349,7 +394,7 @@ class Conv2dFn(Function):
                 dx = dx + dskip
         elif dskip is not None:
             dx = dskip
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 def _cat_args(xs):
@@ -361,13 +406,13 @@ def _cat_args(xs):
     return (*ptrs, *chans, len(xs))
 
 
-def conv1x1_cat_raw(xs, wp, bias, residual, Co, relu):
+def conv1x1_cat_raw(xs, wp, bias, residual, Co, relu, bn_stats=False):
     """y = act(conv1x1(cat(xs, channel)) + bias + residual) without the concatenated tensor (one launch)"""
     N, H, W, _ = xs[0].shape
     cp = rup(Co, 16)
     y = torch.empty((N, H, W, cp), dtype=xs[0].dtype, device=xs[0].device)
-    call("cn_conv1x1_cat_fwd", *_cat_args(xs), wp, bias, residual, y, N, H, W, Co, cp,
-         residual.shape[-1] if residual is not None else 0, int(relu), dtype_code(xs[0].dtype))
+    BnStats.launch(bn_stats, y, "cn_conv1x1_cat_fwd", *_cat_args(xs), wp, bias, residual, y, N, H, W, Co, cp,
+                   residual.shape[-1] if residual is not None else 0, int(relu), dtype_code(xs[0].dtype))
     return y
 
 
@@ -378,11 +423,11 @@ class Conv1x1CatFn(Function):
     weight fp32 [Co, sum C_s, 1, 1]; every C_s a multiple of 16."""
 
     @staticmethod
-    def forward(ctx, weight, *xs):
+    def forward(ctx, weight, bn_stats, *xs):
         Co = weight.shape[0]
         xs = tuple(t.contiguous() for t in xs)
         assert sum(t.shape[-1] for t in xs) == weight.shape[1], "Root conv: channel counts of the children do not add up"
-        y = conv1x1_cat_raw(xs, pack_weight(weight, 1, xs[0].dtype), None, None, Co, False)
+        y = conv1x1_cat_raw(xs, pack_weight(weight, 1, xs[0].dtype), None, None, Co, False, bn_stats=bn_stats)
         ctx.save_for_backward(weight, *xs)
         ctx.order = SideGrads.next_order()
         return y
@@ -420,11 +465,11 @@ class Conv1x1CatFn(Function):
             for i, (c, k0) in enumerate(zip(chans, offs)):
                 if ctx.needs_input_grad[1 + i]:
                     dxs[i] = _igemm(dy, wpd[k0:k0 + c], None, None, c, 1, 1, 1, 0, True, False, H, W)
-        return (dw, *dxs)
+        return (dw, None, *dxs)
 
 
-def conv1x1_cat(xs, weight):
-    return Conv1x1CatFn.apply(weight, *xs)
+def conv1x1_cat(xs, weight, bn_stats=False):
+    return BnStats.pop(Conv1x1CatFn.apply(weight, bn_stats, *xs)) if bn_stats else Conv1x1CatFn.apply(weight, False, *xs)
 
 
 class ConvTranspose2dFn(Function):
@@ -480,14 +525,14 @@ class StemConvFn(Function):
     """7x7 conv on the NCHW fp32 image (3 channels) -> NHWC activations; no data gradient (it is the input)."""
 
     @staticmethod
-    def forward(ctx, img, weight, stride, pad, dtype):
+    def forward(ctx, img, weight, stride, pad, dtype, bn_stats=False):
         Co, Ci, KH, KW = weight.shape
         N, _, H, W = img.shape
         OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
         img = img.contiguous()
         y = torch.empty((N, OH, OW, Co), dtype=dtype, device=img.device)
-        call("cn_stem_conv_fwd", img, weight.detach().contiguous(), None, None, y, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, 0,
-             dtype_code(dtype))
+        BnStats.launch(bn_stats, y, "cn_stem_conv_fwd", img, weight.detach().contiguous(), None, None, y, N, Ci, H, W, Co, KH, KW, stride,
+                       pad, OH, OW, 0, dtype_code(dtype))
         ctx.save_for_backward(img, weight)
         ctx.cfg = (stride, pad)
         ctx.order = SideGrads.next_order()
@@ -506,10 +551,10 @@ class StemConvFn(Function):
                      dtype_code(dy.dtype))
                 GradReady.note(weight)
             SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy, claims=(weight,))
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         dw = torch.zeros_like(weight, dtype=torch.float32)
         call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))
-        return None, dw, None, None, None
+        return None, dw, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ batch norm
@@ -517,15 +562,21 @@ class BatchNormActFn(Function):
     """Training-mode BatchNorm2d + optional residual add + optional ReLU (one fused apply pass)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, relu, part=None):
+        """part: the statistics sink the kernel that produced x filled in its epilogue (BnStats) — x is then read once, by the
+        apply pass, instead of twice"""
         C = x.shape[-1]
         npix = x.numel() // C
         y = torch.empty_like(x)
         stats = torch.empty((4, C), dtype=torch.float32, device=x.device)     # mean, invstd, scale, shift
         mean, invstd, ss = stats[0], stats[1], stats[2:]
         ws, n = _bn_ws(npix, C, x.device)
-        call("cn_bn_train_fwd", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd, ss,
-             npix, C, BN_MOMENTUM, BN_EPS, int(relu), dtype_code(x.dtype), ws, n)
+        if part is not None:
+            call("cn_bn_train_fwd_stats", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd, ss,
+                 part, part.shape[0], npix, C, BN_MOMENTUM, BN_EPS, int(relu), dtype_code(x.dtype), ws, n)
+        else:
+            call("cn_bn_train_fwd", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd, ss,
+                 npix, C, BN_MOMENTUM, BN_EPS, int(relu), dtype_code(x.dtype), ws, n)
         # ReLU backward mask: without a residual input it is recomputed from x and the saved affine (y is not re-read)
         need_y = relu and residual is not None
         ctx.save_for_backward(x, y if need_y else None, gamma, stats)
@@ -549,12 +600,12 @@ class BatchNormActFn(Function):
             call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, gamma.grad, beta.grad, 1, npix, C,
                  int(relu), dtype_code(x.dtype), ws, n)
             GradReady.note(gamma, beta)
-            return dx, None, None, None, None, dres, None
+            return dx, None, None, None, None, dres, None, None
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, dgamma, dbeta, 0, npix, C, int(relu),
              dtype_code(x.dtype), ws, n)
-        return dx, dgamma, dbeta, None, None, dres, None
+        return dx, dgamma, dbeta, None, None, dres, None, None
 
 
 class ScaleShiftActFn(Function):
@@ -791,7 +842,7 @@ class DCNv2Fn(Function):
     weight [Co,Ci,3,3], bias [Co], om_weight [27,Ci,3,3], om_bias [27]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, om_weight, om_bias):
+    def forward(ctx, x, weight, bias, om_weight, om_bias, bn_stats=False):
         Co, Ci, _, _ = weight.shape
         N, H, W, _ = x.shape
         dt = dtype_code(x.dtype)
@@ -807,7 +858,7 @@ class DCNv2Fn(Function):
             # fused: bilinear sampling writes the MFMA operand tile in LDS, no column tensor
             cp = rup(Co, 16)
             y = (torch.empty if cp == Co else torch.zeros)((N, H, W, cp), dtype=x.dtype, device=x.device)
-            call("cn_dcn_fwd", x, om, wp, bias.detach(), y, N, H, W, Ci, Ci, Co, cp, om.shape[-1], 0, dt)
+            BnStats.launch(bn_stats, y, "cn_dcn_fwd", x, om, wp, bias.detach(), y, N, H, W, Ci, Ci, Co, cp, om.shape[-1], 0, dt)
             col = None
         ctx.save_for_backward(x, om, col, weight, om_weight)
         ctx.params = (bias, om_weight, om_bias)
@@ -910,7 +961,7 @@ class DCNv2Fn(Function):
         dx = torch.empty_like(x)
         call("cn_conv2d_fwd", dom, wpo, None, dx_s, dx, N, H, W, om.shape[-1], om.shape[-1], H, W, Ci, Ci, Ci,
              3, 3, 1, 1, 1, 0, dt, dt)
-        return dx, dw, db, dw_om, db_om
+        return dx, dw, db, dw_om, db_om, None
 
 
 # ------------------------------------------------------------------------------------------------ losses
@@ -1032,8 +1083,12 @@ class GatherL1Fn(Function):
 
 
 # ------------------------------------------------------------------------------------------------ functional aliases
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, defer_relu_bwd=False, passthrough=False):
-    return Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd, passthrough)
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, defer_relu_bwd=False, passthrough=False, bn_stats=False):
+    """bn_stats: the output feeds a training-mode BatchNorm — ask the kernel for the batch statistics (BnStats)"""
+    out = Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd, passthrough, bn_stats)
+    if bn_stats:
+        BnStats.pop(out[0] if passthrough else out)
+    return out
 
 
 def conv_transpose2d(x, weight, stride=2, pad=1):
@@ -1041,7 +1096,7 @@ def conv_transpose2d(x, weight, stride=2, pad=1):
 
 
 def batch_norm_act(x, bn, residual=None, relu=True):
-    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu)
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, relu, getattr(x, "_bn_part", None))
 
 
 def max_pool(x, k, stride, pad=0):

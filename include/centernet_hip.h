@@ -108,6 +108,21 @@ int cn_stem_conv_wgrad(const float* x_nchw, const void* dy, float* dw, int N, in
 
 /* ---- batch norm (nn.BatchNorm2d, momentum 0.1) + ReLU + residual add ---------------------- */
 size_t cn_bn_workspace_bytes(int64_t npix, int C);
+/* Training-mode conv + BN (pose_dla_dcn.py:55-68, 435-454; msra_resnet.py:29-58): the kernel that PRODUCES the BN input also
+ * accumulates the batch statistics.  cn_bn_stats_arm(part, slots, C) arms the NEXT forward launch of the calling host thread
+ * (cn_conv2d_fwd, cn_conv1x1_cat_fwd, cn_dcn_fwd, cn_stem_conv_fwd): when the kernel it dispatches to has the hook (bf16, y_ld == C), every
+ * workgroup adds per-channel sum / sum of squares of the values it stores (after rounding to bf16) to row (workgroup % slots) of
+ * part[slots][2][C] (fp32 atomics) and cn_bn_stats_taken() then returns 1; otherwise `part` is untouched and it returns 0 (the
+ * caller falls back to cn_bn_train_fwd, which reads x itself).  `part` must be all-zero when armed (slots <= 1024, use
+ * cn_bn_stats_slots()); cn_bn_train_fwd_stats = cn_bn_train_fwd without the statistics pass over x: finalize from `part`
+ * (handed back all-zero) + the apply pass. */
+int cn_bn_stats_slots(void);
+int cn_bn_stats_arm(float* part, int slots, int C);
+int cn_bn_stats_taken(void);
+int cn_bn_train_fwd_stats(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                          float* save_scale_shift, float* part, int slots, int64_t npix, int C, float momentum, float eps,
+                          int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
 /* training forward: batch statistics over npix rows; y = act(gamma*(x-mean)*invstd + beta [+ residual]);
  * updates running stats (unbiased var) in place; saves mean / invstd for backward.  save_scale_shift (nullable,
  * fp32 [2][C]) receives the per-channel affine the apply pass used (y = act(fma(x, scale, shift) [+ residual])). */

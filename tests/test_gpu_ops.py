@@ -653,3 +653,76 @@ def test_dcn_far_buffer_is_left_clean():
     buf = o._FAR_BUFFERS[((1, 20, 24, 64), str(x.device))]
     assert float(buf.abs().max()) == 0.0
     assert float(x.grad.float().abs().sum()) > 0.0
+
+
+BN_STAT_PRODUCERS = [  # kind, N, H, W, Ci, Co, k, stride  (which kernel: see the comment)
+    ("conv", 2, 16, 16, 128, 128, 3, 1),      # halo-tile 3x3 kernel (conv3x3s1_kernel), LDS-staged epilogue
+    ("conv", 2, 13, 11, 256, 256, 3, 1),      # ragged tiles
+    ("conv", 2, 16, 16, 64, 128, 3, 2),       # implicit GEMM (stride 2)
+    ("conv", 1, 12, 20, 32, 64, 1, 1),        # implicit GEMM 1x1
+    ("cat", 2, 8, 8, (128, 128), 128, 1, 1),  # DLA Root: conv1x1 over a concatenation
+    ("dcn", 2, 12, 20, 64, 64, 3, 1),         # blend-matrix DCNv2 forward
+    ("dcn", 1, 9, 7, 64, 32, 3, 1),
+    ("conv", 2, 9, 70, 16, 16, 3, 1),         # direct 16-channel kernel (DLA level0)
+    ("stem", 2, 37, 41, 3, 16, 7, 1),         # 7x7 stem on the NCHW fp32 image (DLA base_layer)
+]
+
+
+@pytest.mark.parametrize("cfg", BN_STAT_PRODUCERS)
+def test_bn_statistics_from_the_producer_epilogue(cfg):
+    """N1 (north_star: conv + BN + ReLU fused, training mode): the producing kernel fills the statistics sink with sum / sum of
+    squares of the bf16 values it stores; cn_bn_train_fwd_stats then equals cn_bn_train_fwd on the same tensor and hands the sink
+    back all-zero.  Reference: msra_resnet.py:29-58 / pose_dla_dcn.py:55-68, 435-454 (conv -> nn.BatchNorm2d in training)."""
+    from centernet_amd import nn as hnn
+    o = ops()
+    kind, N, H, W, Ci, Co, k, stride = cfg
+    dt = torch.bfloat16
+    torch.manual_seed(3)
+    if kind == "cat":
+        xs = [to_nhwc(torch.randn(N, c, H, W), dt).requires_grad_(True) for c in Ci]
+        conv = hnn.Conv2d(sum(Ci), Co, 1).to(DEV)
+        produce = lambda flag: o.conv1x1_cat(xs, conv.weight, bn_stats=flag)
+    elif kind == "stem":
+        img = torch.randn(N, Ci, H, W, device=DEV)
+        stem = hnn.StemConv(Ci, Co, k, stride, k // 2).to(DEV)
+        produce = lambda flag: stem(img, dt, bn_stats=flag)
+    elif kind == "dcn":
+        x = to_nhwc(torch.randn(N, Ci, H, W), dt).requires_grad_(True)
+        dcn = hnn.DCN(Ci, Co).to(DEV)
+        torch.nn.init.normal_(dcn.conv_offset_mask.weight, std=0.02)
+        produce = lambda flag: dcn(x, bn_stats=flag)
+    else:
+        x = to_nhwc(torch.randn(N, Ci, H, W), dt).requires_grad_(True)
+        conv = hnn.Conv2d(Ci, Co, k, stride, k // 2).to(DEV)
+        produce = lambda flag: conv(x, bn_stats=flag)
+    y0 = produce(False)
+    assert getattr(y0, "_bn_part", None) is None
+    y1 = produce(True)
+    part = getattr(y1, "_bn_part", None)
+    assert part is not None, "this producer's kernel is expected to have the statistics hook"
+    assert torch.equal(y0.detach(), y1.detach()), "the hook must not change the stored values"
+    yf = y1.detach().float().reshape(-1, y1.shape[-1])
+    got = part.double().sum(0).cpu()                                        # [2][C]
+    ref = torch.stack([yf.double().sum(0), (yf.double() ** 2).sum(0)]).cpu()
+    scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-6)
+    assert float(((got - ref).abs() / scale).max()) < 1e-5, "sum / sum of squares of the stored values"
+    # BN on top: fused statistics vs the stand-alone statistics pass
+    bn_a, bn_b = hnn.BatchNorm2d(y1.shape[-1]).to(DEV).train(), hnn.BatchNorm2d(y1.shape[-1]).to(DEV).train()
+    za = bn_a(y1, None, True)                                               # consumes (and clears) the sink
+    assert float(part.abs().max()) == 0.0, "the sink is handed back all-zero"
+    zb = bn_b(y0, None, True)
+    close(za, zb, dt, "BN(conv) with epilogue statistics vs stand-alone statistics", scale=float(zb.detach().float().abs().max()))
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-4, atol=1e-6)
+    za.float().square().sum().backward()                                    # backward runs through the same saved statistics
+
+
+def test_bn_statistics_hook_can_be_declined(monkeypatch):
+    """kernels without the hook (weight-stationary 3x3, fp32 compute) report `not taken`: BN then reads x itself"""
+    from centernet_amd import nn as hnn
+    x = to_nhwc(torch.randn(1, 16, 8, 8), torch.float32).requires_grad_(True)
+    conv = hnn.Conv2d(16, 32, 3, 1, 1).to(DEV)
+    y = conv(x, bn_stats=True)
+    assert getattr(y, "_bn_part", None) is None
+    bn = hnn.BatchNorm2d(32).to(DEV).train()
+    z = bn(y, None, True)
+    assert bool(torch.isfinite(z).all())
