@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3s1_kernel(const ConvGeom g) {
 // each lane stores 4 consecutive channels of one pixel (8 bytes), a group again being one contiguous 512-byte run.
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define C16_GROUPS 4
-__global__ __launch_bounds__(256) void conv3x3_c16_kernel(const ConvGeom g) {
+__global__ __launch_bounds__(256, 4) void conv3x3_c16_kernel(const ConvGeom g) {     // <= 128 registers: four waves per SIMD (an HBM stream)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, kc = lane >> 4;
     const int half = kc & 1, tsel = kc >> 1;

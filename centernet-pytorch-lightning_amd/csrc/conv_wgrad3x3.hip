@@ -40,13 +40,21 @@ __device__ static inline bf16x8_t tr_frag16(const bf16_t* tile, int pitch, int c
 }
 
 // TAPS = 9: one workgroup accumulates all taps;  TAPS = 3: blockIdx.z selects the tap row kh.
-template <int BMW, int BNW, int TAPS>
-__global__ __launch_bounds__(256) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
+// SLAB: instead of fp32 atomics into the packed gradient, every workgroup stores its accumulators as ONE private slab (fragment
+// order: a wave's store instruction is 256 contiguous bytes) and wgrad3x3_reduce_kernel sums the slabs of a (channel tile, tap
+// row) straight into the parameter-layout gradient.  Measured (tools/wgrad_bench.py, 64->64 @128^2, batch 64): the atomic flush
+// of the 147 KB accumulator tile costs 0.25 us PER WORKGROUP, serialised chip-wide (device-scope fp32 atomics execute at the
+// memory side, ~600 GB/s) — 65 us of a 135 us launch with 256 workgroups, 98 of 166 us with the 384 the train step uses.
+// NW = 8 (512 threads, 4 x 2 waves): all nine taps of a 128 x 64 channel tile with 144 accumulator registers per wave — dY is then
+// read ONCE per launch instead of once per tap row (the 64 -> 256 head convs: 2.4 GB -> 0.8 GB of operand traffic per launch).
+template <int BMW, int BNW, int TAPS, bool SLAB = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
+    constexpr int NT = NW * 64;
     constexpr int YP = BMW + 32, XP = BNW + 32;               // +64 B: the 4 rows of a transposing read hit disjoint banks
     constexpr int YCG = BMW / 8, XCG = BNW / 8;
-    constexpr int YV = (W3_TH * W3_TW * YCG + 255) / 256;     // 16-byte loads per thread
-    constexpr int XV = (W3_HP * XCG + 255) / 256;
-    constexpr int WM = BMW / 2, WN = BNW / 2;                 // 2 x 2 waves
+    constexpr int YV = (W3_TH * W3_TW * YCG + NT - 1) / NT;   // 16-byte loads per thread
+    constexpr int XV = (W3_HP * XCG + NT - 1) / NT;
+    constexpr int WM = BMW / (NW / 2), WN = BNW / 2;          // (NW / 2) x 2 waves
     constexpr int MI = WM / 32, NJ = WN / 32;
     constexpr int HROWS = TAPS == 9 ? W3_TH + 2 : W3_TH;      // halo rows staged
 
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
         const int64_t img = (int64_t)n * g.H * g.W;
 #pragma unroll
         for (int v = 0; v < YV; ++v) {
-            const int idx = tid + v * 256;
+            const int idx = tid + v * NT;
             const int px = idx / YCG, c = co0 + (idx % YCG) * 8;
             const int oh = th0 + px / W3_TW, ow = tw0 + px % W3_TW;
             uint4 val = make_uint4(0, 0, 0, 0);
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
         }
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
-            const int idx = tid + v * 256;
+            const int idx = tid + v * NT;
             const int hp = idx / XCG, c = ci0 + (idx % XCG) * 8;
             const int hr = hp / W3_HW;                         // staged halo row: image row th0 - 1 + kh0 + hr
             const int ih = th0 - 1 + kh0 + hr, iw = tw0 - 1 + hp % W3_HW;
@@ -104,12 +112,12 @@ __global__ __launch_bounds__(256) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
     auto lstore = [&]() {
 #pragma unroll
         for (int v = 0; v < YV; ++v) {
-            const int idx = tid + v * 256;
+            const int idx = tid + v * NT;
             if (idx < W3_TH * W3_TW * YCG) *reinterpret_cast<uint4*>(yt + (idx / YCG) * YP + (idx % YCG) * 8) = ry[v];
         }
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
-            const int idx = tid + v * 256;
+            const int idx = tid + v * NT;
             if (idx < HROWS * W3_HW * XCG) *reinterpret_cast<uint4*>(xt + (idx / XCG) * XP + (idx % XCG) * 8) = rx[v];
         }
     };
@@ -139,6 +147,19 @@ __global__ __launch_bounds__(256) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
         }
     }
 
+    if constexpr (SLAB) {
+        constexpr int PER_WAVE = TAPS * MI * NJ * 16 * 64;
+        float* sl = g.dwp + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) * (NW * PER_WAVE) + wave * PER_WAVE + lane;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sl[(((t * MI + i) * NJ + j) * 16 + r) * 64] = acc[t][i][j][r];
+        return;
+    }
     // D rows = co: (r&3) + 8*(r>>2) + 4*(lane>>5); D col = ci: lane&31
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -156,6 +177,77 @@ __global__ __launch_bounds__(256) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
                 }
             }
     }
+}
+
+// Sum of the k-split slabs of wgrad3x3s1_kernel<.., SLAB = true> into the PARAMETER layout dw[Co][Ci][3][3] (fp32; accumulate != 0
+// adds, e.g. straight into the flat gradient buffer).  One workgroup per 64-float slab row (= one accumulator register of one
+// wave): 64 lanes x 4 groups of k-splits, the groups meet in LDS.  Deterministic (fixed summation order).
+template <int BMW, int BNW, int TAPS, int NW>
+__global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int gx, int ci_tiles,
+                                                              int Co, int Ci, int accumulate) {
+    constexpr int WM = BMW / (NW / 2), WN = BNW / 2, MI = WM / 32, NJ = WN / 32;
+    constexpr int ROWS_PER_WAVE = TAPS * MI * NJ * 16, TILE = NW * ROWS_PER_WAVE * 64;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int row = blockIdx.x;                                     // slab row: (wave, t, i, j, r)
+    const int64_t part = (int64_t)blockIdx.y * gridDim.z + blockIdx.z;
+    const int64_t nparts = (int64_t)gridDim.y * gridDim.z;
+    const float* p = slabs + part * TILE + (int64_t)row * 64 + lane;
+    float v = 0.f;
+    int s = sg;
+    for (; s + 12 < gx; s += 16) {                                  // four independent loads in flight
+        const float a = p[(int64_t)s * nparts * TILE], b = p[(int64_t)(s + 4) * nparts * TILE];
+        const float c = p[(int64_t)(s + 8) * nparts * TILE], d = p[(int64_t)(s + 12) * nparts * TILE];
+        v += (a + b) + (c + d);
+    }
+    for (; s < gx; s += 4) v += p[(int64_t)s * nparts * TILE];
+    red[sg][lane] = v;
+    __syncthreads();
+    if (sg != 0) return;
+    v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int wave = row / ROWS_PER_WAVE, rem = row % ROWS_PER_WAVE;
+    const int r = rem & 15, j = (rem >> 4) % NJ, i = (rem >> 4) / NJ % MI, t = (rem >> 4) / (NJ * MI);
+    const int co0 = ((int)blockIdx.y / ci_tiles) * BMW, ci0 = ((int)blockIdx.y % ci_tiles) * BNW;
+    const int co = co0 + (wave >> 1) * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int ci = ci0 + (wave & 1) * WN + j * 32 + (lane & 31);
+    const int tap = TAPS == 9 ? t : (int)blockIdx.z * 3 + t;
+    if (co < Co && ci < Ci) {
+        float* d = dw + ((int64_t)co * Ci + ci) * 9 + tap;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+template <int BMW, int BNW, int TAPS>
+static size_t w3_slab_plan(Wgrad3Geom& g) {              // fills the tiling fields; -> bytes of slab workspace
+    const int co_tiles = cdiv(g.Co, BMW);
+    g.ci_tiles = cdiv(g.Ci, BNW);
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
+    // the 8-wave all-taps tile runs one workgroup per CU and its slab is 295 KB: one round of workgroups (64 -> 256 @128^2: 298 us
+    // with 256 workgroups, 368 with 384)
+    const int target = (BMW == 128 && TAPS == 9 && cn_wgrad_target_blocks() > 256) ? 256 : cn_wgrad_target_blocks();
+    int64_t want = (target + par - 1) / par;
+    if (want > ntiles) want = ntiles;
+    if (want < 1) want = 1;
+    g.tiles_per_block = (int)((ntiles + want - 1) / want);
+    const int64_t gx = (ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
+    return (size_t)gx * par * TAPS * BMW * BNW * sizeof(float);
+}
+
+template <int BMW, int BNW, int TAPS, int NW = 4>
+static void launch_w3_slab(Wgrad3Geom& g, float* dw, int accumulate, hipStream_t st) {
+    (void)w3_slab_plan<BMW, BNW, TAPS>(g);
+    const int co_tiles = cdiv(g.Co, BMW);
+    const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
+    const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
+    const int hrows = TAPS == 9 ? W3_TH + 2 : W3_TH;
+    const size_t smem = ((size_t)W3_TH * W3_TW * (BMW + 32) + (size_t)hrows * W3_HW * (BNW + 32)) * sizeof(bf16_t);
+    if (smem > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)wgrad3x3s1_kernel<BMW, BNW, TAPS, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const dim3 grid(gx, co_tiles * g.ci_tiles, TAPS == 9 ? 1 : 3);
+    hipLaunchKernelGGL((wgrad3x3s1_kernel<BMW, BNW, TAPS, true, NW>), grid, dim3(NW * 64), smem, st, g);
+    hipLaunchKernelGGL((wgrad3x3_reduce_kernel<BMW, BNW, TAPS, NW>), dim3(TAPS * BMW * BNW / 64, grid.y, grid.z), dim3(256), 0, st, g.dwp, dw, gx,
+                       g.ci_tiles, g.Co, g.Ci, accumulate);
 }
 
 template <int BMW, int BNW, int TAPS>
@@ -187,6 +279,32 @@ bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, 
     g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
     if (Co > 64) launch_w3<128, 64, 3>(g, st);      // 68.6 KB LDS, 96 accumulator registers
     else launch_w3<64, 64, 9>(g, st);               // 59 KB LDS, 144 accumulator registers
+    return true;
+}
+
+
+// Slab form of the above: `slabs` is scratch (wgrad3x3s1_slab_bytes), the result lands in the parameter-layout gradient dw.
+size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld) {
+    static const bool disabled = getenv("CN_DISABLE_WGRAD3X3") != nullptr || getenv("CN_DISABLE_WGRAD_SLABS") != nullptr;
+    if (disabled || Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) return 0;
+    Wgrad3Geom g;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co;
+    g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
+    static const bool taps9 = getenv("CN_WGRAD3X3_WIDE_TAPS3") == nullptr;      // A/B: the 4-wave 128 x 64 tile with one tap row per workgroup
+    return Co > 64 ? (taps9 ? w3_slab_plan<128, 64, 9>(g) : w3_slab_plan<128, 64, 3>(g)) : w3_slab_plan<64, 64, 9>(g);
+}
+
+bool wgrad3x3s1_slab_launch(const void* x, const void* dy, float* slabs, float* dw, int accumulate, int N, int H, int W, int Ci, int x_ld,
+                            int Co, int dy_ld, hipStream_t st) {
+    if (wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld) == 0) return false;
+    Wgrad3Geom g;
+    g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.dwp = slabs;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.ktot = 9 * Ci;
+    g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
+    static const bool taps9 = getenv("CN_WGRAD3X3_WIDE_TAPS3") == nullptr;
+    if (Co > 64 && taps9) launch_w3_slab<128, 64, 9, 8>(g, dw, accumulate, st);     // 8 waves, all taps: dY read once
+    else if (Co > 64) launch_w3_slab<128, 64, 3>(g, dw, accumulate, st);
+    else launch_w3_slab<64, 64, 9>(g, dw, accumulate, st);
     return true;
 }
 

@@ -323,6 +323,29 @@ def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=None):
     return dwp, db
 
 
+def _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=None, want_bias=False, db_into=None):
+    """Weight (+ bias) gradient in PARAMETER layout: -> (dw fp32 [Co,Ci,KH,KW] — `into` when given, accumulated in place —, db).
+    Shapes whose kernel has the slab form (cn_conv2d_wgrad_direct: bf16 3x3 / stride 1) need neither a pre-zeroed packed gradient
+    nor an unpack launch; everything else goes through cn_conv2d_wgrad + cn_unpack_wgrad."""
+    N, H, W, Cx = x.shape
+    _, OH, OW, ld = dy.shape
+    dt = dtype_code(x.dtype)
+    if Cx == Ci and x.dtype == torch.bfloat16:
+        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes", N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW, stride, pad, dt))
+        if n:
+            ws = _hip.workspace(n, x.device, "wgrad_slabs")
+            dw = into if into is not None else torch.empty((Co, Ci, KH, KW), dtype=torch.float32, device=x.device)
+            db = db_into if db_into is not None else (torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None)
+            call("cn_conv2d_wgrad_direct", x, dy, dw, db, int(into is not None), ws, n, N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW,
+                 stride, pad, dt)
+            return dw, db
+    dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=db_into)
+    if into is not None:
+        return unpack_wgrad(dwp, Co, Ci, KH, KW, into=into), db
+    dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
+    return dw, db
+
+
 # ------------------------------------------------------------------------------------------------ conv
 class Conv2dFn(Function):
     """nn.Conv2d (+bias, +ReLU) on NHWC.  weight fp32 [Co,Ci,KH,KW]; x channels = rup(Ci,16) (zero padded)."""
@@ -364,13 +387,11 @@ class Conv2dFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1] and Cx == Ci and SideGrads.usable(weight, ctx.bias_ref):
             def side_work(x=x, dy=dy, bias=ctx.bias_ref):
-                dwp, _ = _wgrad(x, dy, Co, KH, KW, stride, pad, False, db_into=bias.grad if has_bias else None)
-                unpack_wgrad(dwp, Co, Ci, KH, KW, into=weight.grad)
+                _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=weight.grad, db_into=bias.grad if has_bias else None)
                 GradReady.note(weight, bias)
             SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), x, dy, claims=(weight, ctx.bias_ref))
         elif ctx.needs_input_grad[1]:
-            dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, has_bias and ctx.needs_input_grad[2])
-            dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
+            dw, db = _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, want_bias=has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0]:
             wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
             if Cx != Ci:
@@ -460,10 +481,10 @@ class Conv1x1CatFn(Function):
                 wgrads(dw)
                 dw = dw.view(Co, Ct, 1, 1)
         dxs = [None] * len(xs)
-        if any(ctx.needs_input_grad[1:]):
+        if any(ctx.needs_input_grad[2:]):             # inputs: weight, bn_stats flag, *xs
             wpd = pack_weight(weight, 0, dt)          # rows = input channel (of the concatenation), k = rup(Co, 16)
             for i, (c, k0) in enumerate(zip(chans, offs)):
-                if ctx.needs_input_grad[1 + i]:
+                if ctx.needs_input_grad[2 + i]:
                     dxs[i] = _igemm(dy, wpd[k0:k0 + c], None, None, c, 1, 1, 1, 0, True, False, H, W)
         return (dw, None, *dxs)
 
@@ -950,13 +971,11 @@ class DCNv2Fn(Function):
         # offset/mask conv backward (its data gradient is added to the sampling gradient through `residual`)
         if side:
             def side_work_om(x=x, dom=dom, p1=ctx.params[1], p2=ctx.params[2]):
-                dwp_om, _ = _wgrad(x, dom, 27, 3, 3, 1, 1, False, db_into=p2.grad)
-                unpack_wgrad(dwp_om, 27, Ci, 3, 3, into=p1.grad)
+                _wgrad_param(x, dom, 27, Ci, 3, 3, 1, 1, into=p1.grad, db_into=p2.grad)
                 GradReady.note(p1, p2)
             SideGrads.submit(side_work_om, x, dom, claims=(ctx.params[1], ctx.params[2]))
         else:
-            dwp_om, db_om = _wgrad(x, dom, 27, 3, 3, 1, 1, True)
-            dw_om = unpack_wgrad(dwp_om, 27, Ci, 3, 3)
+            dw_om, db_om = _wgrad_param(x, dom, 27, Ci, 3, 3, 1, 1, want_bias=True)
         wpo = pack_weight(om_weight, 0, x.dtype)              # rows = Ci, k = tap*32 + c
         dx = torch.empty_like(x)
         call("cn_conv2d_fwd", dom, wpo, None, dx_s, dx, N, H, W, om.shape[-1], om.shape[-1], H, W, Ci, Ci, Ci,

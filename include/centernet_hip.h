@@ -91,6 +91,17 @@ int cn_conv2d_variant(int Ci, int Co, int KH, int KW, int stride, int pad, int d
 int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
                     int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                     int KH, int KW, int stride, int pad, int dtype, void* stream);
+/* The same gradient straight into the PARAMETER layout dw[Co][Ci][KH][KW] (fp32, accumulate != 0 adds — e.g. into the flat
+ * gradient buffer), for the shapes whose kernel has the slab form (bf16, 3x3 / stride 1 / pad 1, Ci > 16): every workgroup
+ * stores its split-K partial as a private slab in `ws` and one reduction launch sums them in a fixed order — no fp32 atomics
+ * (device-scope atomics execute at the memory side: 0.25 us per workgroup flush, serialised chip-wide), no pre-zeroed packed
+ * gradient, no cn_unpack_wgrad launch.  cn_conv2d_wgrad_direct_bytes = scratch size, 0 when the shape is not handled (use
+ * cn_conv2d_wgrad + cn_unpack_wgrad).  db: as in cn_conv2d_wgrad (accumulated into, nullable). */
+size_t cn_conv2d_wgrad_direct_bytes(int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld, int KH, int KW,
+                                    int stride, int pad, int dtype);
+int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
+                           int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                           int KH, int KW, int stride, int pad, int dtype, void* stream);
 
 /* Tunable: number of workgroups the split-K weight-gradient kernels spread over (default 1536 = ~6 per CU).  A host that
  * runs them on a second stream beside the data-gradient chain lowers it (~384) so they stay in the background. */

@@ -276,6 +276,63 @@ def test_network_bf16_vs_oracle(arch, size):
         assert rel < (2e-2 if k in ("loss", "hm_loss") else 5e-2), (k, rel)
 
 
+@pytest.mark.parametrize("which", ["dla_level3_tree", "ida_up_dcn", "res_layer"])
+def test_bf16_gradient_paths_of_subnetworks(which):
+    """A gradient PATH lost (or doubled) in the bf16-only plumbing — epilogue statistics, slab-form weight gradients, the Root conv
+    over a concatenation, skip gradients folded into data-gradient epilogues — shows as a relative L2 error of ~1 on the tensors
+    behind it.  The fp32 goldens cannot see bf16-only code, and on the WHOLE network bf16 gradients of a random-weight net are
+    dominated by cancellation noise (measured: median relative L2 0.5 on ResNet-18, 1.1 on DLA-34 — tools/grad_modes.py), so the
+    check runs on sub-networks a few layers deep: every parameter's and the input's bf16 gradient within 35 % (L2) of this
+    package's own fp32-mode gradient (the mode the reference-made goldens pin), same weights and inputs, training-mode BN.
+    Measured worst tensors: two ResNet blocks 9 %, IDAUp with two DCNv2 layers 12 %, DLA level-3 tree (8 convs, 2 Roots) 22 %; with
+    the Root's first child's gradient dropped (the bug this test was written after) everything upstream reads ~100 %."""
+    from centernet_amd import ops
+    from centernet_amd.models.backbones import pose_dla_dcn as dla
+    from centernet_amd.models.backbones import msra_resnet as res
+
+    def build():
+        torch.manual_seed(11)
+        if which == "dla_level3_tree":       # nested trees, project, two Roots (one over four children), max-pools, residual blocks
+            return dla.Tree(2, dla.BasicBlock, 64, 128, 2, level_root=True), (4, 32, 32, 64)
+        if which == "ida_up_dcn":            # DeformConv (DCNv2 + BN + ReLU) -> depthwise up-conv -> merge -> DeformConv
+            return dla.IDAUp(64, [64, 128], [1, 2]), None
+        return torch.nn.Sequential(res.BasicBlock(64, 64), res.BasicBlock(64, 64)), (4, 16, 16, 64)
+
+    grads = {}
+    for dt in (torch.float32, torch.bfloat16):
+        net, shape = build()
+        rng.fill_state_dict(net, 9)
+        net = net.to(DEV).train()
+        g = torch.Generator().manual_seed(5)
+        if which == "ida_up_dcn":
+            for m in net.modules():          # non-zero sampling offsets (the reference zero-initialises conv_offset_mask)
+                if hasattr(m, "conv_offset_mask"):
+                    torch.nn.init.normal_(m.conv_offset_mask.weight, std=0.02)
+            xs = [ops.mark_nhwc(torch.randn(4, 16, 16, 64, generator=g).to(DEV).to(dt).requires_grad_(True)),
+                  ops.mark_nhwc(torch.randn(4, 8, 8, 128, generator=g).to(DEV).to(dt).requires_grad_(True))]
+            layers = list(xs)
+            net(layers, 0, 2)
+            y, ins = layers[-1], xs
+        else:
+            x = ops.mark_nhwc(torch.randn(*shape, generator=g).to(DEV).to(dt).requires_grad_(True))
+            y, ins = net(x), [x]
+        r = torch.randn(y.shape, generator=g).to(DEV)
+        (y.float() * r).sum().backward()
+        grads[dt] = {**{n: p.grad.detach().double() for n, p in net.named_parameters() if p.grad is not None},
+                     **{f"input{i}": t.grad.detach().double() for i, t in enumerate(ins)}}
+    rel = {}
+    scale = max(float(v.norm()) / v.numel() ** 0.5 for v in grads[torch.float32].values())
+    for n, g32 in grads[torch.float32].items():
+        assert n in grads[torch.bfloat16], f"{n}: no bf16 gradient"
+        if float(g32.norm()) / g32.numel() ** 0.5 < 1e-6 * scale:     # conv biases in front of a BatchNorm: exactly zero gradient
+            continue
+        rel[n] = float((grads[torch.bfloat16][n] - g32).norm()) / float(g32.norm())
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:4]
+    print(f"{which}: bf16 vs fp32-mode gradients, relative L2 over {len(rel)} tensors: median {np.median(list(rel.values())):.3f}, "
+          f"worst {[(n, round(v, 3)) for n, v in worst]}")
+    assert worst[0][1] < 0.35, worst
+
+
 # ------------------------------------------------------------------------------------------------ backbone <-> head seam
 class _TorchBackbone(torch.nn.Module):
     """A third-party backbone as the reference's registry expects one (models/__init__.py:6-19): plain torch, NCHW fp32 in,
