@@ -32,8 +32,10 @@
 #define DB_MG 4
 #define DB_WR (DB_TH + 2 * DB_MG)        // 16 halo rows
 #define DB_WC (DB_TW + 2 * DB_MG)        // 24 halo columns
-#define DB_PIX 144                       // bytes per halo pixel: 64 bf16 + 16 (16 consecutive pixels' 16-byte slots tile all 64 banks)
-#define DB_ROW (DB_WC * DB_PIX)
+#define DB_PIX 128                       // bytes per halo pixel (64 bf16); the eight 16-byte chunks of pixel number n are XOR-swizzled
+#define DB_ROW (DB_WC * DB_PIX)          // with (n >> 1) & 7: the 16 consecutive pixels of an operand read then tile all 64 banks
+// LDS byte offset of 16-byte chunk c (0..7) of halo pixel n
+__device__ static inline int db_chunk(int n, int c) { return n * DB_PIX + ((c ^ ((n >> 1) & 7)) << 4); }
 
 #ifdef DOMB_PROBE   // development build only (tools/dom_probe.py): cycle stamps of wave 0 of the first workgroups
 __device__ unsigned long long domb_ts[1024 * 40];
@@ -61,8 +63,13 @@ template <int COP>   // channels of dY (contraction length of the first product)
 __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
     constexpr int KS = COP / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const Xw = smem;                                              // [16][24] pixels x 144 B
+    unsigned char* const Xw = smem;                                              // [16][24] pixels x 128 B (chunk-swizzled)
     float* const OmAll = reinterpret_cast<float*>(smem + DB_WR * DB_ROW);        // 4 waves x [32 px][29]
+    // COP == 64: the tap's W fragments are shared through LDS (two buffers of 8 fragments x 1 KB): loaded from global memory by ONE
+    // wave each (two fragments per wave) instead of by all four — the fragment loads (32 rows x 32 bytes per instruction) kept the
+    // CU's vector-memory pipe busy for a seventh of the kernel (350 vs 405 us with tap 0's fragments reused for every tap)
+    constexpr bool WLDS = COP == 64;
+    unsigned char* const Ws = smem + DB_WR * DB_ROW + 4 * 32 * 29 * 4;           // WLDS: 2 x [2 cb][KS][64 lanes] x 16 B
 
     DB_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -117,11 +124,8 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
     // 32 cb + swap_bits_2_3(r), so that accumulator registers 8a .. 8a+7 of lane half hh are channels 32 cb + 16 a + 8 hh .. +7
     const int wrow = (nl & ~12) | ((nl & 4) << 1) | ((nl & 8) >> 1);
     const bf16_t* const wbase = g.wd2 + ((int64_t)ci0 + wrow) * COP + 8 * hh;
-    // COP == 64: two register sets, the next tap's fragments are requested a whole tap ahead (an L2 round trip under load is about as
-    // long as a tap; with one set the first taps of every tile waited 2 000 - 2 600 cycles for them).  COP == 128: one set (128 more
-    // registers do not fit), re-loaded right after its last use.
-    constexpr bool WDB = COP == 64;
-    u32x4w wfa[2][KS], wfb[WDB ? 2 : 1][WDB ? KS : 1];
+    // COP == 128: one register set, re-loaded right after its last use (two would not fit)
+    u32x4w wfa[2][KS];
     auto wload = [&](u32x4w (&wf)[2][KS], int tap) {
 #ifdef DOMB_NOW      // timing experiment only: every tap uses tap 0's fragments (no per-tap global loads)
         if (tap > 1) return;
@@ -132,7 +136,21 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) wf[cb][s] = *reinterpret_cast<const u32x4w*>(p + (int64_t)32 * cb * COP + 16 * s);
     };
-    wload(wfa, 0);
+    // WLDS: this wave's two fragments (index f = 2 wave + i = cb * KS + s) of a tap, global -> registers -> LDS buffer
+    u32x4w wq[2];
+    auto wq_load = [&](int tap) {
+        const bf16_t* p = wbase + (int64_t)tap * g.Ci * COP;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = 2 * wave + i;
+            wq[i] = *reinterpret_cast<const u32x4w*>(p + (int64_t)32 * (f / KS) * COP + 16 * (f % KS));
+        }
+    };
+    auto wq_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4w*>(Ws + buf * (2 * KS * 1024) + ((2 * wave + i) * 64 + lane) * 16) = wq[i];
+    };
+    if (WLDS) wq_load(0); else wload(wfa, 0);
 
     // ---- geometry table of the wave's 32 pixels: entry 2k / 2k+1 = sampling position of tap k in IMAGE coordinates, formed like the
     //      reference forms it (one fp32 add of the integer position h - 1 + ky and the offset: floor / fraction are then bit-identical
@@ -171,23 +189,27 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * 256;
-        st16(Xw + (v >> 3) * DB_PIX + (v & 7) * 16, hv[i]);
+        st16(Xw + db_chunk(v >> 3, v & 7), hv[i]);
     }
-    __syncthreads();        // the only barrier: from here on a wave reads the halo image and its own table
+    if (WLDS) wq_store(0);
+    __syncthreads();        // COP == 128: the only barrier — from here on a wave reads the halo image and its own table
     DB_STAMP(1);
+    if (WLDS) wq_load(1);
 
     float* const orow = Om + nl * 29;
     float ro[3] = {orow[0], orow[1], orow[18]};
     // A-operand address of the second product: lane (q, hh) reads window pixel (row q >> 4 of the pair, column q & 15), 8 channels
-    const unsigned char* const xbase = Xw + ((grow + (nl >> 4)) * DB_WC + gcol + (nl & 15)) * DB_PIX + 16 * hh;
+    // (pixel number n = row * 24 + column: (n >> 1) & 7 does not depend on the row PAIR, so one address per k-step serves every pair)
+    const unsigned char* xop[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xop[s] = Xw + db_chunk((grow + (nl >> 4)) * DB_WC + gcol + (nl & 15), 2 * s + hh);
     const int prow = nl >> 3, pcol = nl & 7;                // this lane's pixel inside the group
     const int wy_org = ty0 + grow - DB_MG, wx_org = tx0 + gcol - DB_MG;      // image coordinates of the group's window origin
     const bool direct_far = g.far != nullptr;
 
-    auto tap_body = [&](const int tap, u32x4w (&wf)[2][KS], u32x4w (&wnext)[2][KS]) {
+    auto tap_body = [&](const int tap, u32x4w (&wf)[2][KS]) {
         // ---- geometry of (own pixel, tap) ----
         DB_STAMP(2 + 4 * tap);
-        if (WDB) wload(wnext, tap < 8 ? tap + 1 : 8);
         const float pyr = ro[0], pxr = ro[1], m = ro[2];
         {
             const int nt = tap < 8 ? tap + 1 : 8;
@@ -213,9 +235,17 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
         const bool any = pm != 0;
         pm &= pm - 1;
         u32x4w xa[4];
-        if (WDB) {
+        u32x4w wloc[2][KS];
+        if (WLDS) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xbase + j * (2 * DB_ROW) + 32 * s);
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) wloc[cb][s] = *reinterpret_cast<const u32x4w*>(Ws + (tap & 1) * (2 * KS * 1024) + ((cb * KS + s) * 64 + lane) * 16);
+        }
+        u32x4w (&W)[2][KS] = WLDS ? wloc : wf;
+        if (WLDS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xop[s] + j * (2 * DB_ROW));
         }
 
         // ---- dcol^T[ci][p] = W_k^T dY^T ----
@@ -228,11 +258,11 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                dc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[cb][s]), __builtin_bit_cast(bf16x8_t, dyf[s]), dc[cb], 0, 0, 0);
-        if (!WDB) {                                          // single set: re-loaded right after its last use
+                dc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, W[cb][s]), __builtin_bit_cast(bf16x8_t, dyf[s]), dc[cb], 0, 0, 0);
+        if (!WLDS) {                                         // single register set: re-loaded right after its last use
             wload(wf, tap < 8 ? tap + 1 : 8);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xbase + j * (2 * DB_ROW) + 32 * s);
+            for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xop[s] + j * (2 * DB_ROW));
         }
         // ---- column weights of this lane's 8 window columns (register i of a pair row <-> column 8 (i >> 2) + 4 hh + (i & 3)); VALU
         //      work placed behind the MFMAs it does not depend on ----
@@ -272,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
                 if (more) { j = __builtin_ctz(pm); pm &= pm - 1; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xbase + j * (2 * DB_ROW) + 32 * s);
+                for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xop[s] + j * (2 * DB_ROW));
                 __builtin_amdgcn_sched_barrier(0);
                 const int d0 = 2 * jc - wr;                  // row 2 jc is corner row d0 (0 = top, 1 = bottom) of this pixel, if either
                 const float wy0 = d0 == 0 ? 1.f - ly : (d0 == 1 ? ly : 0.f), wy1 = d0 == -1 ? 1.f - ly : (d0 == 0 ? ly : 0.f);
@@ -352,17 +382,14 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
         if (hh == 0) {
             orow[2 * tap] = sy * m; orow[2 * tap + 1] = sx * m; orow[18 + tap] = sm * m * (1.f - m);
         }
-    };
-    if constexpr (WDB) {
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap += 2) {
-            tap_body(tap, wfa, wfb);
-            if (tap + 1 < 9) tap_body(tap + 1, wfb, wfa);
+        if (WLDS) {           // next tap's fragments into the other buffer (last read a tap ago), the tap after that on its way
+            wq_store((tap + 1) & 1);
+            __syncthreads();
+            wq_load(tap < 7 ? tap + 2 : 8);
         }
-    } else {
+    };
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) tap_body(tap, wfa, wfa);
-    }
+    for (int tap = 0; tap < 9; ++tap) tap_body(tap, wfa);
 
     // ---- one coalesced row of 32 values per pixel (27 results + zero padding) ----
     DB_STAMP(38);
@@ -414,7 +441,7 @@ bool dcn_dom_bm_launch(const void* dy, const void* wd2, const void* x, const flo
     const int64_t tiles = (int64_t)((H + DB_TH - 1) / DB_TH) * ((W + DB_TW - 1) / DB_TW) * N;
     if (tiles > 0x7fffffff) return false;
     const dim3 grid((unsigned)tiles, blocks);
-    const size_t smem = (size_t)DB_WR * DB_ROW + 4 * 32 * 29 * 4;
+    const size_t smem = (size_t)DB_WR * DB_ROW + 4 * 32 * 29 * 4 + (dy_ld == 64 ? 2 * 8 * 1024 : 0);
     if (dy_ld == 64) {
         (void)hipFuncSetAttribute((const void*)dcn_dom_bm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(dcn_dom_bm_kernel<64>, grid, dim3(256), smem, st, g);

@@ -17,6 +17,10 @@ KERNELS = {
     "conv3x3_ws_kernel<64, false, 0, true>": ("conv3x3_ws_kernel<64>", CSRC + "conv3x3_ws.hip",
                                               "weight-stationary kernel, ReLU variant = the three 64->256 head convs: 134 MB in (x 1.27 halo, x 4 channel blocks through L2) + 537 MB out"),
     "dcn_bwd_dom_kernel<64>": ("dcn_bwd_dom_kernel<64>", CSRC + "dcn_fused.hip", "offset/mask gradient of the 64-output-channel DCN layers"),
+    "dcn_dom_bm_kernel<64>": ("dcn_dom_bm_kernel<64>", CSRC + "dcn_dom_bm.hip", "offset/mask gradient of the DCN layers with 64 output channels (matrix-core corner dots)"),
+    "dcn_dx_bm_kernel<2>": ("dcn_dx_bm_kernel<2>", CSRC + "dcn_bm.hip", "data gradient of the 64->64 DCN layers"),
+    "dcn_fwd_bm_kernel<2>": ("dcn_fwd_bm_kernel<2>", CSRC + "dcn_bm.hip", "forward of the 64->64 DCN layers"),
+    "dcn_wgrad_bm_kernel": ("dcn_wgrad_bm_kernel", CSRC + "dcn_bm.hip", "weight gradient of the DCN layers (launch mix)"),
     "topk_map128_kernel": ("topk_map128_kernel<true>", CSRC + "topk_stream.h", "B=64, C=80, 128x128 fp32 maps: 335.5 MB algorithmic read (SURVEY 8d)"),
     "bn_bwd_apply_kernel<unsigned short>": ("bn_bwd_apply_kernel<bf16>", CSRC + "bn.hip", "launch mix of all BN layers"),
 }
@@ -26,7 +30,7 @@ for l in raw:
     m = re.match(r"(FETCH_SIZE|WRITE_SIZE) (.+) launches (\d+) avg_kib ([0-9.e+-]+)", l)
     if m:
         vals[(m.group(2), m.group(1))] = (int(m.group(3)), float(m.group(4)))
-out = {"recipe": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --no-cpu-baseline --no-probe --no-inference --steps 3 --warmup 1 ; "
+out = {"recipe": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --no-cpu-baseline --no-probe --no-inference --no-extras --steps 3 --warmup 1 ; "
                  "same with --pmc WRITE_SIZE (separate passes, counters only). Both counters are in KiB. gfx950 correction per /opt/skills/guides/MI355X_MICROARCH.md: "
                  "FETCH_SIZE reports half of wide streaming reads -> doubled. WRITE_SIZE calibrated in round 1 on the 64->256 head conv launch: 524288 KiB reported = its 512 MiB output exactly.",
        "raw": raw, "kernels": {}}

@@ -2,30 +2,34 @@
 # Collect the round's evidence on the GPU box into gpurun_out/prof_<tag>/ (copy what is to be judged into profiles/):
 #   bench line + per-launch table, rocprofv3 kernel-trace summary of the same bench command, FETCH_SIZE / WRITE_SIZE of the
 #   dominant kernel in two separate counter-only passes, isolated op timings.
-# usage: tools/profile_round.sh r02
-tag=${1:-r02}
+# usage: tools/profile_round.sh r03
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 --probe-detail $out/ops_by_shape.txt > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/bench_line.json
 rm -rf $out/kt
-timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o p -- python bench.py --no-cpu-baseline --no-inference --steps 10 --warmup 3 > $out/kt.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o p -- python bench.py --no-cpu-baseline --no-inference --no-extras --steps 10 --warmup 3 > $out/kt.log 2>&1
 db=$(ls $out/kt/*.db 2>/dev/null | head -1)
-[ -n "$db" ] && { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-inference --steps 10 --warmup 3   ($tag; 3 warm-up + 10 timed graph-replayed steps + 2 eagerly launched probe steps; durations include side-stream contention)"; python tools/rocpd_stats.py $db 70; } > $out/bench_kernel_stats.txt
+[ -n "$db" ] && { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-inference --no-extras --steps 10 --warmup 3   ($tag; 3 warm-up + 10 timed graph-replayed steps + 2 eagerly launched probe steps; durations include side-stream contention)"; python tools/rocpd_stats.py $db 70; } > $out/bench_kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $out/pmc
-  timeout 900 rocprofv3 --kernel-trace --pmc $c -d $out/pmc -o p -- python bench.py --no-cpu-baseline --no-probe --no-inference --steps 3 --warmup 1 > /dev/null 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d $out/pmc -o p -- python bench.py --no-cpu-baseline --no-probe --no-inference --no-extras --steps 3 --warmup 1 > /dev/null 2>&1
   python - <<PY >> $out/pmc_traffic_raw.txt
 import sqlite3, glob
 c = sqlite3.connect(glob.glob('$out/pmc/*.db')[0])
-for pat in ('conv3x3s1_kernel<unsigned short, 128, 64, 8>', 'conv3x3_ws_kernel<64, false, 0, true>', 'dcn_bwd_dom_kernel<64>', 'topk_map128_kernel', 'bn_bwd_apply_kernel<unsigned short>'):
+for pat in ('conv3x3s1_kernel<unsigned short, 128, 64, 8>', 'conv3x3_ws_kernel<64, false, 0, true>', 'dcn_dom_bm_kernel<64>', 'dcn_dx_bm_kernel<2>', 'dcn_fwd_bm_kernel<2>', 'dcn_wgrad_bm_kernel', 'topk_map128_kernel', 'bn_bwd_apply_kernel<unsigned short>'):
     rows = c.execute("select dispatch_id, sum(value) from counters_collection where kernel_name like ? and counter_name='$c' group by dispatch_id", ('%' + pat + '%',)).fetchall()
     print('$c', pat, 'launches', len(rows), 'avg_kib', sum(r[1] for r in rows) / max(1, len(rows)))
 PY
 done
-rm -rf $out/pmc $out/kt
+rm -rf $out/pmc
 python tools/pmc_traffic_json.py $out/pmc_traffic_raw.txt > $out/pmc_traffic.json
 python tools/opbench.py decode bn conv > $out/opbench.txt 2>&1
 DCN_SHAPES=3 python tools/opbench.py dcn >> $out/opbench.txt 2>&1
+python tools/wgrad_bench.py 256 384 > $out/wgrad_bench.txt 2>&1
+python tools/gap_check.py $db > $out/gap_check.txt 2>&1 || true
+ls -la $out
+rm -rf $out/kt
 ls -la $out
