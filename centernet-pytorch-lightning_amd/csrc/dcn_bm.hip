@@ -419,6 +419,14 @@ bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const flo
 // takes 541 us with zero offsets and 955 us with N(0, 0.5 px) offsets on 64->64 @128^2 (one hit per destination and tap vs four).
 // The source geometry of all nine taps (tile-relative sampling position, sigmoid(mask)) is computed once per tile into an LDS
 // table that re-uses the halo image once the fragments are loaded.
+#ifdef DXB_PROBE   // development build only (tools/dxbm_probe.py)
+__device__ unsigned long long dxb_ts[1024 * 32];
+#define DXB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) dxb_ts[blockIdx.x * 32 + (k)] = clock64(); } while (0)
+extern "C" int dxb_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dxb_ts), sizeof(dxb_ts)); }
+#else
+#define DXB_STAMP(k) do { } while (0)
+#endif
+
 struct DxBmGeom {
     const bf16_t* dy; const float* om; const bf16_t* wp; float* far; int* far_flag; bf16_t* dx;
     int N, H, W, dx_ld, ktot;
@@ -438,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
     unsigned char* const Ws = smem + DXB_TBYTES + 4 * 32 * DXB_TP;    // 2 weight buffers (behind the halo image: 51712 > 49152)
     constexpr int WSB = 4 * 2 * 32 * NCB * 16;
 
+    DXB_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_w = (g.W + BM_TW - 1) / BM_TW;
     const int ty0 = (blockIdx.x / tiles_w) * BM_TH, tx0 = (blockIdx.x % tiles_w) * BM_TW;
@@ -544,6 +553,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
     wstore(0);
     wload(1);
     __syncthreads();
+    DXB_STAMP(1);
 
     f32x16_t acc[NCB];
 #pragma unroll
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
 
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
+        DXB_STAMP(2 + 3 * tap);
         f32x16_t st[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -609,6 +620,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             __builtin_amdgcn_wave_barrier();
         }
         // ---- dx^T[ci][q] += W_k[.][ci]^T G^T[.][q] ----
+        DXB_STAMP(3 + 3 * tap);
         const unsigned char* wb = Ws + (tap & 1) * WSB;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -622,10 +634,12 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
                 acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wv), sf, acc[cb], 0, 0, 0);
             }
         }
+        DXB_STAMP(4 + 3 * tap);
         wstore((tap + 1) & 1);
         __syncthreads();
         wload(tap < 7 ? tap + 2 : 8);
     }
+    DXB_STAMP(29);
 
     // ---- epilogue: + dx_far (lazy protocol of cn_dcn_bwd_dx: added and restored to zero only when a dom kernel flagged far
     //      samples), bf16 through the wave's T tile, 16-byte coalesced stores ----
@@ -661,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             if (oy < g.H && ox < g.W) *reinterpret_cast<u32x4v*>(g.dx + (img + (int64_t)oy * g.W + ox) * g.dx_ld + ch * 8) = o;
         }
     }
+    DXB_STAMP(31);
 }
 
 bool dcn_dx_bm_shape_ok(int Ci, int dy_ld, int om_ld) {

@@ -359,7 +359,8 @@ class TrainStep:
         self._between = bool(os.environ.get("CN_EXCHANGE_BETWEEN_GRAPHS")) and graph
         # weight gradients on a second stream, deposited straight into the flat gradient buffer (they report to the exchange
         # through ops.GradReady, so data parallelism keeps them)
-        self.side = SideGrads.enable(side_grads and self.opt.flat_p.is_cuda and not os.environ.get("CN_NO_SIDE"))
+        self.side = SideGrads.enable(side_grads and self.opt.flat_p.is_cuda and not os.environ.get("CN_NO_SIDE"),
+                                     fp32=getattr(model, "compute_dtype", None) == torch.float32)
         if self.sync is not None:
             self.sync.broadcast_state(model)
         self._g1 = self._g2 = None

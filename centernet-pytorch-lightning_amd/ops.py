@@ -222,11 +222,15 @@ class SideGrads:
     active = False        # only true while a TrainStep (which joins afterwards) is running its backward
 
     @classmethod
-    def enable(cls, on=True):
+    def enable(cls, on=True, fp32=False):
+        """fp32 (parity mode): the generic fp32 weight-gradient kernels are several times longer — they keep the wider grid"""
         if on and cls.stream is None:
             cls.stream = torch.cuda.Stream()
-        # background-shaped weight-gradient grids while they share the GPU with the data-gradient chain
-        cls.thin = int(_os.environ.get("CN_WGRAD_BLOCKS", 384 if on else 1536))
+        # background-shaped weight-gradient grids while they share the GPU with the data-gradient chain.  Round 3 (slab-form 3x3
+        # kernels at two waves per SIMD, matrix-core DCN weight gradient): the side stream has slack, so the fewer CUs it occupies the
+        # faster the critical chain runs — DLA-34 bs 64: 1 413 / 1 432 / 1 437 / 1 460 / 1 480 / 1 478 / 1 368 / 1 165 images/s with
+        # 768 / 512 / 384 / 192 / 160 / 128 / 96 / 64 workgroups (below ~128 the side stream itself becomes the critical path)
+        cls.thin = int(_os.environ.get("CN_WGRAD_BLOCKS", (384 if fp32 else 160) if on else 1536))
         call("cn_set_wgrad_parallelism", cls.thin)
         return on
 
