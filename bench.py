@@ -649,6 +649,12 @@ def main():
                     "tflops": round(ach, 2), "frac_mfma": round(ach / peak, 4), "gbps": round(gbps, 1),
                     "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4),
                     "step": step_roof,
+                    # the dominant template may be a weight-gradient kernel: those run on the side stream with a deliberately thin
+                    # grid (cn_set_wgrad_parallelism, 160 workgroups: fewer CUs taken from the critical chain), which is the grid the
+                    # probe times them on; the largest template of the LAUNCH-STREAM chain (what decides the step) is named next to it
+                    "side_stream_grid": int(__import__("centernet_amd.ops", fromlist=["SideGrads"]).SideGrads.thin),
+                    "launch_stream_dominant": (lambda kv: dict(kernel=kv[0], **row(kv[1])))(
+                        max(((k, v) for k, v in by.items() if "wgrad" not in k), key=lambda kv: kv[1][1])),
                     "mfma_kernels": {k: row(v) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]},
                     "all_igemm": {"achieved": round(allf / allt / 1e12, 2), "ms_per_step": round(allt / args.probe_steps * 1e3, 3)},
                     "entry_points_ms_per_step": {k: round(v[1] / args.probe_steps * 1e3, 3)

@@ -404,7 +404,10 @@ def test_reference_shaped_seam_nchw_both_ways(golden):
         assert out[k].shape == out_ref[k].shape == (1, {"heatmap": 80}.get(k, 2), 128, 128)
         assert torch.allclose(out[k].detach().cpu(), out_ref[k].detach(), rtol=1e-4, atol=1e-5), k
     gb, gr = bb.conv.weight.grad.cpu(), ref_bb.conv.weight.grad     # the gradient crosses the seam back into plain torch
-    assert float((gb - gr).norm() / gr.norm()) < 1e-4
+    # 5e-4: the last hop is ATen's own conv weight gradient on the GPU (MIOpen picks its algorithm from what ran before in the
+    # process: 3e-5 when this test runs alone, 1.5e-4 in the middle of the whole suite); the HIP head's part of the chain is held to
+    # 1e-4 by the output check above and by test_head_conv_fused_relu_backward
+    assert float((gb - gr).norm() / gr.norm()) < 5e-4
 
     # (c) this package's backbone (NCHW fp32 out) -> a plain torch head
     plain = torch.nn.Conv2d(64, 5, 1).to(DEV)
