@@ -325,16 +325,17 @@ extern "C" int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld
 }
 
 // Weight gradient straight into the PARAMETER layout dw[Co][Ci][KH][KW] (fp32; accumulate != 0 adds to it), for the shapes whose
-// kernel has the slab form (bf16, 3x3 / stride 1 / pad 1, Ci > 16): split-K partials leave as private slabs in `ws` and one
+// kernel has the slab form (bf16, 3x3 / stride 1 or 2 / pad 1, Ci > 16): split-K partials leave as private slabs in `ws` and one
 // reduction launch sums them — no fp32 atomics, no pre-zeroed packed gradient, no unpack launch, fixed summation order.
 // cn_conv2d_wgrad_direct_bytes: scratch size, 0 = shape not handled here (use cn_conv2d_wgrad + cn_unpack_wgrad).
 bool wgrad3x3s1_slab_launch(const void* x, const void* dy, float* slabs, float* dw, int accumulate, int N, int H, int W, int Ci, int x_ld,
-                            int Co, int dy_ld, hipStream_t st);
-size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld);
+                            int Co, int dy_ld, int stride, hipStream_t st);
+size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld, int stride);
 extern "C" size_t cn_conv2d_wgrad_direct_bytes(int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld, int KH, int KW,
                                                int stride, int pad, int dtype) {
-    if (dtype != CN_BF16 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || OH != H || OW != W || Ci <= 16) return 0;
-    return wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld);
+    if (dtype != CN_BF16 || KH != 3 || KW != 3 || (stride != 1 && stride != 2) || pad != 1 || Ci <= 16) return 0;
+    if (OH != (H + 2 - 3) / stride + 1 || OW != (W + 2 - 3) / stride + 1) return 0;
+    return wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld, stride);
 }
 extern "C" int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
                                       int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
@@ -345,7 +346,7 @@ extern "C" int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, 
     if (ws_bytes < need) { cn_set_error("cn_conv2d_wgrad_direct: workspace too small"); return CN_EWORKSPACE; }
     CN_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) == 0 && x_ld >= Ci && dy_ld >= Co, "cn_conv2d_wgrad_direct: bad pointers / pitches");
     hipStream_t st = (hipStream_t)stream;
-    if (!wgrad3x3s1_slab_launch(x, dy, (float*)ws, dw, accumulate, N, H, W, Ci, x_ld, Co, dy_ld, st))
+    if (!wgrad3x3s1_slab_launch(x, dy, (float*)ws, dw, accumulate, N, H, W, Ci, x_ld, Co, dy_ld, stride, st))
         CN_UNSUPPORTED("cn_conv2d_wgrad_direct: shape not handled");
     CN_LAUNCH_CHECK("cn_conv2d_wgrad_direct");
     if (db) {

@@ -25,15 +25,30 @@ struct Wgrad3Geom {
     int N, H, W, Ci, x_ld, Co, dy_ld, ktot;
     int tiles_h, tiles_w, ci_tiles;
     int tiles_per_block;
+    int OH, OW;          // output (dY) size: H, W for stride 1; (H - 1) / 2 + 1 ... for the stride-2 variant
 };
 
 // 32(channel) x 16(pixel) operand from a [row][channel] LDS tile; the 16 pixels are rows row0 .. row0+15.
 __device__ static inline bf16x8_t tr_frag16(const bf16_t* tile, int pitch, int c0, int row0, int lane) {
+    // (pixels `step` rows apart — the stride-2 weight gradient — are read by passing step * pitch as the pitch and row0 / step ... see tr_frag16s)
     const int r = lane & 15, g = lane >> 4;
     const bf16_t* p = tile + (row0 + 8 * (g >> 1) + (r >> 2)) * pitch + c0 + 16 * (g & 1) + 4 * (r & 3);
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
     const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * pitch));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// the same operand from 16 pixels that lie S tile rows apart, starting at row0 (stride-2 convolution: every other halo pixel)
+template <int S>
+__device__ static inline bf16x8_t tr_frag16s(const bf16_t* tile, int pitch, int c0, int row0, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    const bf16_t* p = tile + (row0 + S * (8 * (g >> 1) + (r >> 2))) * pitch + c0 + 16 * (g & 1) + 4 * (r & 3);
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * S * pitch));
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
@@ -47,20 +62,25 @@ __device__ static inline bf16x8_t tr_frag16(const bf16_t* tile, int pitch, int c
 // memory side, ~600 GB/s) — 65 us of a 135 us launch with 256 workgroups, 98 of 166 us with the 384 the train step uses.
 // NW = 8 (512 threads, 4 x 2 waves): all nine taps of a 128 x 64 channel tile with 144 accumulator registers per wave — dY is then
 // read ONCE per launch instead of once per tap row (the 64 -> 256 head convs: 2.4 GB -> 0.8 GB of operand traffic per launch).
-template <int BMW, int BNW, int TAPS, bool SLAB = false, int NW = 4>
+// S = 2: the stride-2 3x3 / pad 1 convs (the first conv of every DLA / ResNet stage): 4x16 output tiles, a 9x33 halo, every other halo
+// pixel per operand (tr_frag16s) — these ran on the generic split-K kernel, one workgroup column per TAP (x re-read nine times,
+// two MFMAs per wave and barrier): 32->64 @256^2 886 us, 64->128 284, 128->256 163, 256->512 168 on the step's thin grids.
+template <int BMW, int BNW, int TAPS, bool SLAB = false, int NW = 4, int S = 1>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad3x3s1_kernel(const Wgrad3Geom g) {
     constexpr int NT = NW * 64;
+    constexpr int TH = S == 1 ? W3_TH : 4;                    // output rows per tile
+    constexpr int HW = (W3_TW - 1) * S + 3;                   // halo columns
     constexpr int YP = BMW + 32, XP = BNW + 32;               // +64 B: the 4 rows of a transposing read hit disjoint banks
     constexpr int YCG = BMW / 8, XCG = BNW / 8;
-    constexpr int YV = (W3_TH * W3_TW * YCG + NT - 1) / NT;   // 16-byte loads per thread
-    constexpr int XV = (W3_HP * XCG + NT - 1) / NT;
+    constexpr int HROWS = TAPS == 9 ? (TH - 1) * S + 3 : (TH - 1) * S + 1;      // halo rows staged
+    constexpr int YV = (TH * W3_TW * YCG + NT - 1) / NT;      // 16-byte loads per thread
+    constexpr int XV = (HROWS * HW * XCG + NT - 1) / NT;
     constexpr int WM = BMW / (NW / 2), WN = BNW / 2;          // (NW / 2) x 2 waves
     constexpr int MI = WM / 32, NJ = WN / 32;
-    constexpr int HROWS = TAPS == 9 ? W3_TH + 2 : W3_TH;      // halo rows staged
 
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];   // [128][YP] dY tile | [HROWS*18][XP] X halo
     bf16_t* const yt = lds;
-    bf16_t* const xt = lds + W3_TH * W3_TW * YP;
+    bf16_t* const xt = lds + TH * W3_TW * YP;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int co0 = (blockIdx.y / g.ci_tiles) * BMW, ci0 = (blockIdx.y % g.ci_tiles) * BNW;
@@ -85,26 +105,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad3x3s1_kernel(co
     auto gload = [&](int64_t tile) {
         const int n = (int)(tile / (g.tiles_h * g.tiles_w));
         const int r = (int)(tile - (int64_t)n * g.tiles_h * g.tiles_w);
-        const int th0 = (r / g.tiles_w) * W3_TH, tw0 = (r % g.tiles_w) * W3_TW;
-        const int64_t img = (int64_t)n * g.H * g.W;
+        const int th0 = (r / g.tiles_w) * TH, tw0 = (r % g.tiles_w) * W3_TW;
+        const int64_t img = (int64_t)n * g.H * g.W, oimg = (int64_t)n * g.OH * g.OW;
 #pragma unroll
         for (int v = 0; v < YV; ++v) {
             const int idx = tid + v * NT;
             const int px = idx / YCG, c = co0 + (idx % YCG) * 8;
             const int oh = th0 + px / W3_TW, ow = tw0 + px % W3_TW;
             uint4 val = make_uint4(0, 0, 0, 0);
-            if (idx < W3_TH * W3_TW * YCG && oh < g.H && ow < g.W && c < g.Co)
-                val = *reinterpret_cast<const uint4*>(g.dy + (img + (int64_t)oh * g.W + ow) * g.dy_ld + c);
+            if (idx < TH * W3_TW * YCG && oh < g.OH && ow < g.OW && c < g.Co)
+                val = *reinterpret_cast<const uint4*>(g.dy + (oimg + (int64_t)oh * g.OW + ow) * g.dy_ld + c);
             ry[v] = val;
         }
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
             const int idx = tid + v * NT;
             const int hp = idx / XCG, c = ci0 + (idx % XCG) * 8;
-            const int hr = hp / W3_HW;                         // staged halo row: image row th0 - 1 + kh0 + hr
-            const int ih = th0 - 1 + kh0 + hr, iw = tw0 - 1 + hp % W3_HW;
+            const int hr = hp / HW;                            // staged halo row: image row th0 * S - 1 + kh0 + hr
+            const int ih = th0 * S - 1 + kh0 + hr, iw = tw0 * S - 1 + hp % HW;
             uint4 val = make_uint4(0, 0, 0, 0);
-            if (idx < HROWS * W3_HW * XCG && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W && c < g.Ci)
+            if (idx < HROWS * HW * XCG && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W && c < g.Ci)
                 val = *reinterpret_cast<const uint4*>(g.x + (img + (int64_t)ih * g.W + iw) * g.x_ld + c);
             rx[v] = val;
         }
@@ -113,12 +133,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad3x3s1_kernel(co
 #pragma unroll
         for (int v = 0; v < YV; ++v) {
             const int idx = tid + v * NT;
-            if (idx < W3_TH * W3_TW * YCG) *reinterpret_cast<uint4*>(yt + (idx / YCG) * YP + (idx % YCG) * 8) = ry[v];
+            if (idx < TH * W3_TW * YCG) *reinterpret_cast<uint4*>(yt + (idx / YCG) * YP + (idx % YCG) * 8) = ry[v];
         }
 #pragma unroll
         for (int v = 0; v < XV; ++v) {
             const int idx = tid + v * NT;
-            if (idx < HROWS * W3_HW * XCG) *reinterpret_cast<uint4*>(xt + (idx / XCG) * XP + (idx % XCG) * 8) = rx[v];
+            if (idx < HROWS * HW * XCG) *reinterpret_cast<uint4*>(xt + (idx / XCG) * XP + (idx % XCG) * 8) = rx[v];
         }
     };
 
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad3x3s1_kernel(co
         __syncthreads();
         if (tile + 1 < t_end) gload(tile + 1);   // in flight while this tile is multiplied
 #pragma unroll
-        for (int kk = 0; kk < W3_TH; ++kk) {  // one k16 step = one 16-pixel tile row
+        for (int kk = 0; kk < TH; ++kk) {     // one k16 step = one 16-pixel tile row
             bf16x8_t fa[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[i] = tr_frag16(yt, YP, wm + i * 32, kk * W3_TW, lane);
@@ -138,7 +158,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void wgrad3x3s1_kernel(co
                 const int kh = t / 3, kw = t % 3;             // TAPS == 3: kh is relative to kh0 (the halo starts at that row)
                 bf16x8_t fb[NJ];
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[j] = tr_frag16(xt, XP, wn + j * 32, (kk + kh) * W3_HW + kw, lane);
+                for (int j = 0; j < NJ; ++j) fb[j] = tr_frag16s<S>(xt, XP, wn + j * 32, (kk * S + kh) * HW + kw, lane);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -225,7 +245,9 @@ static size_t w3_slab_plan(Wgrad3Geom& g) {              // fills the tiling fie
     const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
     // the 8-wave all-taps tile runs one workgroup per CU and its slab is 295 KB: one round of workgroups (64 -> 256 @128^2: 298 us
     // with 256 workgroups, 368 with 384)
-    const int target = (BMW == 128 && TAPS == 9 && cn_wgrad_target_blocks() > 256) ? 256 : cn_wgrad_target_blocks();
+    static const int env_blocks = getenv("CN_WGRAD3X3_BLOCKS") ? atoi(getenv("CN_WGRAD3X3_BLOCKS")) : 0;            // A/B: this family's own grid
+    const int base_target = env_blocks > 0 ? env_blocks : cn_wgrad_target_blocks();
+    const int target = (BMW == 128 && TAPS == 9 && base_target > 256) ? 256 : base_target;
     int64_t want = (target + par - 1) / par;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
@@ -234,18 +256,19 @@ static size_t w3_slab_plan(Wgrad3Geom& g) {              // fills the tiling fie
     return (size_t)gx * par * TAPS * BMW * BNW * sizeof(float);
 }
 
-template <int BMW, int BNW, int TAPS, int NW = 4>
+template <int BMW, int BNW, int TAPS, int NW = 4, int S = 1>
 static void launch_w3_slab(Wgrad3Geom& g, float* dw, int accumulate, hipStream_t st) {
     (void)w3_slab_plan<BMW, BNW, TAPS>(g);
     const int co_tiles = cdiv(g.Co, BMW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
-    const int hrows = TAPS == 9 ? W3_TH + 2 : W3_TH;
-    const size_t smem = ((size_t)W3_TH * W3_TW * (BMW + 32) + (size_t)hrows * W3_HW * (BNW + 32)) * sizeof(bf16_t);
+    constexpr int TH = S == 1 ? W3_TH : 4, HW = (W3_TW - 1) * S + 3;
+    const int hrows = TAPS == 9 ? (TH - 1) * S + 3 : (TH - 1) * S + 1;
+    const size_t smem = ((size_t)TH * W3_TW * (BMW + 32) + (size_t)hrows * HW * (BNW + 32)) * sizeof(bf16_t);
     if (smem > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)wgrad3x3s1_kernel<BMW, BNW, TAPS, true, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)wgrad3x3s1_kernel<BMW, BNW, TAPS, true, NW, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const dim3 grid(gx, co_tiles * g.ci_tiles, TAPS == 9 ? 1 : 3);
-    hipLaunchKernelGGL((wgrad3x3s1_kernel<BMW, BNW, TAPS, true, NW>), grid, dim3(NW * 64), smem, st, g);
+    hipLaunchKernelGGL((wgrad3x3s1_kernel<BMW, BNW, TAPS, true, NW, S>), grid, dim3(NW * 64), smem, st, g);
     hipLaunchKernelGGL((wgrad3x3_reduce_kernel<BMW, BNW, TAPS, NW>), dim3(TAPS * BMW * BNW / 64, grid.y, grid.z), dim3(256), 0, st, g.dwp, dw, gx,
                        g.ci_tiles, g.Co, g.Ci, accumulate);
 }
@@ -276,6 +299,7 @@ bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, 
     Wgrad3Geom g;
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.dwp = dwp;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.ktot = 9 * Ci;
+    g.OH = H; g.OW = W;
     g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
     if (Co > 64) launch_w3<128, 64, 3>(g, st);      // 68.6 KB LDS, 96 accumulator registers
     else launch_w3<64, 64, 9>(g, st);               // 59 KB LDS, 144 accumulator registers
@@ -284,25 +308,35 @@ bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, 
 
 
 // Slab form of the above: `slabs` is scratch (wgrad3x3s1_slab_bytes), the result lands in the parameter-layout gradient dw.
-size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld) {
+// stride 1 (OH = H) or 2 (OH = (H - 1) / 2 + 1), pad 1.
+static void w3_tiles(Wgrad3Geom& g, int stride) {
+    g.OH = stride == 1 ? g.H : (g.H - 1) / 2 + 1;
+    g.OW = stride == 1 ? g.W : (g.W - 1) / 2 + 1;
+    g.tiles_h = cdiv(g.OH, stride == 1 ? W3_TH : 4); g.tiles_w = cdiv(g.OW, W3_TW);
+}
+size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld, int stride) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD3X3") != nullptr || getenv("CN_DISABLE_WGRAD_SLABS") != nullptr;
-    if (disabled || Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) return 0;
+    static const bool no_s2 = getenv("CN_DISABLE_WGRAD3X3_S2") != nullptr;
+    if (disabled || Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0 || (stride != 1 && stride != 2) || (stride == 2 && no_s2)) return 0;
     Wgrad3Geom g;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co;
-    g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
+    w3_tiles(g, stride);
     static const bool taps9 = getenv("CN_WGRAD3X3_WIDE_TAPS3") == nullptr;      // A/B: the 4-wave 128 x 64 tile with one tap row per workgroup
-    return Co > 64 ? (taps9 ? w3_slab_plan<128, 64, 9>(g) : w3_slab_plan<128, 64, 3>(g)) : w3_slab_plan<64, 64, 9>(g);
+    return Co > 64 ? ((taps9 || stride == 2) ? w3_slab_plan<128, 64, 9>(g) : w3_slab_plan<128, 64, 3>(g)) : w3_slab_plan<64, 64, 9>(g);
 }
 
 bool wgrad3x3s1_slab_launch(const void* x, const void* dy, float* slabs, float* dw, int accumulate, int N, int H, int W, int Ci, int x_ld,
-                            int Co, int dy_ld, hipStream_t st) {
-    if (wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld) == 0) return false;
+                            int Co, int dy_ld, int stride, hipStream_t st) {
+    if (wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld, stride) == 0) return false;
     Wgrad3Geom g;
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.dwp = slabs;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.ktot = 9 * Ci;
-    g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
+    w3_tiles(g, stride);
     static const bool taps9 = getenv("CN_WGRAD3X3_WIDE_TAPS3") == nullptr;
-    if (Co > 64 && taps9) launch_w3_slab<128, 64, 9, 8>(g, dw, accumulate, st);     // 8 waves, all taps: dY read once
+    if (stride == 2) {
+        if (Co > 64) launch_w3_slab<128, 64, 9, 8, 2>(g, dw, accumulate, st);
+        else launch_w3_slab<64, 64, 9, 4, 2>(g, dw, accumulate, st);
+    } else if (Co > 64 && taps9) launch_w3_slab<128, 64, 9, 8>(g, dw, accumulate, st);     // 8 waves, all taps: dY read once
     else if (Co > 64) launch_w3_slab<128, 64, 3>(g, dw, accumulate, st);
     else launch_w3_slab<64, 64, 9>(g, dw, accumulate, st);
     return true;
@@ -498,7 +532,8 @@ extern "C" int cn_dcn_wgrad(const void* x, const float* om, const void* dy, floa
     CN_CHECK_ARG(x && om && dy && dwp && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "cn_dcn_wgrad: bad args");
     if (dtype != CN_BF16) CN_UNSUPPORTED("cn_dcn_wgrad: bf16 only (fp32 parity mode goes through cn_dcn_im2col + cn_conv2d_wgrad)");
     if (Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) CN_UNSUPPORTED("cn_dcn_wgrad: channel counts must be multiples of 8");
-    if (dcn_wgrad_bm_launch(x, om, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, om_ld, cn_wgrad_target_blocks(), (hipStream_t)stream)) {
+    static const int env_blocks = getenv("CN_DCN_WGRAD_BLOCKS") ? atoi(getenv("CN_DCN_WGRAD_BLOCKS")) : 0;      // A/B: this family's own grid
+    if (dcn_wgrad_bm_launch(x, om, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, om_ld, env_blocks > 0 ? env_blocks : cn_wgrad_target_blocks(), (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_wgrad(bm)");
         return CN_OK;
     }

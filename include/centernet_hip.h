@@ -92,7 +92,7 @@ int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
                     int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                     int KH, int KW, int stride, int pad, int dtype, void* stream);
 /* The same gradient straight into the PARAMETER layout dw[Co][Ci][KH][KW] (fp32, accumulate != 0 adds — e.g. into the flat
- * gradient buffer), for the shapes whose kernel has the slab form (bf16, 3x3 / stride 1 / pad 1, Ci > 16): every workgroup
+ * gradient buffer), for the shapes whose kernel has the slab form (bf16, 3x3 / stride 1 or 2 / pad 1, Ci > 16): every workgroup
  * stores its split-K partial as a private slab in `ws` and one reduction launch sums them in a fixed order — no fp32 atomics
  * (device-scope atomics execute at the memory side: 0.25 us per workgroup flush, serialised chip-wide), no pre-zeroed packed
  * gradient, no cn_unpack_wgrad launch.  cn_conv2d_wgrad_direct_bytes = scratch size, 0 when the shape is not handled (use

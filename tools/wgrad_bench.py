@@ -44,3 +44,20 @@ for (N, HW, Ci, Co) in SHAPES:
         us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad_direct", x, dy, dw, None, 1, ws, n, N, HW, HW, Ci, Ci, HW, HW, Co, ld, 3, 3, 1, 1, code), n=10)
         print(f"wgrad 3x3s1 {Ci:3d}->{Co:3d} @{HW:3d}^2  blocks {b:5d}: {us:8.1f} us (min {mn:8.1f})  {flops / us / 1e6:7.1f} TF   slabs {n / 1e6:6.1f} MB", flush=True)
     del x, dy, dw
+
+print("stride 2 (input size given): cn_conv2d_wgrad (generic split-K kernel, one workgroup column per tap) vs cn_conv2d_wgrad_direct (halo-tile slab form)")
+for (N, HW, Ci, Co) in [(64, 256, 32, 64), (64, 128, 64, 128), (64, 64, 128, 256), (64, 32, 256, 512)]:
+    OHW = HW // 2
+    x = torch.randn(N, HW, HW, Ci, device=DEV).to(dt)
+    dy = torch.randn(N, OHW, OHW, Co, device=DEV).to(dt)
+    dwp = torch.zeros((Co + 31) // 32 * 32, 9 * Ci, device=DEV)
+    dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
+    flops = 2.0 * N * OHW * OHW * Ci * Co * 9
+    for b in blocks:
+        _hip.query("cn_set_wgrad_parallelism", b)
+        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad", x, dy, dwp, None, N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code), n=10)
+        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes", N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code))
+        ws = torch.empty(max(n, 16), dtype=torch.uint8, device=DEV)
+        us2, mn2 = timeit(lambda: _hip.call("cn_conv2d_wgrad_direct", x, dy, dw, None, 1, ws, n, N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code), n=10) if n else (float("nan"), 0)
+        print(f"wgrad 3x3s2 {Ci:3d}->{Co:3d} @{HW:3d}^2  blocks {b:5d}: generic {us:8.1f} us   slab {us2:8.1f} us  ({flops / us2 / 1e6:6.1f} TF)", flush=True)
+    del x, dy, dwp, dw
