@@ -621,7 +621,7 @@ extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
     if (entry == 2 && dcn_dom_bm_shape_ok(Ci, Co, Ci, 32)) return 1000000 + Co;                        // dcn_dom_bm_kernel<COP>
     if (entry == 2) return (Ci % 64 == 0 && cn_dcn_bwd_dom_slabs(128, Co, CN_BF16) == 2) ? Co : 0;   // slabs(128, .) == 2 <=> the tile kernel takes this dy_ld
     if (entry == 3) {
-        if (dcn_dx_bm_shape_ok(Ci, Co, 32)) return 1000000 + Ci / 32;
+        if (dcn_dx_bm_shape_ok(Ci, Co, 32)) return 1000000 + (Ci > 64 ? 2 : Ci / 32);      // wider dx: 64-channel blocks on grid z, still <2>
         const int bn = Ci % 128 == 0 ? 128 : (Ci % 64 == 0 ? 64 : 32);
         return 3000000 + bn * 1000 + (Co % 64 == 0 ? 64 : (Co % 32 == 0 ? 32 : 16));
     }

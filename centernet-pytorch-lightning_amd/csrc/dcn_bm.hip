@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             const int slot = tid + i * 256;
             const int ci = slot % (32 * NCB), sh = slot / (32 * NCB), h = sh & 1, s = sh >> 1;
             const int c0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * h;
-            const bf16_t* p = g.wp + (int64_t)ci * g.ktot + tap * 64 + c0;
+            const bf16_t* p = g.wp + (int64_t)(32 * NCB * blockIdx.z + ci) * g.ktot + tap * 64 + c0;     // blockIdx.z: 64-channel block of dx
             wr_[i][0] = *reinterpret_cast<const uint2*>(p);
             wr_[i][1] = *reinterpret_cast<const uint2*>(p + 8);
         }
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
     //      samples), bf16 through the wave's T tile, 16-byte coalesced stores ----
     const bool use_far = g.far != nullptr && (g.far_flag == nullptr || *g.far_flag != 0);
     if (use_far && live) {
-        float* fp = g.far + (img + (int64_t)gy * g.W + gx) * (32 * NCB);
+        float* fp = g.far + (img + (int64_t)gy * g.W + gx) * g.dx_ld + 32 * NCB * blockIdx.z;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             const int idx = lane + 64 * i, p = idx / CPP, ch = idx % CPP;
             const int oy = ty0 + grow + (p >> 3), ox = tx0 + gcol + (p & 7);
             const u32x4v o = *reinterpret_cast<const u32x4v*>(T + p * DXB_TP + ch * 16);
-            if (oy < g.H && ox < g.W) *reinterpret_cast<u32x4v*>(g.dx + (img + (int64_t)oy * g.W + ox) * g.dx_ld + ch * 8) = o;
+            if (oy < g.H && ox < g.W) *reinterpret_cast<u32x4v*>(g.dx + (img + (int64_t)oy * g.W + ox) * g.dx_ld + 32 * NCB * blockIdx.z + ch * 8) = o;
         }
     }
     DXB_STAMP(31);
@@ -680,7 +680,11 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
 
 bool dcn_dx_bm_shape_ok(int Ci, int dy_ld, int om_ld) {
     static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_DX_BM") != nullptr;
-    return !disabled && dy_ld == 64 && (Ci == 64 || Ci == 32) && om_ld == 32;
+    // Ci = 128 / 256 (dY still 64 channels: the 128->64 and 256->64 layers): one workgroup column per 64-channel block of dx, each
+    // rebuilding the adjoint blend.  Against the hit-list kernel that is level with zero offsets (128->64 @64^2: 184 us there) and
+    // 1.7x ahead with N(0, 0.5 px) offsets (378 us there) — the regime a network is in once conv_offset_mask has moved.
+    static const bool no_wide = getenv("CN_DCN_DX_BM_NARROW") != nullptr;
+    return !disabled && dy_ld == 64 && (Ci == 64 || Ci == 32 || (!no_wide && (Ci == 128 || Ci == 256))) && om_ld == 32;
 }
 
 // returns false when the shape is not handled here (caller falls back to the adjoint-gather kernel)
@@ -691,8 +695,8 @@ bool dcn_dx_bm_launch(const void* dy, const void* wpd0, const float* om, float* 
     DxBmGeom g;
     g.dy = (const bf16_t*)dy; g.om = om; g.wp = (const bf16_t*)wpd0; g.far = far; g.far_flag = far_flag; g.dx = (bf16_t*)dx;
     g.N = N; g.H = H; g.W = W; g.dx_ld = Ci; g.ktot = 9 * 64;
-    const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N);
-    if (Ci == 64) {
+    const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N, Ci > 64 ? Ci / 64 : 1);
+    if (Ci >= 64) {
         const size_t smem = DXB_TBYTES + 4 * 32 * DXB_TP + 2 * (4 * 2 * 64 * 16);
         (void)hipFuncSetAttribute((const void*)dcn_dx_bm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(dcn_dx_bm_kernel<2>, grid, dim3(256), smem, st, g);

@@ -148,6 +148,9 @@ if __name__ == "__main__":
     for (N, H, W, Ci) in [(2, 16, 32, 64), (1, 13, 21, 64), (1, 8, 16, 32)]:
         for sigma in (0.0, 0.5, 1.5, 4.0):
             worst = max(worst, check_dx(N, H, W, Ci, 64, sigma))
+    for Ci in (128, 256):
+        for sigma in (0.0, 1.5, 4.0):
+            worst = max(worst, check_dx(2, 16, 32, Ci, 64, sigma))
     print("worst rel err dx", worst)
     worst = 0.0
     for (N, H, W) in [(2, 16, 32), (1, 13, 21), (3, 24, 48)]:
