@@ -464,6 +464,7 @@ def main():
     # decode overlaps backward; the resident synthetic batch IS the graph's static input (no per-step device-to-device copy of
     # inputs that are already in HBM — with --host-input the copy is host -> device and stays in the timed region)
     step = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_forward=decode, adopt_batch=args.host_input == "none")
+    side_grid = int(__import__("centernet_amd.ops", fromlist=["SideGrads"]).SideGrads.thin)      # what the timed steps and the probe run with
 
     def fence():
         torch.cuda.synchronize()
@@ -652,7 +653,7 @@ def main():
                     # the dominant template may be a weight-gradient kernel: those run on the side stream with a deliberately thin
                     # grid (cn_set_wgrad_parallelism, 160 workgroups: fewer CUs taken from the critical chain), which is the grid the
                     # probe times them on; the largest template of the LAUNCH-STREAM chain (what decides the step) is named next to it
-                    "side_stream_grid": int(__import__("centernet_amd.ops", fromlist=["SideGrads"]).SideGrads.thin),
+                    "side_stream_grid": side_grid,
                     "launch_stream_dominant": (lambda kv: dict(kernel=kv[0], **row(kv[1])))(
                         max(((k, v) for k, v in by.items() if "wgrad" not in k), key=lambda kv: kv[1][1])),
                     "mfma_kernels": {k: row(v) for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]},
