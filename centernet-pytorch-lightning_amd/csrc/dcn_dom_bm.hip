@@ -14,12 +14,15 @@
 //     loaded in the order that makes registers 8a .. 8a+7 of a lane half hold 8 CONSECUTIVE channels (row index with bits 2 and 3
 //     swapped), so those registers, packed to bf16, are the B operand of the second product with no data movement;
 //   * D^T[q][p] = X[q][ci] dcol^T[ci][p] for one PAIR of window rows (2 rows x 16 columns = the M of a 32x32x16 MFMA); the A
-//     operand is a plain 16-byte read of the halo image (pixel pitch 144 B: conflict-free);
+//     operand is a plain 16-byte read of the halo image (128 B per pixel, 16-byte chunks XOR-swizzled with the pixel number:
+//     conflict-free);
 //   * every lane then holds D for its own pixel against 16 of the 32 window pixels of the pair and reduces them with the
 //     separable weights above (8 column weights per tap, two row weights per pair: ~40 FMAs) — no selection, no transposition.
-//     Only the row pairs somebody in the wave samples are visited (three with zero offsets, four with N(0, 0.5 px)).
-//   * dY fragments (loaded once, straight from global memory) and the tap's W fragments (straight from L2, re-loaded right after
-//     their last use, one tap ahead) live in registers: after the prologue there is NO barrier; the nine results of a pixel
+//     Only the row pairs somebody in the wave samples are visited (three with zero offsets, four with N(0, 0.5 px)); the next
+//     pair's fragments are requested between this pair's MFMAs and its reduction.
+//   * dY fragments (loaded once, straight from global memory) live in registers for the whole tile.  The tap's W fragments: dY
+//     with 64 channels — shared through LDS, two buffers, each wave loads two of the eight fragments one tap ahead, one barrier
+//     per tap; 128 channels — one register set per wave, re-loaded from L2 right after its last use.  The nine results of a pixel
 //     overwrite the geometry entries they were computed from in the wave's LDS table and leave as one coalesced row.
 // Samples whose corners leave the window (|offset| > 3 px) take a per-lane VALU path from global memory; the dx_far scatter
 // (corners more than DCN_FAR_R pixels from their pixel: the ones dcn_dx_bm_kernel / dcn_bwd_dx_kernel do not see) is the tile
