@@ -576,6 +576,15 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
         asm volatile("" : "+v"(st[0]), "+v"(st[1]));
+        // the three passes' table entries in one batch of LDS reads (clamped addresses for the lanes without a source): a pass then
+        // has ONE dependent LDS round trip (its T tile) instead of two
+        float tpy[3], tpx[3], tpm[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int sr = min(max(4 * j + s_row0, 1), 10), tc = min(max(tcol, 0), DXB_TC - 1);
+            const float* te = Tab + ((grow + sr - 1) * DXB_TC + tc) * 27;
+            tpy[j] = te[2 * tap]; tpx[j] = te[2 * tap + 1]; tpm[j] = te[18 + tap];
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             // ---- zero the T tile (4608 B), then every source lane drops its corners' weights ----
@@ -585,10 +594,9 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             __builtin_amdgcn_wave_barrier();
             const int s_row = 4 * j + s_row0;                                // group-window row of the source
             const bool src_ok = col_ok && s_row >= 1 && s_row <= 10;
-            const float* te = Tab + ((grow + s_row - 1) * DXB_TC + tcol) * 27;
             bool any = false;
             if (src_ok) {
-                const float pyt = te[2 * tap], pxt = te[2 * tap + 1], m = te[18 + tap];
+                const float pyt = tpy[j], pxt = tpx[j], m = tpm[j];
                 const float fy = floorf(pyt), fx = floorf(pxt);
                 const int y0 = (int)fy - grow, x0 = (int)fx - gcol;           // destination of corner 00, group-local
                 const float ly = pyt - fy, lx = pxt - fx;

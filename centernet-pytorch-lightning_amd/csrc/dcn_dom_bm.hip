@@ -41,8 +41,8 @@
 __device__ static inline int db_chunk(int n, int c) { return n * DB_PIX + ((c ^ ((n >> 1) & 7)) << 4); }
 
 #ifdef DOMB_PROBE   // development build only (tools/dom_probe.py): cycle stamps of wave 0 of the first workgroups
-__device__ unsigned long long domb_ts[1024 * 40];
-#define DB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) domb_ts[blockIdx.x * 40 + (k)] = clock64(); } while (0)
+__device__ unsigned long long domb_ts[1024 * 48];
+#define DB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) domb_ts[blockIdx.x * 48 + (k)] = clock64(); } while (0)
 extern "C" int domb_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(domb_ts), sizeof(domb_ts)); }
 #else
 #define DB_STAMP(k) do { } while (0)
@@ -189,11 +189,13 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
             if (part < 7) { d[0] = tv[i][0]; d[1] = tv[i][1]; d[2] = tv[i][2]; if (part < 6) d[3] = tv[i][3]; }
         }
     }
+    DB_STAMP(40);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * 256;
         st16(Xw + db_chunk(v >> 3, v & 7), hv[i]);
     }
+    DB_STAMP(41);
     if (WLDS) wq_store(0);
     __syncthreads();        // COP == 128: the only barrier — from here on a wave reads the halo image and its own table
     DB_STAMP(1);

@@ -44,13 +44,16 @@ else:
     e0.record(); run(); e1.record()
     torch.cuda.synchronize()
     lib = ctypes.CDLL(SO)
-    buf = np.zeros(1024 * 40, dtype=np.uint64)
+    buf = np.zeros(1024 * 48, dtype=np.uint64)
     assert lib.domb_probe_dump(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    ts = buf.reshape(1024, 40).astype(np.int64)
+    ts = buf.reshape(1024, 48).astype(np.int64)
     ts = ts[ts[:, 39] != 0]
     print(f"launch {e0.elapsed_time(e1) * 1e3:.1f} us, offsets sigma {sigma}, {len(ts)} workgroups stamped")
     med = lambda v: f"median {np.median(v):8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}"
     print("  prologue (start -> barrier)      ", med(ts[:, 1] - ts[:, 0]))
+    print("    start -> geometry table written", med(ts[:, 40] - ts[:, 0]))
+    print("    halo image registers -> LDS    ", med(ts[:, 41] - ts[:, 40]))
+    print("    W store + barrier              ", med(ts[:, 1] - ts[:, 41]))
     a = np.stack([ts[:, 3 + 4 * t] - ts[:, 2 + 4 * t] for t in range(9)], 1)
     b = np.stack([ts[:, 4 + 4 * t] - ts[:, 3 + 4 * t] for t in range(9)], 1)
     c = np.stack([ts[:, 5 + 4 * t] - ts[:, 4 + 4 * t] for t in range(9)], 1)
