@@ -11,6 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import _hip
+from . import ops
 from .ops import SideGrads, PackArena, WeightsEpoch, GradReady
 
 
@@ -399,7 +400,14 @@ class TrainStep:
     def _eager(self, batch, batch_idx=0):
         self.opt.zero_grad()
         self._begin_packs()
-        loss = self.model.training_step(batch, batch_idx)
+        try:
+            loss = self.model.training_step(batch, batch_idx)
+        except BaseException:
+            # a producer may have filled a BatchNorm statistics sink that its BN never got to consume (the sinks are persistent and
+            # must be all-zero when armed): clear them, or the next training-mode BN of that width normalises with stale sums
+            ops.BnStats.reset()
+            PackArena.current, self._packs.recording = None, False
+            raise
         self._fork_post_forward()
         if self.sync is not None and not self._between:
             self.sync.begin()
@@ -426,6 +434,7 @@ class TrainStep:
         SideGrads.pending, SideGrads.active = [], False
         GradReady.sink = GradReady.claim_sink = None
         PackArena.current, self._packs.recording = None, False
+        ops.BnStats.reset()
         if self.sync is not None:
             self.sync.abort()
 

@@ -455,3 +455,36 @@ def test_eval_after_training_uses_fresh_weights_and_statistics(arch, graph):
     for k in want:
         assert torch.allclose(after[k], want[k], rtol=1e-5, atol=1e-6), f"{k}: stale eval cache after training"
         assert not torch.allclose(after[k], before[k], rtol=1e-3, atol=1e-4), f"{k}: training did not change the output?"
+
+
+def test_failed_forward_leaves_the_bn_statistics_sinks_clean(monkeypatch):
+    """The statistics sinks of the conv + BN fusion are persistent and must be all-zero when armed.  A forward pass that dies
+    between a producer (which filled a sink) and its BatchNorm must not poison the next step: TrainStep clears the sinks on the
+    failure path, and the step after the failure equals the step of an untouched model."""
+    from centernet_amd import ops
+    from centernet_amd.engine import TrainStep
+    seed, B, size = 53, 4, 128
+    batch = _to_dev(synth.ctdet_batch(seed, B, size, size))
+    m = _model("res_18", seed, torch.bfloat16).train()
+    step = TrainStep(m, lr=0.0, distributed=False, graph=False)
+    real, calls = ops.batch_norm_act, {"n": 0}
+
+    def dying(x, bn, residual=None, relu=True):
+        calls["n"] += 1
+        if calls["n"] == 4:
+            assert getattr(x, "_bn_part", None) is not None, "the 4th BN's producer is expected to have filled a sink"
+            raise RuntimeError("injected failure between a producer and its BatchNorm")
+        return real(x, bn, residual, relu)
+
+    monkeypatch.setattr(ops, "batch_norm_act", dying)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        step(batch)
+    monkeypatch.setattr(ops, "batch_norm_act", real)
+    torch.cuda.synchronize()
+    assert ops._BN_SINKS and all(float(b.abs().max()) == 0.0 for b in ops._BN_SINKS.values()), "sinks cleared on the failure path"
+    for bn in (mod for mod in m.modules() if hasattr(mod, "_pending")):      # running statistics touched by the dead step: start clean
+        bn.reset_running_stats()
+    loss_after = float(step(batch))
+    m2 = _model("res_18", seed, torch.bfloat16).train()
+    loss_ref = float(TrainStep(m2, lr=0.0, distributed=False, graph=False)(batch))
+    assert loss_after == pytest.approx(loss_ref, rel=1e-5), (loss_after, loss_ref)
