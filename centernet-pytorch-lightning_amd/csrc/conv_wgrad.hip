@@ -52,14 +52,16 @@ struct WgradGeom {
 template <typename T, int BMW, int BNW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     constexpr bool BF = sizeof(T) == 2;
-    constexpr int BKP = BF ? 32 : 16;              // pixels per K tile
+    // pixels per K tile: 64 where two pipeline stages of it fit the 64 KB of static LDS (every tile but 128 x 128) — four MFMAs per wave
+    // and barrier instead of two
+    constexpr int BKP = BF ? ((BMW + BNW <= 192) ? 64 : 32) : 16;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int YV = BKP * BMW / VEC / 256;      // 16-byte loads per thread for the dY tile
     constexpr int XV = BKP * BNW / VEC / 256;
     constexpr int YCG = BMW / VEC, XCG = BNW / VEC;  // channel groups per pixel row
     constexpr int WM = BMW / 2, WN = BNW / 2;      // 2x2 waves
     constexpr int MI = WM / 32, NJ = WN / 32;
-    constexpr int KSTEPS = BF ? 2 : 8;
+    constexpr int KSTEPS = BF ? BKP / 16 : 8;
     static_assert(YV >= 1 && XV >= 1, "tile too small");
 
     constexpr int PADE = BF ? 32 : 0;               // bf16 rows padded by 64 B (bank spread for the transposing reads)
@@ -283,7 +285,7 @@ extern "C" int cn_set_wgrad_parallelism(int blocks) {
 
 template <typename T, int BMW, int BNW>
 static void launch_wgrad(WgradGeom& g, int taps, hipStream_t st) {
-    constexpr int BKP = sizeof(T) == 2 ? 32 : 16;
+    constexpr int BKP = sizeof(T) == 2 ? ((BMW + BNW <= 192) ? 64 : 32) : 16;      // as in the kernel
     int co_tiles = cdiv(g.Co, BMW);
     g.ci_tiles = cdiv(g.Ci, BNW);
     int base = co_tiles * g.ci_tiles * taps;
