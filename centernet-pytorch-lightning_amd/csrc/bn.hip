@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            const float* __restrict__ ss, T* __restrict__ dx,
-                                                           T* __restrict__ dres, int64_t npix, int C, BnLayout L, int relu) {
+                                                           T* __restrict__ dres, const T* __restrict__ racc, int64_t npix, int C,
+                                                           BnLayout L, int relu) {
     constexpr int V = Vec16<T>::N;
     constexpr int U = 4;
     const int tid = threadIdx.x;
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int64_t r0 = (int64_t)blockIdx.x * L.rows_per_blk;
     const int64_t r1 = r0 + L.rows_per_blk < npix ? r0 + L.rows_per_blk : npix;
     for (int64_t rb = r0 + prow; rb < r1; rb += (int64_t)U * L.RPB) {
-        uint4 gr[U], xr[U], yr[U];
+        uint4 gr[U], xr[U], yr[U], ar[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t r = rb + (int64_t)u * L.RPB;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             gr[u] = ldg16(dy + rc * C + cv * V);
             xr[u] = ldg16(x + rc * C + cv * V);
             if (relu && !mask_x) yr[u] = ldg16(y + rc * C + cv * V);
+            if (racc) ar[u] = ldg16(racc + rc * C + cv * V);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -292,7 +294,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                     for (int j = 0; j < V; ++j) gv[j] = yv[j] > 0.f ? gv[j] : 0.f;
                 }
             }
-            if (dres && r < r1) Vec16<T>::store(dres + r * C + cv * V, gv);
+            if (dres && r < r1) {
+                if (racc) {                                // the residual input is a shared tensor: add what its other consumers sent
+                    float av[V], rv[V];
+                    Vec16<T>::unpack(ar[u], av);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) rv[j] = gv[j] + av[j];
+                    Vec16<T>::store(dres + r * C + cv * V, rv);
+                } else {
+                    Vec16<T>::store(dres + r * C + cv * V, gv);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < V; ++j) xv[j] = fmaf(ca[j], gv[j], fmaf(cp[j], xv[j], cq[j]));
             if (r < r1) Vec16<T>::store(dx + r * C + cv * V, xv);
@@ -406,10 +418,11 @@ extern "C" int cn_scale_shift_act(const void* x, const void* residual, void* y, 
     return CN_OK;
 }
 
-extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
-                               const float* save_invstd, const float* scale_shift, void* dx, void* dres, float* dgamma,
-                               float* dbeta, int accumulate, int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes,
-                               void* stream) {
+extern "C" int cn_bn_train_bwd_acc(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                                   const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
+                                   float* dgamma, float* dbeta, int accumulate, int64_t npix, int C, int relu, int dtype, void* ws,
+                                   size_t ws_bytes, void* stream) {
+    CN_CHECK_ARG(!dres_acc || dres, "cn_bn_train_bwd_acc: dres_acc without dres");
     CN_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws && npix > 0 && C > 0,
                  "cn_bn_train_bwd: bad args");
     CN_CHECK_ARG(!relu || y || scale_shift, "cn_bn_train_bwd: relu needs the forward output or the saved scale/shift");
@@ -430,9 +443,17 @@ extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, con
     BnLayout E = ew_layout(npix, C, V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, st,
                                                    (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, coef,
-                                                   scale_shift, (T*)dx, (T*)dres, npix, C, E, relu));
+                                                   scale_shift, (T*)dx, (T*)dres, (const T*)dres_acc, npix, C, E, relu));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(apply)");
     return CN_OK;
+}
+
+extern "C" int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                               const float* save_invstd, const float* scale_shift, void* dx, void* dres, float* dgamma,
+                               float* dbeta, int accumulate, int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes,
+                               void* stream) {
+    return cn_bn_train_bwd_acc(dy, x, y, gamma, save_mean, save_invstd, scale_shift, dx, dres, nullptr, dgamma, dbeta, accumulate,
+                               npix, C, relu, dtype, ws, ws_bytes, stream);
 }
 
 extern "C" int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream) {

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 // windows' x values are not re-read (the first version recomputed every arg-max from x: 2.2x the traffic of this one).
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ dy,
-                                                          T* __restrict__ dx, int N, int H, int W, int CV, int k, int s,
-                                                          int p, int OH, int OW) {
+                                                          const T* __restrict__ acc, T* __restrict__ dx, int N, int H, int W,
+                                                          int CV, int k, int s, int p, int OH, int OW) {
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -61,8 +61,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* _
         pix /= (uint32_t)W;
         const int ih = (int)(pix % (uint32_t)H), n = (int)(pix / (uint32_t)H);
         float g[V];
+        if (acc) {                                             // x is a shared tensor: start from what its other consumers sent
+            Vec16<T>::load(acc + i * V, g);
+        } else {
 #pragma unroll
-        for (int j = 0; j < V; ++j) g[j] = 0.f;
+            for (int j = 0; j < V; ++j) g[j] = 0.f;
+        }
         int oh_lo = ih + p - k + 1;
         oh_lo = oh_lo > 0 ? (oh_lo + s - 1) / s : 0;
         int oh_hi = (ih + p) / s;
@@ -376,16 +380,21 @@ extern "C" int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int
     return CN_OK;
 }
 
-extern "C" int cn_maxpool_bwd(const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
-                              int OH, int OW, int dtype, void* stream) {
+extern "C" int cn_maxpool_bwd_acc(const unsigned char* argmax, const void* dy, const void* acc, void* dx, int N, int H, int W, int C, int k,
+                                  int stride, int pad, int OH, int OW, int dtype, void* stream) {
     CN_CHECK_ARG(argmax && dy && dx, "cn_maxpool_bwd: null");
     POOL_ARGS_CHECK("cn_maxpool_bwd");
     int64_t total = (int64_t)N * H * W * (C / V);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(pool_grid(total)), dim3(256), 0,
-                                                   (hipStream_t)stream, argmax, (const T*)dy, (T*)dx, N, H, W, C / V, k,
+                                                   (hipStream_t)stream, argmax, (const T*)dy, (const T*)acc, (T*)dx, N, H, W, C / V, k,
                                                    stride, pad, OH, OW));
     CN_LAUNCH_CHECK("cn_maxpool_bwd");
     return CN_OK;
+}
+
+extern "C" int cn_maxpool_bwd(const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
+                              int OH, int OW, int dtype, void* stream) {
+    return cn_maxpool_bwd_acc(argmax, dy, nullptr, dx, N, H, W, C, k, stride, pad, OH, OW, dtype, stream);
 }
 
 extern "C" int cn_dwdeconv_fwd(const void* x, const float* w, const void* residual, void* y, int N, int H, int W, int C, int k, int stride,

@@ -87,7 +87,10 @@ class Tree(nn.Module):
         max-pool forward/backward pair and one full-resolution gradient accumulation per two-level tree — same values)."""
         children = [] if children is None else children
         if bottom is None:
-            bottom = self.downsample(x) if self.downsample is not None else x
+            # x feeds the pooling AND tree1; the pooled tensor feeds project / the inner tree / a Root: shared tensors sum their
+            # consumers' gradients in those consumers' own epilogues (ops.GradCell) instead of in autograd's add passes
+            x = ops.share(x)
+            bottom = ops.share(self.downsample(x)) if self.downsample is not None else x
         if self.levels == 1:
             residual = hnn.conv_bn_act(self.project[0], self.project[1], bottom, None, False) if self.project else bottom
         elif self.project is not None and self.project[1].training:
@@ -98,9 +101,9 @@ class Tree(nn.Module):
         if self.levels == 1:
             # stride-1, same-width tree: the residual IS x, so let the block take its own skip path (the skip gradient then
             # joins conv1's data gradient in that kernel's epilogue instead of in an element-wise pass of the autograd engine)
-            x1 = self.tree1(x, None if residual is x else residual)
+            x1 = ops.share(self.tree1(x, None if residual is x else residual))
             return self.root(self.tree2(x1), x1, *children)
-        x1 = self.tree1(x, bottom=bottom if self.downsample is not None and not _POOL_TWICE else None)
+        x1 = ops.share(self.tree1(x, bottom=bottom if self.downsample is not None and not _POOL_TWICE else None))
         children.append(x1)
         return self.tree2(x1, children=children)
 
@@ -140,6 +143,8 @@ class DLA(nn.Module):
         for i in range(6):
             level = getattr(self, f"level{i}")
             x = self._run_conv_level(level, x) if i < 2 else level(x)
+            if i >= 2:
+                x = ops.share(x)        # a level's output feeds the next level and the up path
             y.append(x)
         return y
 
@@ -185,7 +190,7 @@ class IDAUp(nn.Module):
         for i in range(startp + 1, endp):
             j = i - startp
             merged = getattr(self, f"up_{j}")(getattr(self, f"proj_{j}")(layers[i]), layers[i - 1])    # up(proj(x)) + layers[i-1]
-            layers[i] = getattr(self, f"node_{j}")(merged)
+            layers[i] = ops.share(getattr(self, f"node_{j}")(merged))     # later stages read it as DCN input and as skip operand
 
 
 class DLAUp(nn.Module):

@@ -74,6 +74,8 @@ class CenterHead(nn.Module):
 
     def forward(self, x):
         x = self._to_engine(x)
+        if len(self.heads) > 1:
+            x = ops.share(x)      # sibling heads read one map: their data gradients are summed in the conv epilogues (ops.GradCell)
         return {name: self._modules[name](x) for name in self.heads}
 
     def init_weights(self):

@@ -138,6 +138,90 @@ class GradReady:
                     cls.claim_sink(p)
 
 
+class GradCell:
+    """Gradient accumulator of ONE activation tensor that has several consumers (`share`).
+
+    Autograd sums the gradients of a multiply-used tensor with one element-wise add per extra consumer (25 bf16 passes per DLA-34
+    step, 3 tensor passes each).  Here the consumers' backward functions talk to each other instead: whoever finishes first `give`s
+    its gradient to the cell (free), every later one `take`s what is there and adds it in the EPILOGUE of its own data-gradient
+    kernel (the residual input of the conv kernels, cn_bn_train_bwd_acc, cn_maxpool_bwd_acc) before giving the sum back, and
+    all of them return None to autograd; `ShareFn.backward`, which autograd runs once every consumer is done, hands the cell's
+    content to the producer.  A consumer without an epilogue slot (DCNv2's sampling gradient, a pass-through residual) that finds
+    the cell occupied pays one cn_add; consumers that know nothing about cells return their gradient as usual and are summed in
+    `ShareFn.backward` — the result is the same sum in every case (bf16 rounding of partial sums as with autograd's own adds)."""
+    __slots__ = ("partial",)
+    enabled = not _os.environ.get("CN_DISABLE_GRAD_CELLS")
+    adds = 0            # cn_add launches spent on cells (tests / profiling)
+
+    def __init__(self):
+        self.partial = None
+
+    def take(self, like=None):
+        """-> the gradient accumulated so far (None if nothing), handing its ownership to the caller; with `like` given only when
+        it has exactly that tensor's shape and dtype (an epilogue slot reads it element for element)"""
+        g = self.partial
+        if g is None or (like is not None and (g.shape != like.shape or g.dtype != like.dtype)):
+            return None
+        self.partial = None
+        return g
+
+    def give(self, g):
+        """add g to the cell; -> None (what the consumer returns to autograd for this input)"""
+        if g is None:
+            return None
+        if self.partial is None:
+            self.partial = g
+        else:
+            self.partial = _add_tensors(self.partial, g)
+        return None
+
+
+def _add_tensors(a, b):
+    if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float32):
+        return a + b
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    call("cn_add", a, b, out, a.numel(), dtype_code(a.dtype))
+    GradCell.adds += 1
+    return out
+
+
+class ShareFn(Function):
+    """Identity whose output carries a GradCell (see there); the producer's gradient is the cell's content plus whatever
+    cell-unaware consumers returned through autograd."""
+
+    @staticmethod
+    def forward(ctx, x, cell):
+        ctx.cell = cell
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        total = ctx.cell.take()
+        if g is not None:
+            total = g if total is None else _add_tensors(total, g)
+        return total, None
+
+
+def cell_of(t):
+    return getattr(t, "_grad_cell", None) if t is not None else None
+
+
+def share(x):
+    """Declare that activation x feeds several layers (DLA trees: pose_dla_dcn.py:245-262; IDAUp: :482-488; the task heads:
+    heads.py:38-43).  No-op without autograd, or when x is already shared."""
+    if not (GradCell.enabled and torch.is_grad_enabled() and x.requires_grad) or cell_of(x) is not None:
+        return x
+    cell = GradCell()
+    y = ShareFn.apply(x, cell)
+    y._grad_cell = cell
+    for attr in ("_cn_nhwc", "_bn_part"):
+        if hasattr(x, attr):
+            setattr(y, attr, getattr(x, attr))
+    return y
+
+
 class PackArena:
     """Every weight packing a training step needs, produced by ONE launch at the start of the step.
 
@@ -373,13 +457,19 @@ class Conv2dFn(Function):
         ctx.bias_ref = bias
         ctx.order = SideGrads.next_order()
         ctx.passthrough = passthrough
+        ctx.cell = cell_of(x)
         if passthrough:
+            ctx.set_materialize_grads(False)      # a skip path that reports to x's GradCell sends None here, not a zero tensor
             return y, x.view_as(x)
         return y
 
     @staticmethod
     def backward(ctx, dy, dskip=None):
         x, weight, y = ctx.saved_tensors
+        if dy is None:                            # only the skip path carried a gradient
+            if ctx.cell is not None:
+                dskip = ctx.cell.give(dskip)
+            return dskip, None, None, None, None, None, None, None, None, None
         stride, pad, relu, has_bias = ctx.cfg
         Co, Ci, KH, KW = weight.shape
         N, H, W, Cx = x.shape
@@ -412,13 +502,19 @@ class Conv2dFn(Function):
                 dx = _igemm(dy, wpd, None, x, Ci, KH, KW, stride, pad, True, 2, H, W)
             else:
                 skip = dskip.contiguous() if (dskip is not None and dskip.dtype == x.dtype and dskip.shape == x.shape) else None
-                dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
                 if skip is not None:
                     dskip = None                                  # folded into the epilogue
+                elif ctx.cell is not None and not (stride == 2 and KH == 3 and (Co, Ci) in ((32, 16), (64, 32))):
+                    # x is shared: what its other consumers sent rides in the epilogue's residual slot (the two stride-2 shapes
+                    # with a dedicated data-gradient kernel keep it: that kernel has no residual input)
+                    skip = ctx.cell.take(like=x)
+                dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
             if dskip is not None:
-                dx = dx + dskip
+                dx = _add_tensors(dx, dskip)
         elif dskip is not None:
             dx = dskip
+        if ctx.cell is not None:
+            dx = ctx.cell.give(dx)
         return dx, dw, db, None, None, None, None, None, None, None
 
 
@@ -450,11 +546,13 @@ class Conv1x1CatFn(Function):
     @staticmethod
     def forward(ctx, weight, bn_stats, *xs):
         Co = weight.shape[0]
+        cells = [cell_of(t) for t in xs]
         xs = tuple(t.contiguous() for t in xs)
         assert sum(t.shape[-1] for t in xs) == weight.shape[1], "Root conv: channel counts of the children do not add up"
         y = conv1x1_cat_raw(xs, pack_weight(weight, 1, xs[0].dtype), None, None, Co, False, bn_stats=bn_stats)
         ctx.save_for_backward(weight, *xs)
         ctx.order = SideGrads.next_order()
+        ctx.cells = cells
         return y
 
     @staticmethod
@@ -489,7 +587,11 @@ class Conv1x1CatFn(Function):
             wpd = pack_weight(weight, 0, dt)          # rows = input channel (of the concatenation), k = rup(Co, 16)
             for i, (c, k0) in enumerate(zip(chans, offs)):
                 if ctx.needs_input_grad[2 + i]:
-                    dxs[i] = _igemm(dy, wpd[k0:k0 + c], None, None, c, 1, 1, 1, 0, True, False, H, W)
+                    cell = ctx.cells[i]
+                    acc = cell.take(like=xs[i]) if cell is not None else None      # shared child: sum in the epilogue
+                    dxs[i] = _igemm(dy, wpd[k0:k0 + c], None, acc, c, 1, 1, 1, 0, True, False, H, W)
+                    if cell is not None:
+                        dxs[i] = cell.give(dxs[i])
         return (dw, None, *dxs)
 
 
@@ -607,6 +709,7 @@ class BatchNormActFn(Function):
         ctx.save_for_backward(x, y if need_y else None, gamma, stats)
         ctx.beta_ref = beta
         ctx.cfg = (relu, residual is not None)
+        ctx.res_cell = cell_of(residual)
         return y
 
     @staticmethod
@@ -621,16 +724,18 @@ class BatchNormActFn(Function):
         dres = torch.empty_like(x) if has_res else None
         ws, n = _bn_ws(npix, C, x.device)
         beta = ctx.beta_ref
+        cell = ctx.res_cell if has_res else None
+        racc = cell.take(like=x) if cell is not None else None       # shared residual input: its other consumers' sum joins in the store
         if SideGrads.usable(gamma, beta):      # inside a TrainStep: deposit straight into the flat gradient buffer
-            call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, gamma.grad, beta.grad, 1, npix, C,
+            call("cn_bn_train_bwd_acc", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, gamma.grad, beta.grad, 1, npix, C,
                  int(relu), dtype_code(x.dtype), ws, n)
             GradReady.note(gamma, beta)
-            return dx, None, None, None, None, dres, None, None
+            return dx, None, None, None, None, (cell.give(dres) if cell is not None else dres), None, None
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        call("cn_bn_train_bwd", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, dgamma, dbeta, 0, npix, C, int(relu),
+        call("cn_bn_train_bwd_acc", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, dgamma, dbeta, 0, npix, C, int(relu),
              dtype_code(x.dtype), ws, n)
-        return dx, dgamma, dbeta, None, None, dres, None, None
+        return dx, dgamma, dbeta, None, None, (cell.give(dres) if cell is not None else dres), None, None
 
 
 class ScaleShiftActFn(Function):
@@ -679,6 +784,7 @@ class MaxPoolFn(Function):
         call("cn_maxpool_fwd", x, y, idx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
         ctx.save_for_backward(idx)
         ctx.cfg = (k, stride, pad, OH, OW, (N, H, W, C), x.dtype)
+        ctx.cell = cell_of(x)
         return y
 
     @staticmethod
@@ -686,8 +792,9 @@ class MaxPoolFn(Function):
         (idx,) = ctx.saved_tensors
         k, stride, pad, OH, OW, (N, H, W, C), dt = ctx.cfg
         dx = torch.empty((N, H, W, C), dtype=dt, device=dy.device)
-        call("cn_maxpool_bwd", idx, dy.contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(dt))
-        return dx, None, None, None
+        acc = ctx.cell.take(like=dx) if ctx.cell is not None else None
+        call("cn_maxpool_bwd_acc", idx, dy.contiguous(), acc, dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(dt))
+        return (ctx.cell.give(dx) if ctx.cell is not None else dx), None, None, None
 
 
 class DwDeconvFn(Function):
@@ -704,6 +811,7 @@ class DwDeconvFn(Function):
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, pad, OH, OW)
         ctx.has_res = residual is not None
+        ctx.cells = (cell_of(x), cell_of(residual))
         return y
 
     @staticmethod
@@ -725,7 +833,12 @@ class DwDeconvFn(Function):
         elif ctx.needs_input_grad[1]:
             dw = torch.zeros_like(weight, dtype=torch.float32)
             call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
-        return dx, dw, None, None, (dy if ctx.has_res else None)
+        dres = dy if ctx.has_res else None
+        if ctx.cells[0] is not None and dx is not None:
+            dx = ctx.cells[0].give(dx)
+        if ctx.cells[1] is not None:
+            dres = ctx.cells[1].give(dres)
+        return dx, dw, None, None, dres
 
 
 class AddFn(Function):
@@ -887,6 +1000,7 @@ class DCNv2Fn(Function):
             col = None
         ctx.save_for_backward(x, om, col, weight, om_weight)
         ctx.params = (bias, om_weight, om_bias)
+        ctx.cell = cell_of(x)
         return y
 
     @staticmethod
@@ -984,6 +1098,8 @@ class DCNv2Fn(Function):
         dx = torch.empty_like(x)
         call("cn_conv2d_fwd", dom, wpo, None, dx_s, dx, N, H, W, om.shape[-1], om.shape[-1], H, W, Ci, Ci, Ci,
              3, 3, 1, 1, 1, 0, dt, dt)
+        if ctx.cell is not None:
+            dx = ctx.cell.give(dx)
         return dx, dw, db, dw_om, db_om, None
 
 
@@ -1111,6 +1227,8 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, def
     out = Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd, passthrough, bn_stats)
     if bn_stats:
         BnStats.pop(out[0] if passthrough else out)
+    if passthrough and cell_of(x) is not None:
+        out[1]._grad_cell = cell_of(x)       # the skip path of a shared tensor reports to the same cell (its consumer runs first)
     return out
 
 

@@ -152,6 +152,13 @@ int cn_scale_shift_act(const void* x, const void* residual, void* y, const float
 int cn_bn_train_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
                     const float* save_invstd, const float* scale_shift, void* dx, void* dres, float* dgamma, float* dbeta,
                     int accumulate, int64_t npix, int C, int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* the same with dres = masked dy + dres_acc (nullable, same layout as dres): the residual input is a tensor with several consumers
+ * (pose_dla_dcn.py:60-68: a block's input feeds conv1 AND the skip path; :262 it is also a child of the Root) whose other
+ * consumers' gradients are already summed in dres_acc — the sum happens in this store instead of in autograd's add pass */
+int cn_bn_train_bwd_acc(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                        const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
+                        float* dgamma, float* dbeta, int accumulate, int64_t npix, int C, int relu, int dtype, void* ws,
+                        size_t ws_bytes, void* stream);
 /* dx = dy * (y > 0)  (ReLU backward for conv+bias+ReLU heads) */
 int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 
@@ -162,6 +169,10 @@ int cn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int N, int H, 
                    int OH, int OW, int dtype, void* stream);
 int cn_maxpool_bwd(const unsigned char* argmax, const void* dy, void* dx, int N, int H, int W, int C, int k, int stride, int pad,
                    int OH, int OW, int dtype, void* stream);
+/* dx = acc + routed dy (acc nullable, [N,H,W,C]): the pooled tensor also feeds other layers (pose_dla_dcn.py:245-262: a Tree's
+ * input goes through `downsample` AND `tree1`), whose summed gradients arrive in acc */
+int cn_maxpool_bwd_acc(const unsigned char* argmax, const void* dy, const void* acc, void* dx, int N, int H, int W, int C, int k,
+                       int stride, int pad, int OH, int OW, int dtype, void* stream);
 /* Hourglass merge (large_hourglass.py:108-125 MergeUp/make_unpool_layer, :196-204 kp_module.forward):
  * y[N,2H,2W,C] = a + nearest_up2x(low[N,H,W,C]); a == NULL gives plain nn.Upsample(scale_factor=2).  Backward of the
  * up-sampled operand: dlow[N,H,W,C] = 2x2 block sums of dy[N,2H,2W,C] (the `a` operand's gradient is dy itself). */

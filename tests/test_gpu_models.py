@@ -522,3 +522,45 @@ def test_training_next_to_overlapped_decode_survives(tmp_path):
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-800:])
     last = [l for l in r.stdout.splitlines() if l.startswith("step 120:")]
     assert last and "params finite True" in last[0], r.stdout[-800:]
+
+
+def _dla_grads(dtype, cells, seed=11, size=128, batch=2):
+    from centernet_amd import ops
+    old = ops.GradCell.enabled
+    ops.GradCell.enabled = cells
+    ops.GradCell.adds = 0
+    try:
+        m = _model("dla_34", seed, dtype)
+        m.train()
+        x, tgt = synth.ctdet_batch(seed, batch, size, size)
+        outs = m(x.to(DEV))
+        loss, _ = m.loss(outs, {k: v.to(DEV) for k, v in tgt.items()})
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}, ops.GradCell.adds
+    finally:
+        ops.GradCell.enabled = old
+
+
+def test_shared_tensor_gradients_summed_in_epilogues_match_autograd_sums():
+    """ops.GradCell (gradients of multiply-used activations summed in their consumers' kernel epilogues) against autograd's own
+    accumulation (CN_DISABLE_GRAD_CELLS path) on the whole DLA-34 graph: pose_dla_dcn.py:245-262 (Tree fan-outs), :482-488 (IDAUp),
+    heads.py:38-43 (sibling heads).  fp32: the two differ by summation order only; bf16: by the rounding of partial sums."""
+    l0, g0, a0 = _dla_grads(torch.float32, False)
+    l1, g1, a1 = _dla_grads(torch.float32, True)
+    assert a0 == 0 and l0 == pytest.approx(l1, rel=1e-6)
+    assert set(g0) == set(g1)
+    # 25 autograd adds per step before; with cells only a consumer without an epilogue slot that finds the cell occupied pays one
+    assert 0 < a1 <= 6, a1
+    # (a bias in front of a batch-statistic BN has a zero gradient up to rounding noise: absolute floor from the largest gradient)
+    floor = 1e-6 * max(float(v.norm()) for v in g0.values())
+    for n in g0:
+        den = float(g0[n].norm()) + 1e-20
+        assert float((g0[n] - g1[n]).norm()) <= 2e-3 * den + floor, (n, float((g0[n] - g1[n]).norm()) / den)
+    # bf16: same graph, same kernels, partial sums rounded at different points
+    _, h0, _ = _dla_grads(torch.bfloat16, False)
+    _, h1, _ = _dla_grads(torch.bfloat16, True)
+    floor = 1e-3 * max(float(v.norm()) for v in h0.values())
+    for n in h0:
+        den = float(h0[n].norm()) + 1e-20
+        assert float((h0[n] - h1[n]).norm()) <= 0.12 * den + floor, (n, float((h0[n] - h1[n]).norm()) / den)
