@@ -49,7 +49,8 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                          const T* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ ss,
-                                                         float* __restrict__ part, int64_t npix, int C, BnLayout L, int relu) {
+                                                         float* __restrict__ part, int64_t npix, int C, BnLayout L, int relu,
+                                                         int sink_slots) {
     constexpr int V = Vec16<T>::N;
     constexpr int U = 4;                                   // rows in flight per thread
     __shared__ float red[2][256][V + 1];
@@ -129,10 +130,135 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
         __syncthreads();
     }
     if (prow == 0 && cv < L.CV) {
+        if (sink_slots > 0) {       // statistics sink (all-zero on entry): the apply kernel reduces its rows itself, no finalize launch
+            float* row = part + ((int64_t)(blockIdx.x % sink_slots) * 2) * C + cv * V;
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            part[((int64_t)blockIdx.x * 2 + 0) * C + cv * V + j] = red[0][tid][j];
-            part[((int64_t)blockIdx.x * 2 + 1) * C + cv * V + j] = red[1][tid][j];
+            for (int j = 0; j < V; ++j) { atomicAdd(row + j, red[0][tid][j]); atomicAdd(row + C + j, red[1][tid][j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                part[((int64_t)blockIdx.x * 2 + 0) * C + cv * V + j] = red[0][tid][j];
+                part[((int64_t)blockIdx.x * 2 + 1) * C + cv * V + j] = red[1][tid][j];
+            }
+        }
+    }
+}
+
+// ---- statistics sinks reduced by their consumer: the element-wise kernels below take part[slots][2][C] (filled by the producing
+// conv's epilogue in the forward pass, by bn_partial_kernel<1> in the backward pass) and every workgroup reduces the rows of its own
+// channel vectors in its prologue (slots * 2 * C * 4 bytes from L2), instead of a 6-10 us finalize launch in front of every BN
+// pass (106 dependent launches per DLA-34 step).  Workgroup column 0 also writes what the finalize kernels wrote (saved
+// statistics, running statistics, dgamma / dbeta).  A sink cannot be cleared by the kernel that reads it (no grid-wide order), so
+// each of these kernels clears ANOTHER sink whose readers have all retired: the one the previous BN pass on the stream consumed.
+template <int V>
+__device__ inline void bn_sink_totals(const float* __restrict__ part, int slots, int C, const BnLayout& L, int cv, bool cv_ok,
+                                      float (*red)[256][V + 1], float (&t0)[V], float (&t1)[V]) {
+    const int tid = threadIdx.x, cvl = tid % L.CVB, prow = tid / L.CVB;
+    float s0[V], s1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    if (cv_ok && prow < L.RPB) {
+        for (int sl = prow; sl < slots; sl += L.RPB) {
+            const float* p = part + ((int64_t)sl * 2) * C + cv * V;
+#pragma unroll
+            for (int v = 0; v < V / 4; ++v) {
+                const float4 a = *reinterpret_cast<const float4*>(p + 4 * v);
+                const float4 b = *reinterpret_cast<const float4*>(p + C + 4 * v);
+                s0[4 * v] += a.x; s0[4 * v + 1] += a.y; s0[4 * v + 2] += a.z; s0[4 * v + 3] += a.w;
+                s1[4 * v] += b.x; s1[4 * v + 1] += b.y; s1[4 * v + 2] += b.z; s1[4 * v + 3] += b.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[0][tid][j] = s0[j]; red[1][tid][j] = s1[j]; }
+    __syncthreads();
+    int top = 1;
+    while (top < L.RPB) top <<= 1;
+    for (int st = top >> 1; st > 0; st >>= 1) {
+        if (prow < st && prow + st < L.RPB) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) { red[0][tid][j] += red[0][tid + st * L.CVB][j]; red[1][tid][j] += red[1][tid + st * L.CVB][j]; }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { t0[j] = red[0][cvl][j]; t1[j] = red[1][cvl][j]; }      // row slot 0 of the column holds the totals
+}
+
+__device__ inline void bn_clear_retired(float* __restrict__ clear, int clear_n) {
+    if (!clear) return;
+    const int nthr = gridDim.x * gridDim.y * 256;
+    for (int i = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < clear_n; i += nthr) clear[i] = 0.f;
+}
+
+// scale_shift_act_kernel with the forward finalize (bn_finalize_fwd_kernel) in its prologue
+template <typename T>
+__global__ __launch_bounds__(256) void bn_fwd_apply_sink_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                                const float* __restrict__ part, int slots,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                float* __restrict__ smean, float* __restrict__ sinvstd,
+                                                                float* __restrict__ save_ss, float momentum, float eps,
+                                                                int64_t npix, int C, BnLayout L, int relu,
+                                                                float* __restrict__ clear, int clear_n) {
+    constexpr int V = Vec16<T>::N;
+    constexpr int U = 4;
+    __shared__ float red[2][256][V + 1];
+    const int tid = threadIdx.x;
+    const int cvl = tid % L.CVB, prow = tid / L.CVB;
+    const int cv = blockIdx.y * L.CVB + cvl;
+    const bool cv_ok = cv < L.CV;
+    bn_clear_retired(clear, clear_n);
+    float t0[V], t1[V];
+    bn_sink_totals<V>(part, slots, C, L, cv, cv_ok, red, t0, t1);
+    if (prow >= L.RPB || !cv_ok) return;
+    float sc[V], sh[V];
+    const bool writer = blockIdx.x == 0 && prow == 0;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int c = cv * V + j;
+        const double m = (double)t0[j] / (double)npix;
+        double var = (double)t1[j] / (double)npix - m * m;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        sc[j] = gamma[c] * invstd;
+        sh[j] = beta[c] - (float)m * sc[j];
+        if (writer) {
+            smean[c] = (float)m;
+            sinvstd[c] = invstd;
+            if (rmean) {
+                const double unb = npix > 1 ? var * (double)npix / (double)(npix - 1) : var;
+                rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+            }
+            if (save_ss) { save_ss[c] = sc[j]; save_ss[C + c] = sh[j]; }
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * L.rows_per_blk;
+    const int64_t r1 = r0 + L.rows_per_blk < npix ? r0 + L.rows_per_blk : npix;
+    for (int64_t rb = r0 + prow; rb < r1; rb += (int64_t)U * L.RPB) {
+        uint4 xr[U], rr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + (int64_t)u * L.RPB;
+            const int64_t rc = r < r1 ? r : rb;
+            xr[u] = ldg16(x + rc * C + cv * V);
+            if (res) rr[u] = ldg16(res + rc * C + cv * V);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t r = rb + (int64_t)u * L.RPB;
+            float xv[V], rv[V];
+            Vec16<T>::unpack(xr[u], xv);
+            if (res) Vec16<T>::unpack(rr[u], rv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float v = fmaf(xv[j], sc[j], sh[j]);
+                if (res) v += rv[j];
+                if (relu) v = fmaxf(v, 0.f);
+                xv[j] = v;
+            }
+            if (r < r1) Vec16<T>::store(y + r * C + cv * V, xv);
         }
     }
 }
@@ -238,25 +364,48 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restric
 
 // dx = a (g' - b - xhat c),  xhat = (x - mean) invstd   ==   a g' + p x + q   with  p = -a c invstd,  q = -a b - p mean
 // (a = gamma invstd, b = mean(g'), c = mean(g' xhat): bn_finalize_bwd_kernel).  g' = ReLU-masked dy.
-template <typename T>
+// SINK: the statistics come from part[slots][2][C] (bn_partial_kernel<1> with atomics), reduced here (bn_finalize_bwd_kernel in the
+// prologue: coefficients, dgamma / dbeta by workgroup column 0), and `clear` (another, retired sink) is zeroed on the way
+template <typename T, bool SINK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            const float* __restrict__ ss, T* __restrict__ dx,
                                                            T* __restrict__ dres, const T* __restrict__ racc, int64_t npix, int C,
-                                                           BnLayout L, int relu) {
+                                                           BnLayout L, int relu, const float* __restrict__ part, int slots,
+                                                           const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate, float* __restrict__ clear,
+                                                           int clear_n) {
     constexpr int V = Vec16<T>::N;
     constexpr int U = 4;
+    __shared__ float red[2][SINK ? 256 : 1][V + 1];
     const int tid = threadIdx.x;
     const int cvl = tid % L.CVB, prow = tid / L.CVB;
     const int cv = blockIdx.y * L.CVB + cvl;
+    float t0[V], t1[V];
+    if constexpr (SINK) {
+        bn_clear_retired(clear, clear_n);
+        bn_sink_totals<V>(part, slots, C, L, cv, cv < L.CV, red, t0, t1);
+    }
     if (prow >= L.RPB || cv >= L.CV) return;
     const bool mask_x = relu && y == nullptr;
     float ca[V], cp[V], cq[V], sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
         const int c = cv * V + j;
-        const float a = coef[c], b = coef[C + c], cc = coef[2 * C + c], mu = mean[c], is = invstd[c];
+        float a, b, cc;
+        const float mu = mean[c], is = invstd[c];
+        if constexpr (SINK) {
+            a = gamma[c] * is;
+            b = (float)((double)t0[j] / (double)npix);
+            cc = (float)((double)t1[j] / (double)npix);
+            if (blockIdx.x == 0 && prow == 0) {
+                dbeta[c] = accumulate ? dbeta[c] + t0[j] : t0[j];
+                dgamma[c] = accumulate ? dgamma[c] + t1[j] : t1[j];
+            }
+        } else {
+            a = coef[c]; b = coef[C + c]; cc = coef[2 * C + c];
+        }
         // same operation order as the two-step form (xh = (x - mu) * is; a * (g - b - xh * cc)) is NOT kept: the fused affine
         // differs from it by rounding only (fp32), far below the bf16 / 2e-5 test tolerances
         ca[j] = a;
@@ -345,7 +494,7 @@ extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, con
     float* coef = part + (size_t)BN_MAX_BLOCKS * 2 * C;
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 0>), dim3(L.nblk, L.ycols), dim3(256), 0, st,
                                                    (const T*)x, (const T*)nullptr, (const T*)nullptr, (const float*)nullptr,
-                                                   (const float*)nullptr, (const float*)nullptr, part, npix, C, L, 0));
+                                                   (const float*)nullptr, (const float*)nullptr, part, npix, C, L, 0, 0));
     CN_LAUNCH_CHECK("cn_bn_train_fwd(partial)");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, beta,
                        running_mean, running_var, save_mean, save_invstd, coef, save_scale_shift, momentum, eps, (float*)nullptr);
@@ -405,6 +554,26 @@ extern "C" int cn_bn_train_fwd_stats(const void* x, const void* residual, void* 
     return CN_OK;
 }
 
+// cn_bn_train_fwd_stats as ONE launch: the apply kernel reduces `part` itself (see bn_sink_totals).  `part` is left as it is (the
+// caller retires it); `clear` (nullable, clear_n floats, 16-byte aligned, NOT `part`) is a retired sink this launch zeroes.
+extern "C" int cn_bn_train_fwd_sink(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                                    float* save_scale_shift, const float* part, int slots, float* clear, int64_t clear_n,
+                                    int64_t npix, int C, float momentum, float eps, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && part && npix > 0 && C > 0 && slots > 0 && slots <= BN_MAX_BLOCKS,
+                 "cn_bn_train_fwd_sink: bad args");
+    CN_CHECK_ARG(clear != part && clear_n >= 0 && clear_n < (1 << 30), "cn_bn_train_fwd_sink: a launch cannot clear the sink it reads");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0 && C % 4 == 0, "cn_bn_train_fwd_sink: C=%d must be a multiple of %d", C, V);
+    BnLayout E = ew_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_fwd_apply_sink_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (const T*)residual, (T*)y, part, slots, gamma, beta, running_mean,
+                                                   running_var, save_mean, save_invstd, save_scale_shift, momentum, eps, npix, C, E,
+                                                   relu, clear, (int)clear_n));
+    CN_LAUNCH_CHECK("cn_bn_train_fwd_sink");
+    return CN_OK;
+}
+
 extern "C" int cn_scale_shift_act(const void* x, const void* residual, void* y, const float* scale, const float* shift,
                                   int64_t npix, int C, int relu, int dtype, void* stream) {
     CN_CHECK_ARG(x && y && scale && shift && npix > 0 && C > 0, "cn_scale_shift_act: bad args");
@@ -435,16 +604,47 @@ extern "C" int cn_bn_train_bwd_acc(const void* dy, const void* x, const void* y,
     float* coef = part + (size_t)BN_MAX_BLOCKS * 2 * C;
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3(L.nblk, L.ycols), dim3(256), 0, st,
                                                    (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, scale_shift, part,
-                                                   npix, C, L, relu));
+                                                   npix, C, L, relu, 0));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(partial)");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, part, L.nblk, C, npix, gamma, save_invstd,
                        dgamma, dbeta, coef, accumulate);
     CN_LAUNCH_CHECK("cn_bn_train_bwd(finalize)");
     BnLayout E = ew_layout(npix, C, V);
-    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, st,
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(E.nblk, E.ycols), dim3(256), 0, st,
                                                    (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, coef,
-                                                   scale_shift, (T*)dx, (T*)dres, (const T*)dres_acc, npix, C, E, relu));
+                                                   scale_shift, (T*)dx, (T*)dres, (const T*)dres_acc, npix, C, E, relu,
+                                                   (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0,
+                                                   (float*)nullptr, 0));
     CN_LAUNCH_CHECK("cn_bn_train_bwd(apply)");
+    return CN_OK;
+}
+
+// cn_bn_train_bwd_acc as TWO launches: the statistics pass adds its per-workgroup sums to `sink` (fp32 [slots][2][C], all-zero on
+// entry, fp32 atomics: the summation order of the batch sums then varies from run to run like the forward sinks') and the apply
+// pass reduces it itself (no finalize launch).  `sink` is left as it is (the caller retires it); `clear` as in cn_bn_train_fwd_sink.
+extern "C" int cn_bn_train_bwd_sink(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
+                                    float* dgamma, float* dbeta, int accumulate, float* sink, int slots, float* clear, int64_t clear_n,
+                                    int64_t npix, int C, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(!dres_acc || dres, "cn_bn_train_bwd_sink: dres_acc without dres");
+    CN_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sink && npix > 0 && C > 0 && slots > 0 &&
+                     slots <= BN_MAX_BLOCKS, "cn_bn_train_bwd_sink: bad args");
+    CN_CHECK_ARG(!relu || y || scale_shift, "cn_bn_train_bwd_sink: relu needs the forward output or the saved scale/shift");
+    CN_CHECK_ARG(clear != sink && clear_n >= 0 && clear_n < (1 << 30), "cn_bn_train_bwd_sink: a launch cannot clear the sink it reads");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0 && C % 4 == 0, "cn_bn_train_bwd_sink: C=%d must be a multiple of %d", C, V);
+    hipStream_t st = (hipStream_t)stream;
+    BnLayout L = bn_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3(L.nblk, L.ycols), dim3(256), 0, st,
+                                                   (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, scale_shift, sink,
+                                                   npix, C, L, relu, slots));
+    CN_LAUNCH_CHECK("cn_bn_train_bwd_sink(partial)");
+    BnLayout E = ew_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(E.nblk, E.ycols), dim3(256), 0, st,
+                                                   (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, (const float*)nullptr,
+                                                   scale_shift, (T*)dx, (T*)dres, (const T*)dres_acc, npix, C, E, relu,
+                                                   (const float*)sink, slots, gamma, dgamma, dbeta, accumulate, clear, (int)clear_n));
+    CN_LAUNCH_CHECK("cn_bn_train_bwd_sink(apply)");
     return CN_OK;
 }
 

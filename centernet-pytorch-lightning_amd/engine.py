@@ -398,6 +398,7 @@ class TrainStep:
         PackArena.current = None
 
     def _eager(self, batch, batch_idx=0):
+        ops.BnStats.ns = id(self)              # this step's chain of BatchNorm statistics sinks (kept apart from other steps' graphs)
         self.opt.zero_grad()
         self._begin_packs()
         try:
@@ -477,6 +478,7 @@ class TrainStep:
         mode = "thread_local" if (dist.is_initialized() or os.environ.get("CN_CAPTURE_THREAD_LOCAL")) else "global"
         # capture on the stream the warm-up steps ran on: `_hip.workspace` is keyed by stream, so the capture replays into the
         # buffers the warm-up sized instead of allocating a second set from the graph's private pool
+        ops.BnStats.ns = id(self)
         with torch.cuda.graph(self._g1, stream=side, capture_error_mode=mode):
             self.opt.zero_grad()
             self._begin_packs()

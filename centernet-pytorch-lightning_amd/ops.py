@@ -67,35 +67,85 @@ def _far_buffer(shape, device):
     return buf
 
 
-_BN_SINKS = {}
-
-
 class BnStats:
     """Training-mode conv + BN: the producing kernel accumulates the batch statistics of its output in its epilogue (sink protocol of
-    cn_bn_stats_arm).  One persistent all-zero sink per (channels, device): producer and consumer are ordered on the launch
-    stream, and cn_bn_train_fwd_stats hands the sink back cleared.  `launch` arms the sink right before ONE C-ABI launch and
-    remembers whether the kernel took it; the op wrappers pick that up (`pop`) and tag the output tensor for `batch_norm_act`."""
+    cn_bn_stats_arm).  `launch` arms a sink right before ONE C-ABI launch and remembers whether the kernel took it; the op wrappers
+    pick that up (`pop`) and tag the output tensor for `batch_norm_act`.
+
+    Sinks (fp32 [slots][2][C], persistent, all-zero when handed out) are reduced by the kernel that CONSUMES them
+    (cn_bn_train_fwd_sink / cn_bn_train_bwd_sink: no finalize launch), and a kernel cannot clear what its own workgroups are still
+    reading — so the sinks form a chain on the launch stream: a consumed sink is `retired`, and the NEXT sink-consuming launch
+    zeroes it on the way.  `acquire` hands out a sink of the right width that is known to be clean (never a retired or an armed
+    one); at any time exactly one sink per namespace is dirty between steps (the last one consumed), which a replayed hipGraph
+    reproduces, so host state and device state stay in step.  `ns` (set by a TrainStep) keeps the chains of different steps /
+    graphs apart."""
     enabled = not _os.environ.get("CN_DISABLE_BN_EPILOGUE_STATS")
+    fused = not _os.environ.get("CN_DISABLE_BN_SINK_FINALIZE")      # A/B: finalize launches instead of consumer-side reduction
+    slots = int(_os.environ.get("CN_BN_SLOTS", 0))
     last = None
+    ns = None
+    _rings, _state = {}, {}
 
     @classmethod
-    def sink(cls, C, device):
-        key = (int(C), str(device))
-        buf = _BN_SINKS.get(key)
-        if buf is None:
-            buf = _BN_SINKS[key] = torch.zeros((int(_hip.query("cn_bn_stats_slots")), 2, int(C)), dtype=torch.float32, device=device)
+    def _st(cls):
+        st = cls._state.get(cls.ns)
+        if st is None:
+            st = cls._state[cls.ns] = {"dirty": set(), "retired": []}
+        return st
+
+    @classmethod
+    def acquire(cls, kind, C, device):
+        """-> a clean sink for `kind` ('f' forward statistics / 'b' backward sums); marks it dirty"""
+        if not cls.slots:
+            # consumer-side reduction: every workgroup of the apply pass reads slots * 2 * C floats from L2, so few rows (DLA-34 step:
+            # 43.0 / 42.7 / 42.1 / 42.1 / 42.2 ms with 128 / 64 / 32 / 16 / 8 rows; finalize launches + 128 rows: 42.9)
+            cls.slots = 32 if cls.fused else int(_hip.query("cn_bn_stats_slots"))
+        ring = cls._rings.setdefault((cls.ns, kind, int(C), str(device)), [])
+        st = cls._st()
+        for buf in ring:
+            if buf.data_ptr() not in st["dirty"]:
+                break
+        else:
+            buf = torch.zeros((cls.slots, 2, int(C)), dtype=torch.float32, device=device)
+            ring.append(buf)
+        st["dirty"].add(buf.data_ptr())
         return buf
+
+    @classmethod
+    def release(cls, buf):
+        """the sink was handed out but nothing wrote to it (or its consumer cleared it itself)"""
+        cls._st()["dirty"].discard(buf.data_ptr())
+
+    @classmethod
+    def retire(cls, buf):
+        """buf was just consumed by a *_sink launch -> (sink that launch should clear | None).  Call BEFORE the launch."""
+        st = cls._st()
+        clear = st["retired"].pop(0) if st["retired"] else None
+        while st["retired"]:                       # (does not happen in a regular step: at most one sink waits to be cleared)
+            extra = st["retired"].pop(0)
+            extra.zero_()
+            st["dirty"].discard(extra.data_ptr())
+        st["retired"].append(buf)
+        if clear is not None:
+            st["dirty"].discard(clear.data_ptr())
+        return clear
 
     @classmethod
     def launch(cls, want, y, name, *args):
         cls.last = None
         if not (want and cls.enabled and y.dtype == torch.bfloat16):
             return call(name, *args)
-        part = cls.sink(y.shape[-1], y.device)
+        part = cls.acquire("f", y.shape[-1], y.device)
         _hip.query("cn_bn_stats_arm", part.data_ptr(), part.shape[0], part.shape[2])
-        call(name, *args)
+        try:
+            call(name, *args)
+        except BaseException:
+            cls.release(part)
+            raise
         if _hip.query("cn_bn_stats_taken"):
             cls.last = part
+        else:
+            cls.release(part)
 
     @classmethod
     def pop(cls, y):
@@ -108,8 +158,11 @@ class BnStats:
     @classmethod
     def reset(cls):
         """after an aborted step: a producer may have filled a sink nobody consumed"""
-        for buf in _BN_SINKS.values():
-            buf.zero_()
+        for ring in cls._rings.values():
+            for buf in ring:
+                buf.zero_()
+        cls._state.clear()
+        cls.last = None
 
 
 class GradReady:
@@ -698,9 +751,15 @@ class BatchNormActFn(Function):
         stats = torch.empty((4, C), dtype=torch.float32, device=x.device)     # mean, invstd, scale, shift
         mean, invstd, ss = stats[0], stats[1], stats[2:]
         ws, n = _bn_ws(npix, C, x.device)
-        if part is not None:
+        if part is not None and BnStats.fused:
+            clear = BnStats.retire(part)          # one launch: the apply kernel reduces the sink, and zeroes the one consumed before it
+            call("cn_bn_train_fwd_sink", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd, ss,
+                 part, part.shape[0], clear, clear.numel() if clear is not None else 0, npix, C, BN_MOMENTUM, BN_EPS, int(relu),
+                 dtype_code(x.dtype))
+        elif part is not None:
             call("cn_bn_train_fwd_stats", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd, ss,
                  part, part.shape[0], npix, C, BN_MOMENTUM, BN_EPS, int(relu), dtype_code(x.dtype), ws, n)
+            BnStats.release(part)                 # handed back all-zero
         else:
             call("cn_bn_train_fwd", x, residual, y, gamma.detach(), beta.detach(), running_mean, running_var, mean, invstd, ss,
                  npix, C, BN_MOMENTUM, BN_EPS, int(relu), dtype_code(x.dtype), ws, n)
@@ -726,15 +785,27 @@ class BatchNormActFn(Function):
         beta = ctx.beta_ref
         cell = ctx.res_cell if has_res else None
         racc = cell.take(like=x) if cell is not None else None       # shared residual input: its other consumers' sum joins in the store
+        sink = clear = None
+        if BnStats.fused and x.dtype == torch.bfloat16 and C % 8 == 0:
+            # two launches instead of three: the statistics pass adds into a sink that the apply pass reduces itself
+            sink = BnStats.acquire("b", C, x.device)
+            clear = BnStats.retire(sink)
+
+        def run(dgamma, dbeta, accumulate):
+            if sink is not None:
+                call("cn_bn_train_bwd_sink", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, dgamma, dbeta, accumulate,
+                     sink, sink.shape[0], clear, clear.numel() if clear is not None else 0, npix, C, int(relu), dtype_code(x.dtype))
+            else:
+                call("cn_bn_train_bwd_acc", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, dgamma, dbeta, accumulate,
+                     npix, C, int(relu), dtype_code(x.dtype), ws, n)
+
         if SideGrads.usable(gamma, beta):      # inside a TrainStep: deposit straight into the flat gradient buffer
-            call("cn_bn_train_bwd_acc", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, gamma.grad, beta.grad, 1, npix, C,
-                 int(relu), dtype_code(x.dtype), ws, n)
+            run(gamma.grad, beta.grad, 1)
             GradReady.note(gamma, beta)
             return dx, None, None, None, None, (cell.give(dres) if cell is not None else dres), None, None
         dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-        call("cn_bn_train_bwd_acc", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, dgamma, dbeta, 0, npix, C, int(relu),
-             dtype_code(x.dtype), ws, n)
+        run(dgamma, dbeta, 0)
         return dx, dgamma, dbeta, None, None, (cell.give(dres) if cell is not None else dres), None, None
 
 

@@ -134,6 +134,15 @@ int cn_bn_train_fwd_stats(const void* x, const void* residual, void* y, const fl
                           float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                           float* save_scale_shift, float* part, int slots, int64_t npix, int C, float momentum, float eps,
                           int relu, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* cn_bn_train_fwd_stats in ONE launch: the apply kernel reduces `part` (slots * 2 * C floats from L2 per workgroup) in its prologue
+ * and its first workgroup column writes the saved / running statistics — no finalize launch in front of the pass.  `part` is NOT
+ * cleared (no kernel can clear what its own workgroups are still reading); instead the launch zeroes `clear` (nullable, clear_n
+ * floats): another sink, which an EARLIER launch on the same stream consumed.  The caller keeps the chain: every sink consumed by
+ * one of the *_sink entry points is handed as `clear` to the next one (ops.BnStats). */
+int cn_bn_train_fwd_sink(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                         float* save_scale_shift, const float* part, int slots, float* clear, int64_t clear_n,
+                         int64_t npix, int C, float momentum, float eps, int relu, int dtype, void* stream);
 /* training forward: batch statistics over npix rows; y = act(gamma*(x-mean)*invstd + beta [+ residual]);
  * updates running stats (unbiased var) in place; saves mean / invstd for backward.  save_scale_shift (nullable,
  * fp32 [2][C]) receives the per-channel affine the apply pass used (y = act(fma(x, scale, shift) [+ residual])). */
@@ -159,6 +168,13 @@ int cn_bn_train_bwd_acc(const void* dy, const void* x, const void* y, const floa
                         const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
                         float* dgamma, float* dbeta, int accumulate, int64_t npix, int C, int relu, int dtype, void* ws,
                         size_t ws_bytes, void* stream);
+/* cn_bn_train_bwd_acc in TWO launches instead of three: the statistics pass adds its per-workgroup sums into `sink` (fp32
+ * [slots][2][C], all-zero on entry; fp32 atomics) and the apply pass reduces the sink in its prologue (dgamma / dbeta written by its
+ * first workgroup column).  `sink` / `clear` follow the protocol of cn_bn_train_fwd_sink. */
+int cn_bn_train_bwd_sink(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                         const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
+                         float* dgamma, float* dbeta, int accumulate, float* sink, int slots, float* clear, int64_t clear_n,
+                         int64_t npix, int C, int relu, int dtype, void* stream);
 /* dx = dy * (y > 0)  (ReLU backward for conv+bias+ReLU heads) */
 int cn_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, int dtype, void* stream);
 

@@ -481,7 +481,8 @@ def test_failed_forward_leaves_the_bn_statistics_sinks_clean(monkeypatch):
         step(batch)
     monkeypatch.setattr(ops, "batch_norm_act", real)
     torch.cuda.synchronize()
-    assert ops._BN_SINKS and all(float(b.abs().max()) == 0.0 for b in ops._BN_SINKS.values()), "sinks cleared on the failure path"
+    sinks = [b for ring in ops.BnStats._rings.values() for b in ring]
+    assert sinks and all(float(b.abs().max()) == 0.0 for b in sinks), "sinks cleared on the failure path"
     for bn in (mod for mod in m.modules() if hasattr(mod, "_pending")):      # running statistics touched by the dead step: start clean
         bn.reset_running_stats()
     loss_after = float(step(batch))

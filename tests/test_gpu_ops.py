@@ -668,13 +668,17 @@ BN_STAT_PRODUCERS = [  # kind, N, H, W, Ci, Co, k, stride  (which kernel: see th
 ]
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("cfg", BN_STAT_PRODUCERS)
-def test_bn_statistics_from_the_producer_epilogue(cfg):
+def test_bn_statistics_from_the_producer_epilogue(cfg, fused, monkeypatch):
     """N1 (north_star: conv + BN + ReLU fused, training mode): the producing kernel fills the statistics sink with sum / sum of
-    squares of the bf16 values it stores; cn_bn_train_fwd_stats then equals cn_bn_train_fwd on the same tensor and hands the sink
-    back all-zero.  Reference: msra_resnet.py:29-58 / pose_dla_dcn.py:55-68, 435-454 (conv -> nn.BatchNorm2d in training)."""
+    squares of the bf16 values it stores; the BN on top then equals cn_bn_train_fwd on the same tensor.  fused: ONE launch
+    (cn_bn_train_fwd_sink reduces the sink in the apply kernel's prologue; the sink is zeroed by the NEXT sink-consuming launch —
+    here the BN backward, cn_bn_train_bwd_sink); not fused: finalize + apply (cn_bn_train_fwd_stats hands the sink back all-zero).
+    Reference: msra_resnet.py:29-58 / pose_dla_dcn.py:55-68, 435-454 (conv -> nn.BatchNorm2d in training)."""
     from centernet_amd import nn as hnn
     o = ops()
+    monkeypatch.setattr(o.BnStats, "fused", fused)
     kind, N, H, W, Ci, Co, k, stride = cfg
     dt = torch.bfloat16
     torch.manual_seed(3)
@@ -708,12 +712,19 @@ def test_bn_statistics_from_the_producer_epilogue(cfg):
     assert float(((got - ref).abs() / scale).max()) < 1e-5, "sum / sum of squares of the stored values"
     # BN on top: fused statistics vs the stand-alone statistics pass
     bn_a, bn_b = hnn.BatchNorm2d(y1.shape[-1]).to(DEV).train(), hnn.BatchNorm2d(y1.shape[-1]).to(DEV).train()
-    za = bn_a(y1, None, True)                                               # consumes (and clears) the sink
-    assert float(part.abs().max()) == 0.0, "the sink is handed back all-zero"
+    za = bn_a(y1, None, True)                                               # consumes the sink
+    if not fused:
+        assert float(part.abs().max()) == 0.0, "the sink is handed back all-zero"
     zb = bn_b(y0, None, True)
     close(za, zb, dt, "BN(conv) with epilogue statistics vs stand-alone statistics", scale=float(zb.detach().float().abs().max()))
     assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-4, atol=1e-6)
-    za.float().square().sum().backward()                                    # backward runs through the same saved statistics
+    # backward: same saved statistics; sums through a sink reduced by the apply pass (fused) vs partial rows + finalize launch
+    ga = torch.autograd.grad(za.float().square().sum(), [y1, bn_a.weight, bn_a.bias])
+    gb = torch.autograd.grad(zb.float().square().sum(), [y0, bn_b.weight, bn_b.bias])
+    assert float(part.abs().max()) == 0.0, "the retired sink is zeroed by the next sink-consuming launch"
+    close(ga[0], gb[0], dt, "BN backward dx", scale=float(gb[0].float().abs().max()))
+    for u, v, nm in ((ga[1], gb[1], "dgamma"), (ga[2], gb[2], "dbeta")):
+        assert float((u - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, nm
 
 
 def test_bn_statistics_hook_can_be_declined(monkeypatch):
