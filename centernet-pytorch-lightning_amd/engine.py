@@ -471,6 +471,13 @@ class TrainStep:
             m._pending = n
         WeightsEpoch.bump()
         torch.cuda.synchronize()
+        if dist.is_initialized():
+            # the process group's watchdog thread wakes every 100 ms to reap finished collectives; let it retire the warm-up steps'
+            # work objects before the capture starts, so that it has nothing to poll while this stream (and RCCL's own, which
+            # joins the capture) is capturing — an event query landing in that window ends the process (hipErrorCapturedEvent,
+            # seen in about one of four runs of test_rccl_exchange_next_to_graphs)
+            import time
+            time.sleep(0.35)
         if os.environ.get("CN_FAIL_CAPTURE"):
             raise RuntimeError("CN_FAIL_CAPTURE set (test hook for the eager fallback)")
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

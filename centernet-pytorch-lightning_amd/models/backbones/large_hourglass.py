@@ -59,6 +59,7 @@ class Residual(nn.Module):
         if len(self.skip) == 0:
             y, idt = hnn.conv_bn_act_skip(self.conv1, self.bn1, x)
         else:
+            x = ops.share(x)          # skip projection + conv1: data gradients summed in a kernel epilogue (ops.GradCell)
             idt = hnn.conv_bn_act(self.skip[0], self.skip[1], x, None, False)
             y = hnn.conv_bn_act(self.conv1, self.bn1, x)
         return hnn.conv_bn_act(self.conv2, self.bn2, y, idt, True)
@@ -90,6 +91,7 @@ class KpModule(nn.Module):
         self.merge = nn.Identity()
 
     def forward(self, x):
+        x = ops.share(x)              # both arms of the hourglass module read x
         up1 = self.up1(x)
         low3 = self.low3(self.low2(self.low1(x)))
         return ops.upsample2x_add(up1, low3)
@@ -117,7 +119,8 @@ class HourglassNet(nn.Module):
         inter = self.pre(img)
         outs = []
         for i in range(self.nstack):
-            cnv = self.cnvs[i](self.kps[i](inter))
+            inter = ops.share(inter)  # the stack and (except for the last one) the inter-stack residual read it
+            cnv = ops.share(self.cnvs[i](self.kps[i](inter)))      # heads + the inter-stack projection
             outs.append(cnv)
             if i < self.nstack - 1:           # relu(inters_(inter) + cnvs_(cnv)) -> residual (:312-315)
                 a = hnn.conv_bn_act(self.inters_[i][0], self.inters_[i][1], inter, None, False)

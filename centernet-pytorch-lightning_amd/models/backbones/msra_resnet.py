@@ -27,6 +27,7 @@ class BasicBlock(nn.Module):
         if self.downsample is None:
             y, idt = hnn.conv_bn_act_skip(self.conv1, self.bn1, x)
         else:
+            x = ops.share(x)          # feeds the projection AND conv1: their data gradients meet in a kernel epilogue (ops.GradCell)
             idt = hnn.conv_bn_act(self.downsample[0], self.downsample[1], x, None, False)
             y = hnn.conv_bn_act(self.conv1, self.bn1, x)
         return hnn.conv_bn_act(self.conv2, self.bn2, y, idt, True)
@@ -47,6 +48,7 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        x = ops.share(x)              # identity / projection path + conv1 (ops.GradCell)
         idt = x if self.downsample is None else hnn.conv_bn_act(self.downsample[0], self.downsample[1], x, None, False)
         y = hnn.conv_bn_act(self.conv1, self.bn1, x)
         y = hnn.conv_bn_act(self.conv2, self.bn2, y)
