@@ -27,13 +27,19 @@ static BnLayout bn_layout(int64_t npix, int C, int vec) {
 }
 
 // layout of the element-wise passes: same thread -> (row slot, channel vector) map, up to 8 workgroups per CU, >= 4*U rows each
-static BnLayout ew_layout(int64_t npix, int C, int vec) {
+static BnLayout ew_layout(int64_t npix, int C, int vec, int wg_cap = 2048) {
     BnLayout L = bn_layout(npix, C, vec);
     int64_t want = (npix + (int64_t)L.RPB * 16 - 1) / ((int64_t)L.RPB * 16);
-    int64_t cap = 2048 / L.ycols;
+    int64_t cap = wg_cap / L.ycols;
     L.nblk = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     L.rows_per_blk = (npix + L.nblk - 1) / L.nblk;
     return L;
+}
+
+// workgroups of the sink-reducing element-wise kernels: each pays the reduction prologue once (A/B: CN_BN_SINK_WGS)
+static int sink_wg_cap() {
+    static const int cap = [] { const char* e = getenv("CN_BN_SINK_WGS"); const int v = e ? atoi(e) : 0; return v >= 256 ? v : 2048; }();
+    return cap;
 }
 
 extern "C" size_t cn_bn_workspace_bytes(int64_t npix, int C) {
@@ -565,7 +571,7 @@ extern "C" int cn_bn_train_fwd_sink(const void* x, const void* residual, void* y
     CN_CHECK_ARG(clear != part && clear_n >= 0 && clear_n < (1 << 30), "cn_bn_train_fwd_sink: a launch cannot clear the sink it reads");
     int V = dtype == CN_F32 ? 4 : 8;
     CN_CHECK_ARG(C % V == 0 && C % 4 == 0, "cn_bn_train_fwd_sink: C=%d must be a multiple of %d", C, V);
-    BnLayout E = ew_layout(npix, C, V);
+    BnLayout E = ew_layout(npix, C, V, sink_wg_cap());
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(bn_fwd_apply_sink_kernel<T>, dim3(E.nblk, E.ycols), dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (const T*)residual, (T*)y, part, slots, gamma, beta, running_mean,
                                                    running_var, save_mean, save_invstd, save_scale_shift, momentum, eps, npix, C, E,
@@ -639,7 +645,7 @@ extern "C" int cn_bn_train_bwd_sink(const void* dy, const void* x, const void* y
                                                    (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, scale_shift, sink,
                                                    npix, C, L, relu, slots));
     CN_LAUNCH_CHECK("cn_bn_train_bwd_sink(partial)");
-    BnLayout E = ew_layout(npix, C, V);
+    BnLayout E = ew_layout(npix, C, V, sink_wg_cap());
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(E.nblk, E.ycols), dim3(256), 0, st,
                                                    (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, (const float*)nullptr,
                                                    scale_shift, (T*)dx, (T*)dres, (const T*)dres_acc, npix, C, E, relu,

@@ -22,7 +22,7 @@ KERNELS = {
     "dcn_fwd_bm_kernel<2>": ("dcn_fwd_bm_kernel<2>", CSRC + "dcn_bm.hip", "forward of the 64->64 DCN layers"),
     "dcn_wgrad_bm_kernel": ("dcn_wgrad_bm_kernel", CSRC + "dcn_bm.hip", "weight gradient of the DCN layers (launch mix)"),
     "topk_map128_kernel": ("topk_map128_kernel<true>", CSRC + "topk_stream.h", "B=64, C=80, 128x128 fp32 maps: 335.5 MB algorithmic read (SURVEY 8d)"),
-    "bn_bwd_apply_kernel<unsigned short>": ("bn_bwd_apply_kernel<bf16>", CSRC + "bn.hip", "launch mix of all BN layers"),
+    "bn_bwd_apply_kernel<unsigned short": ("bn_bwd_apply_kernel<bf16>", CSRC + "bn.hip", "launch mix of all BN layers"),
 }
 raw = [l.strip() for l in open(sys.argv[1]) if l.strip()]
 vals = {}
