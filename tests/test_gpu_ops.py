@@ -737,3 +737,55 @@ def test_bn_statistics_hook_can_be_declined(monkeypatch):
     bn = hnn.BatchNorm2d(32).to(DEV).train()
     z = bn(y, None, True)
     assert bool(torch.isfinite(z).all())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_shared_tensor_gradient_cells_small_graph(dt):
+    """ops.share / ops.GradCell on a graph with one consumer of every kind, against autograd's own accumulation over the same
+    operators (each of which is held to its torch reference elsewhere in this file)
+    (pose_dla_dcn.py:245-262: a Tree's input goes through `downsample` and a stride-1 block whose skip path ends in bn2's residual
+    input, and it is a child of a Root):  x -> { max-pool (cn_maxpool_bwd_acc), conv1 with the skip path of a residual block
+    (cn_bn_train_bwd_acc for the skip, the conv's residual slot), 1x1 Root over [block, x] (residual slot), a pass-through use }."""
+    from centernet_amd import nn as hnn
+    o = ops()
+    N, C, H, W = 2, 32, 12, 16
+    torch.manual_seed(7)
+    x0 = rnd(torch.randn(N, C, H, W), dt)
+    conv1, conv2, root = hnn.Conv2d(C, C, 3, 1, 1), hnn.Conv2d(C, C, 3, 1, 1), hnn.Conv2d(2 * C, C, 1)
+    bn1, bn2, bnr = hnn.BatchNorm2d(C), hnn.BatchNorm2d(C), hnn.BatchNorm2d(C)
+    mods = [conv1, conv2, root, bn1, bn2, bnr]
+    for m in mods:
+        m.to(DEV).train()
+        for p in m.parameters():
+            p.data = rnd(p.data.cpu(), dt).to(DEV) if p.dim() > 1 else p.data
+
+    def net(x, shared):
+        if shared:
+            x = o.share(x)
+        pooled = o.max_pool(x, 2, 2)
+        y, skip = hnn.conv_bn_act_skip(conv1, bn1, x)
+        blk = hnn.conv_bn_act(conv2, bn2, y, skip, True)
+        r = hnn.cat_conv_bn_act(root, bnr, [blk, x], None, True)
+        return pooled, r, x
+
+    outs = {}
+    for shared in (False, True):
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        old, o.GradCell.adds = o.GradCell.enabled, 0
+        o.GradCell.enabled = shared
+        try:
+            xg = to_nhwc(x0, dt).requires_grad_(True)
+            xin = xg * 1                                    # a non-leaf producer, like a layer's output
+            pooled, r, xa = net(xin, shared)
+            torch.manual_seed(11)
+            gp, gr, gx = (torch.randn_like(pooled.float()).to(dt), torch.randn_like(r.float()).to(dt), torch.randn_like(xa.float()).to(dt))
+            torch.autograd.backward([pooled, r, xa], [gp, gr, gx])     # `xa` itself is read by a cell-unaware consumer too
+            outs[shared] = (xg.grad.detach().float().cpu(), [p.grad.detach().float().cpu() for m in mods for p in m.parameters()], o.GradCell.adds)
+        finally:
+            o.GradCell.enabled = old
+    (g0, p0, a0), (g1, p1, a1) = outs[False], outs[True]
+    assert a0 == 0 and a1 <= 1, (a0, a1)                    # the cell-unaware use joins in ShareFn.backward: at most one add
+    close(g1, g0, dt, "d x through shared-tensor cells vs autograd accumulation")
+    for u, v in zip(p1, p0):
+        close(u, v, dt, "parameter gradient", scale=max(1e-6, float(v.abs().max())))
