@@ -217,8 +217,8 @@ class GradSync:
             if self._fork is None:
                 self._fork = torch.cuda.Stream()
             self._fork.wait_stream(self._main)
-            if SideGrads.stream is not None:
-                self._fork.wait_stream(SideGrads.stream)
+            for st in SideGrads.all_streams():
+                self._fork.wait_stream(st)
             with torch.cuda.stream(self._fork):
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

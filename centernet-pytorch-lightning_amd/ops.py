@@ -356,6 +356,7 @@ class SideGrads:
     Under hipGraph capture this becomes a fork/join of graph branches.  Not used together with grad-ready hooks.
     """
     stream = None
+    more = []             # further weight-gradient streams (CN_SIDE_STREAMS > 1): submissions go round robin over [stream] + more
     active = False        # only true while a TrainStep (which joins afterwards) is running its backward
 
     @classmethod
@@ -363,6 +364,7 @@ class SideGrads:
         """fp32 (parity mode): the generic fp32 weight-gradient kernels are several times longer — they keep the wider grid"""
         if on and cls.stream is None:
             cls.stream = torch.cuda.Stream()
+            cls.more = [torch.cuda.Stream() for _ in range(int(_os.environ.get("CN_SIDE_STREAMS", 1)) - 1)]
         # background-shaped weight-gradient grids while they share the GPU with the data-gradient chain.  Round 3 (slab-form 3x3
         # kernels at two waves per SIMD, matrix-core DCN weight gradient): the side stream has slack, so the fewer CUs it occupies the
         # faster the critical chain runs — DLA-34 bs 64: 1 413 / 1 432 / 1 437 / 1 460 / 1 480 / 1 478 / 1 368 / 1 165 images/s with
@@ -416,14 +418,23 @@ class SideGrads:
         cls.pending.append((ev, fn, tensors))
 
     @classmethod
+    def all_streams(cls):
+        return ([cls.stream] if cls.stream is not None else []) + cls.more
+
+    rr = 0
+
+    @classmethod
     def _flush(cls):
         todo, cls.pending = cls.pending, []
+        streams = cls.all_streams()
         for ev, fn, tensors in todo:
-            cls.stream.wait_event(ev)
+            st = streams[cls.rr % len(streams)]       # layers' weight gradients are independent of each other
+            cls.rr += 1
+            st.wait_event(ev)
             for t in tensors:
                 if t is not None:
-                    t.record_stream(cls.stream)
-            with torch.cuda.stream(cls.stream):
+                    t.record_stream(st)
+            with torch.cuda.stream(st):
                 fn()
 
     @classmethod
@@ -431,8 +442,10 @@ class SideGrads:
         if cls.stream is not None:
             cls._flush()
         if cls.active and cls.stream is not None:
-            torch.cuda.current_stream().wait_stream(cls.stream)
+            for st in cls.all_streams():
+                torch.cuda.current_stream().wait_stream(st)
         cls.active = False
+        cls.rr = 0
 
 
 def conv_out(h, k, s, p):
