@@ -733,13 +733,28 @@ struct WgBmGeom {
 };
 
 #define WGB_NT 576
+#define WGB_XB (BM_WR * BM_WC * BM_PIXB)       // 49 152 B: x halo image
+#define WGB_YB (BM_TH * BM_TW * BM_PIXB)       // 16 384 B: dY tile
+#define WGB_RB (BM_TH * BM_TW * 128)           // 16 384 B: raw offsets / mask logits of the tile (32 floats per pixel)
+#define WGB_OT (4 * 32 * 29 * 4)               // 14 848 B: geometry table
+__device__ uint4 wgb_zero_page[8];             // 128 zero bytes: DMA source of everything outside the image
 
+// PIPE: the images of tile t+1 (x halo, dY tile, raw offsets: 80 KB) travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KB
+// per wave instruction, no staging registers) into a second set of buffers WHILE tile t is computed.  The workgroup is alone on its
+// CU (nine waves, 168 registers) and used to sit through every tile's loads: stage (issue 10 loads per thread, wait, store to LDS,
+// barrier) and compute alternated, nothing overlapped.  The half swizzle of the images is applied to the DMA SOURCE address (lane l
+// of an instruction fills physical 16-byte piece l & 7 of pixel l >> 3 and fetches the logical piece that lives there); pixels
+// outside the image fetch a zero page.  The offsets arrive raw and are turned into the geometry table LDS -> LDS at the top of
+// their tile.  LDS: 2 x (48 + 16) KB images + 16 KB raw offsets + 14.5 KB table = 158.9 KB of the CU's 160.
+template <bool PIPE>
 __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const Xw = smem;                                   // x halo image [16][24] x 128 B
-    unsigned char* const Yt = smem + BM_WR * BM_WC * BM_PIXB;         // dY tile [8][16] x 128 B (same half swizzle)
-    float* const OmT = reinterpret_cast<float*>(Yt + BM_TH * BM_TW * BM_PIXB);      // [4 groups][32 px][29]
-    u32x4v* const Lut = reinterpret_cast<u32x4v*>(reinterpret_cast<unsigned char*>(OmT) + 4 * 32 * 29 * 4);   // [23]
+    constexpr int XOFF1 = PIPE ? WGB_XB : 0, YOFF0 = PIPE ? 2 * WGB_XB : WGB_XB, YOFF1 = PIPE ? YOFF0 + WGB_YB : YOFF0;
+    constexpr int ROFF = YOFF1 + WGB_YB, OOFF = PIPE ? ROFF + WGB_RB : ROFF;
+    unsigned char* Xw = smem;                                         // x halo image [16][24] x 128 B (PIPE: of the tile being computed)
+    unsigned char* Yt = smem + YOFF0;                                 // dY tile [8][16] x 128 B (same half swizzle)
+    float* const OmT = reinterpret_cast<float*>(smem + OOFF);         // [4 groups][32 px][29]
+    u32x4v* const Lut = reinterpret_cast<u32x4v*>(smem + OOFF + WGB_OT);   // [23]
     const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
     if (tid < 23) {
         const int c = tid - 8;
@@ -767,6 +782,59 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
     const int64_t t_beg = (int64_t)blockIdx.x * g.tiles_per_block;
     const int64_t t_end = t_beg + g.tiles_per_block < ntiles ? t_beg + g.tiles_per_block : ntiles;
 
+    // ---- PIPE: one tile's images by LDS-DMA: 48 + 16 + 16 one-KB pieces, piece J = 9 p + wave ----
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tap);
+    auto issue_tile = [&](int64_t tile_, int buf_) {
+        const int n_ = (int)(tile_ / (g.tiles_h * g.tiles_w));
+        const int rt_ = (int)(tile_ - (int64_t)n_ * g.tiles_h * g.tiles_w);
+        const int ty_ = (rt_ / g.tiles_w) * BM_TH, tx_ = (rt_ % g.tiles_w) * BM_TW;
+        const int64_t img_ = (int64_t)n_ * g.H * g.W;
+        const char* const Xb = reinterpret_cast<const char*>(g.x + img_ * g.Ci + 64 * blockIdx.y);
+        const char* const Yb = reinterpret_cast<const char*>(g.dy + img_ * g.Co + 64 * blockIdx.z);
+        const char* const Ob = reinterpret_cast<const char*>(g.om + img_ * 32);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                // per-lane addressing recomputed per tile: hoisted out of the tile loop it pins registers
+        const char* const zp = reinterpret_cast<const char*>(wgb_zero_page) + (ln & 7) * 16;
+        const int pl = ln >> 3, q = ln & 7;
+#pragma unroll 1
+        for (int p = 0; p < 9; ++p) {
+            const int J = p * 9 + wave_s;
+            if (J >= 80) continue;
+            const char* src;
+            unsigned dst;
+            if (J < 48) {                                   // x halo: pixel J*8 + pl of the [16][24] window
+                const int pix = J * 8 + pl, r = pix / BM_WC, c = pix - r * BM_WC;
+                const int hy = ty_ - BM_MG + r, hx = tx_ - BM_MG + c;
+                const bool ok = (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
+                const int ql = q ^ (((c >> 1) & 1) << 2);   // the logical piece stored at physical piece q (bm_lds_ofs)
+                src = ok ? Xb + (((int64_t)hy * g.W + hx) * g.Ci + ql * 8) * 2 : zp;
+                dst = lds_base + (unsigned)((buf_ ? XOFF1 : 0) + J * 1024);
+            } else {
+                const int I = J < 64 ? J - 48 : J - 64, pix = I * 8 + pl, pr = pix >> 4, pc = pix & 15;
+                const int py_ = ty_ + pr, px_ = tx_ + pc;
+                const bool ok = py_ < g.H && px_ < g.W;
+                if (J < 64) {                               // dY tile
+                    const int ql = q ^ (((pc >> 1) & 1) << 2);
+                    src = ok ? Yb + (((int64_t)py_ * g.W + px_) * g.Co + ql * 8) * 2 : zp;
+                    dst = lds_base + (unsigned)((buf_ ? YOFF1 : YOFF0) + I * 1024);
+                } else {                                    // raw offsets / mask logits (32 floats per pixel, unswizzled)
+                    src = ok ? Ob + (((int64_t)py_ * g.W + px_) * 32 + q * 4) * 4 : zp;
+                    dst = lds_base + (unsigned)(ROFF + I * 1024);
+                }
+            }
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    int buf = 0;
+    if constexpr (PIPE) {
+        if (t_beg < t_end) issue_tile(t_beg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // also publishes Lut
+    }
+
 #pragma unroll 1
     for (int64_t tile = t_beg; tile < t_end; ++tile) {
         const int n = (int)(tile / (g.tiles_h * g.tiles_w));
@@ -776,6 +844,31 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
         const bf16_t* __restrict__ X = g.x + img * g.Ci + 64 * blockIdx.y;      // this workgroup's 64-channel block of x ...
         const bf16_t* __restrict__ DY = g.dy + img * g.Co + 64 * blockIdx.z;    // ... and of dY: dW[co block][ci block]
         const float* __restrict__ OM = g.om + img * 32;
+        if constexpr (PIPE) {
+            // the images of this tile are in buffer `buf` (DMA retired behind the previous tile's MFMAs); raw offsets -> table
+            Xw = smem + (buf ? XOFF1 : 0);
+            Yt = smem + (buf ? YOFF1 : YOFF0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int v = tid + i * WGB_NT;
+                const int pix = v >> 3, q = v & 7;
+                if (v >= 1024 || q == 7) continue;
+                const int pr = pix >> 4, pc = pix & 15;
+                const float4 o4 = *reinterpret_cast<const float4*>(smem + ROFF + pix * 128 + q * 16);
+                const bool inimg = ty0 + pr < g.H && tx0 + pc < g.W;
+                float* d = OmT + ((((pr >> 2) * 2 + (pc >> 3)) * 32 + (pr & 3) * 8 + (pc & 7)) * 29) + q * 4;
+                const float v4[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = q * 4 + j, k = e >> 1, k3 = (k * 11) >> 5;
+                    float val = v4[j] + (float)((e & 1) ? (pc & 7) + 3 + (k - 3 * k3) : (pr & 3) + 3 + k3);
+                    if (q >= 4 && e >= 18) val = inimg ? __builtin_amdgcn_rcpf(1.f + __expf(-v4[j])) : 0.f;
+                    if (e < 27) d[j] = val;
+                }
+            }
+            __syncthreads();                       // table complete; the raw offsets may be overwritten
+            if (tile + 1 < t_end) issue_tile(tile + 1, buf ^ 1);
+        } else {
         __syncthreads();                           // everybody is done with the previous tile's images
         // ---- staging: x halo (3072 vectors), dY tile (1024), offsets / masks of the 128 pixels (896) ----
         {
@@ -827,6 +920,7 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
             }
         }
         __syncthreads();
+        }   // !PIPE
 
 #pragma unroll 1
         for (int grp = 0; grp < 4; ++grp) {
@@ -946,6 +1040,11 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
                 }
             }
         }
+        if constexpr (PIPE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the next tile have landed ...
+            __syncthreads();                                        // ... everybody's have, and everybody is done with this tile's images
+            buf ^= 1;
+        }
     }
     // ---- flush: acc[cb][mb] register v of lane = dW_tap[co = 32 cb + 8 (v >> 2) + 4 hh + (v & 3)][ci = 32 mb + nl] ----
 #pragma unroll
@@ -983,8 +1082,15 @@ bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* 
     if (want < 1) want = 1;
     g.tiles_per_block = (int)((ntiles + want - 1) / want);
     const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
-    const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + BM_TH * BM_TW * BM_PIXB + 4 * 32 * 29 * 4 + 512;
-    (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(dcn_wgrad_bm_kernel, dim3(gx, Ci / 64, Co / 64), dim3(WGB_NT), smem, st, g);
+    static const bool no_pipe = getenv("CN_DCN_WGRAD_NO_PIPE") != nullptr;      // A/B: stage through registers, nothing overlapped
+    if (no_pipe) {
+        const size_t smem = (size_t)WGB_XB + WGB_YB + WGB_OT + 512;
+        (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_wgrad_bm_kernel<false>, dim3(gx, Ci / 64, Co / 64), dim3(WGB_NT), smem, st, g);
+    } else {
+        const size_t smem = (size_t)2 * WGB_XB + 2 * WGB_YB + WGB_RB + WGB_OT + 512;
+        (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(dcn_wgrad_bm_kernel<true>, dim3(gx, Ci / 64, Co / 64), dim3(WGB_NT), smem, st, g);
+    }
     return true;
 }
