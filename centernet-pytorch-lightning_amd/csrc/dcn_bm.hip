@@ -746,8 +746,13 @@ __device__ uint4 wgb_zero_page[8];             // 128 zero bytes: DMA source of 
 // of an instruction fills physical 16-byte piece l & 7 of pixel l >> 3 and fetches the logical piece that lives there); pixels
 // outside the image fetch a zero page.  The offsets arrive raw and are turned into the geometry table LDS -> LDS at the top of
 // their tile.  LDS: 2 x (48 + 16) KB images + 16 KB raw offsets + 14.5 KB table = 158.9 KB of the CU's 160.
-template <bool PIPE>
-__global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) {
+// NW = 9: wave t owns tap t.  NW = 8: the same for taps 0..7 and tap 8 is dealt out by pixel group to waves 0..3 (a second accumulator
+// set; two waves per SIMD allow 256 registers).  Nine waves put three on one SIMD and two on the others, and the tile waits for the
+// SIMD with three tap-works per group; eight waves leave 2 x 4 + 1 = 9 group-works on every SIMD instead of 12 on the busiest.
+template <bool PIPE, int NW>
+__global__ __launch_bounds__(NW * 64) void dcn_wgrad_bm_kernel(const WgBmGeom g) {
+    constexpr int NT = NW * 64;
+    static_assert(NW == 9 || (NW == 8 && PIPE), "eight waves: pipelined variant only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int XOFF1 = PIPE ? WGB_XB : 0, YOFF0 = PIPE ? 2 * WGB_XB : WGB_XB, YOFF1 = PIPE ? YOFF0 + WGB_YB : YOFF0;
     constexpr int ROFF = YOFF1 + WGB_YB, OOFF = PIPE ? ROFF + WGB_RB : ROFF;
@@ -770,13 +775,13 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
     const int r16 = lane & 15, g16 = lane >> 4;
     typedef __attribute__((address_space(3))) s16x4_t_* lds_ptr;
 
-    f32x16_t acc[2][2];                                               // [co block][ci block] of dW_tap
+    f32x16_t acc[2][2], acc8[2][2];                                   // [co block][ci block] of dW_tap (acc8: this wave's share of tap 8, NW = 8)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; acc8[a][b][r] = 0.f; }
 
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     const int64_t t_beg = (int64_t)blockIdx.x * g.tiles_per_block;
@@ -798,8 +803,8 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
         const char* const zp = reinterpret_cast<const char*>(wgb_zero_page) + (ln & 7) * 16;
         const int pl = ln >> 3, q = ln & 7;
 #pragma unroll 1
-        for (int p = 0; p < 9; ++p) {
-            const int J = p * 9 + wave_s;
+        for (int p = 0; p < (80 + NW - 1) / NW; ++p) {
+            const int J = p * NW + wave_s;
             if (J >= 80) continue;
             const char* src;
             unsigned dst;
@@ -849,8 +854,8 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
             Xw = smem + (buf ? XOFF1 : 0);
             Yt = smem + (buf ? YOFF1 : YOFF0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int v = tid + i * WGB_NT;
+            for (int i = 0; i < (1024 + NT - 1) / NT; ++i) {
+                const int v = tid + i * NT;
                 const int pix = v >> 3, q = v & 7;
                 if (v >= 1024 || q == 7) continue;
                 const int pr = pix >> 4, pc = pix & 15;
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
             }
             __syncthreads();                       // table complete; the raw offsets may be overwritten
             if (tile + 1 < t_end) issue_tile(tile + 1, buf ^ 1);
-        } else {
+        } else if constexpr (NW == 9) {
         __syncthreads();                           // everybody is done with the previous tile's images
         // ---- staging: x halo (3072 vectors), dY tile (1024), offsets / masks of the 128 pixels (896) ----
         {
@@ -922,12 +927,11 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
         __syncthreads();
         }   // !PIPE
 
-#pragma unroll 1
-        for (int grp = 0; grp < 4; ++grp) {
+        auto do_group = [&](const int grp, const int tapx, f32x16_t (&accx)[2][2]) {
             const int grow = (grp >> 1) * 4, gcol = (grp & 1) * 8;
             // ---- geometry of (own pixel, this wave's tap) ----
             const float* orow = OmT + (grp * 32 + nl) * 29;
-            const float pyr = orow[2 * tap], pxr = orow[2 * tap + 1], m = orow[18 + tap];
+            const float pyr = orow[2 * tapx], pxr = orow[2 * tapx + 1], m = orow[18 + tapx];
             const float fy = floorf(pyr), fx = floorf(pxr);
             const int wr = (int)fy, wc = (int)fx;
             const float ly = pyr - fy, lx = pxr - fx;
@@ -1008,8 +1012,8 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
                     for (int v = 0; v < 16; ++v) {
                         const int co = 32 * cb + 8 * (v >> 2) + 4 * hh + (v & 3);
                         const float dyv = bf2f(*reinterpret_cast<const bf16_t*>(yp + ((((co >> 5) ^ (pc >> 1)) & 1) << 6) + (co & 31) * 2));
-                        acc[cb][0][v] += dyv * sv0;
-                        acc[cb][1][v] += dyv * sv1;
+                        accx[cb][0][v] += dyv * sv0;
+                        accx[cb][1][v] += dyv * sv1;
                     }
             }
             // ---- dW[co][ci] += dY^T[co][p] S[p][ci]   (K = the group's 32 pixels in the accumulator's row order) ----
@@ -1035,10 +1039,15 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
                     const s16x8_t_ ya = {part[0][0], part[0][1], part[0][2], part[0][3], part[1][0], part[1][1], part[1][2], part[1][3]};
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb)
-                        acc[cb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ya), __builtin_bit_cast(bf16x8_t, sb[mb]),
-                                                                              acc[cb][mb], 0, 0, 0);
+                        accx[cb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, ya), __builtin_bit_cast(bf16x8_t, sb[mb]),
+                                                                               accx[cb][mb], 0, 0, 0);
                 }
             }
+        };
+#pragma unroll 1
+        for (int grp = 0; grp < 4; ++grp) do_group(grp, tap, acc);
+        if constexpr (NW == 8) {
+            if (tap < 4) do_group(tap, 8, acc8);          // tap 8: pixel group w of the tile belongs to wave w
         }
         if constexpr (PIPE) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the next tile have landed ...
@@ -1055,6 +1064,7 @@ __global__ __launch_bounds__(WGB_NT) void dcn_wgrad_bm_kernel(const WgBmGeom g) 
             for (int v = 0; v < 16; ++v) {
                 const int co = 64 * blockIdx.z + 32 * cb + 8 * (v >> 2) + 4 * hh + (v & 3), ci = 64 * blockIdx.y + 32 * mb + nl;
                 atomicAdd(g.dwp + (int64_t)co * g.ktot + tap * g.Ci + ci, acc[cb][mb][v]);
+                if (NW == 8 && tap < 4) atomicAdd(g.dwp + (int64_t)co * g.ktot + 8 * g.Ci + ci, acc8[cb][mb][v]);
             }
 }
 
@@ -1083,14 +1093,21 @@ bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* 
     g.tiles_per_block = (int)((ntiles + want - 1) / want);
     const int gx = (int)((ntiles + g.tiles_per_block - 1) / g.tiles_per_block);
     static const bool no_pipe = getenv("CN_DCN_WGRAD_NO_PIPE") != nullptr;      // A/B: stage through registers, nothing overlapped
+    // A/B: eight waves, tap 8 dealt out by pixel group (9 group-works per SIMD instead of 12 on the busiest): 314 vs 308 us on
+    // 64->64 @128^2, step 42.00 vs 42.01 ms — the kernel is bound by the latency of a wave's own chain, not by the busiest SIMD
+    static const bool nine = getenv("CN_DCN_WGRAD_WAVES8") == nullptr;
     if (no_pipe) {
         const size_t smem = (size_t)WGB_XB + WGB_YB + WGB_OT + 512;
-        (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(dcn_wgrad_bm_kernel<false>, dim3(gx, Ci / 64, Co / 64), dim3(WGB_NT), smem, st, g);
+        (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel<false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((dcn_wgrad_bm_kernel<false, 9>), dim3(gx, Ci / 64, Co / 64), dim3(576), smem, st, g);
+    } else if (nine) {
+        const size_t smem = (size_t)2 * WGB_XB + 2 * WGB_YB + WGB_RB + WGB_OT + 512;
+        (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel<true, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((dcn_wgrad_bm_kernel<true, 9>), dim3(gx, Ci / 64, Co / 64), dim3(576), smem, st, g);
     } else {
         const size_t smem = (size_t)2 * WGB_XB + 2 * WGB_YB + WGB_RB + WGB_OT + 512;
-        (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(dcn_wgrad_bm_kernel<true>, dim3(gx, Ci / 64, Co / 64), dim3(WGB_NT), smem, st, g);
+        (void)hipFuncSetAttribute((const void*)dcn_wgrad_bm_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((dcn_wgrad_bm_kernel<true, 8>), dim3(gx, Ci / 64, Co / 64), dim3(512), smem, st, g);
     }
     return true;
 }
