@@ -1072,7 +1072,8 @@ bool dcn_wgrad_bm_shape_ok(int Ci, int x_ld, int Co, int dy_ld, int om_ld) {
     static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_WGRAD_BM") != nullptr;
     // every (x block, dY block) pair re-samples: measured ahead of dcn_wgrad_kernel up to 8 pairs (128->64@64^2 319 -> 183 us, 128->128
     // 395 -> 296, 256->128@32^2 229 -> 175), level with it beyond (256->256 310 vs 287 zero offsets, 313 vs 343 N(0,0.5))
-    return !disabled && Ci % 64 == 0 && x_ld == Ci && Co % 64 == 0 && dy_ld == Co && om_ld == 32 && (Ci / 64) * (Co / 64) <= 8;
+    static const int max_pairs = [] { const char* e = getenv("CN_DCN_WGRAD_BM_PAIRS"); return e ? atoi(e) : 8; }();
+    return !disabled && Ci % 64 == 0 && x_ld == Ci && Co % 64 == 0 && dy_ld == Co && om_ld == 32 && (Ci / 64) * (Co / 64) <= max_pairs;
 }
 
 // returns false when the shape is not handled here (caller falls back to dcn_wgrad_kernel)
