@@ -547,9 +547,6 @@ class Conv2dFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1] and Cx == Ci and SideGrads.usable(weight, ctx.bias_ref):
             def side_work(x=x, dy=dy, bias=ctx.bias_ref):
-                dbg = _os.environ.get("CN_DEBUG_SKIP_CONV_WGRAD")
-                if dbg and (dbg == "all" or (dbg == "backbone" and not has_bias) or (dbg == "heads" and has_bias)):
-                    return
                 _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=weight.grad, db_into=bias.grad if has_bias else None)
                 GradReady.note(weight, bias)
             SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), x, dy, claims=(weight, ctx.bias_ref))
@@ -1117,8 +1114,6 @@ class DCNv2Fn(Function):
 
         if side:
             def side_work():
-                if _os.environ.get("CN_DEBUG_SKIP_DCN_WGRAD"):
-                    return
                 dwp, _ = main_wgrad(ctx.params[0].grad, False)
                 unpack_wgrad(dwp, Co, Ci, 3, 3, into=weight.grad)
                 GradReady.note(weight, ctx.params[0])
