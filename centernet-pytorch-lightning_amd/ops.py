@@ -1046,7 +1046,9 @@ def emit_maps(maps, out_channels, nchw_out):
     (models/__init__.py:14-19), else the engine's NHWC handles, tagged for `heads.CenterHead`."""
     if nchw_out:
         return [ToNCHWFn.apply(m, out_channels) for m in maps]
-    return [mark_nhwc(m, out_channels) for m in maps]
+    # a map that is a shared alias inside the backbone (GradCell) leaves as a plain view: the tensor a caller holds must receive its
+    # gradient through autograd (retain_grad / torch.autograd.grad on it), not have it routed past it through a cell
+    return [mark_nhwc(m.view_as(m) if cell_of(m) is not None else m, out_channels) for m in maps]
 
 
 def to_nhwc(x_nchw, dtype, cpad=None):

@@ -568,3 +568,19 @@ def test_shared_tensor_gradients_summed_in_epilogues_match_autograd_sums():
     for n in h0:
         den = float(h0[n].norm()) + 1e-20
         assert float((h0[n] - h1[n]).norm()) <= 0.12 * den + floor, (n, float((h0[n] - h1[n]).norm()) / den)
+
+
+def test_backbone_output_gradient_is_visible_to_autograd():
+    """The NHWC handle a backbone returns is what a caller may hold on to (retain_grad, torch.autograd.grad): it must not be one of
+    the shared aliases whose consumers route their gradients past autograd (ops.GradCell), although three sibling heads read it."""
+    from centernet_amd import ops
+    m = _model("dla_34", 5, torch.bfloat16).train()
+    x, tgt = synth.ctdet_batch(5, 2, 128, 128)
+    feats = m.backbone(x.to(DEV))
+    assert all(ops.cell_of(f) is None for f in feats)
+    feats[-1].retain_grad()
+    outs = [head(f) for head, f in zip(m.heads, feats)]                 # CenterNetDetection.forward (centernet_detection.py:40-41)
+    loss, _ = m.loss(outs, {k: v.to(DEV) for k, v in tgt.items()})
+    loss.backward()
+    g = feats[-1].grad
+    assert g is not None and g.shape == feats[-1].shape and float(g.float().abs().sum()) > 0
