@@ -365,6 +365,8 @@ class TrainStep:
         if self.sync is not None:
             self.sync.broadcast_state(model)
         self._g1 = self._g2 = None
+        TrainStep._ns_next += 1
+        self._ns = ("step", TrainStep._ns_next)      # namespace of this step's BatchNorm statistics sinks (ops.BnStats)
         self._inflight = None
         self._bns = [m for m in model.modules() if hasattr(m, "_pending")]
 
@@ -398,7 +400,7 @@ class TrainStep:
         PackArena.current = None
 
     def _eager(self, batch, batch_idx=0):
-        ops.BnStats.ns = id(self)              # this step's chain of BatchNorm statistics sinks (kept apart from other steps' graphs)
+        ops.BnStats.ns = self._ns              # this step's chain of BatchNorm statistics sinks (kept apart from other steps' graphs)
         self.opt.zero_grad()
         self._begin_packs()
         try:
@@ -485,7 +487,7 @@ class TrainStep:
         mode = "thread_local" if (dist.is_initialized() or os.environ.get("CN_CAPTURE_THREAD_LOCAL")) else "global"
         # capture on the stream the warm-up steps ran on: `_hip.workspace` is keyed by stream, so the capture replays into the
         # buffers the warm-up sized instead of allocating a second set from the graph's private pool
-        ops.BnStats.ns = id(self)
+        ops.BnStats.ns = self._ns
         with torch.cuda.graph(self._g1, stream=side, capture_error_mode=mode):
             self.opt.zero_grad()
             self._begin_packs()
@@ -542,6 +544,7 @@ class TrainStep:
         self._throttle()
         return self._loss
 
+    _ns_next = 0
     MAX_STEPS_AHEAD = int(os.environ.get("CN_MAX_STEPS_AHEAD", 3))
 
     def _throttle(self):
