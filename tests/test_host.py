@@ -385,3 +385,49 @@ def test_bench_launch_contract_two_processes():
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
     r = _run_bench(2, 4, 29643)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bn_statistics_sink_chain_bookkeeping():
+    """ops.BnStats (host side of cn_bn_train_fwd_sink / cn_bn_train_bwd_sink): a sink-consuming launch cannot clear the sink its own
+    workgroups read, so every consumed sink is zeroed by the NEXT such launch.  Simulated on CPU tensors: `acquire` never hands out a
+    sink that still holds sums, consecutive uses of one width get different buffers, every step of the same sequence makes the same
+    choices (what a replayed hipGraph relies on) and leaves exactly one sink dirty; namespaces do not see each other's sinks."""
+    import torch
+    from centernet_amd import ops
+    B = ops.BnStats
+    saved = (B.ns, B._rings, B._state, B.slots, B.fused)
+    B.ns, B._rings, B._state, B.slots, B.fused = ("test", 1), {}, {}, 4, True
+    try:
+        dirty_dev = set()                                       # what the DEVICE would hold: buffers with non-zero content
+
+        def use(kind, C):
+            buf = B.acquire(kind, C, "cpu")
+            assert buf.data_ptr() not in dirty_dev, "a sink that still holds sums was handed out"
+            dirty_dev.add(buf.data_ptr())                       # producer epilogue / statistics pass adds into it
+            clear = B.retire(buf)                               # the consuming launch ...
+            assert clear is None or clear.data_ptr() != buf.data_ptr()
+            if clear is not None:
+                dirty_dev.discard(clear.data_ptr())             # ... zeroes the one consumed before it
+            return buf.data_ptr(), None if clear is None else clear.data_ptr()
+
+        def step():
+            seq = [use("f", 16), use("f", 16), use("f", 32), use("f", 64), use("f", 64), use("f", 64)]
+            seq += [use("b", 64), use("b", 64), use("b", 64), use("b", 32), use("b", 16), use("b", 16)]
+            return seq
+
+        s1 = step()
+        assert len(dirty_dev) == 1                              # the last sink consumed waits for the next step's first launch
+        assert all(a[0] != b[0] for a, b in zip(s1, s1[1:])), "consecutive uses share a buffer"
+        s2, s3 = step(), step()
+        assert s2 == s3 and [p for p, _ in s1] == [p for p, _ in s2], "a replayed step must make the same choices"
+        assert s2[0][1] == s1[-1][0], "the first launch of a step clears the previous step's last sink"
+        assert len(dirty_dev) == 1
+        # another TrainStep's namespace: own buffers, own chain
+        B.ns = ("test", 2)
+        t1 = step()
+        assert not ({p for p, _ in t1} & {p for p, _ in s1})
+        # failure path: everything zeroed, state forgotten
+        B.reset()
+        assert all(float(b.abs().max()) == 0.0 for ring in B._rings.values() for b in ring) and not B._state
+    finally:
+        B.ns, B._rings, B._state, B.slots, B.fused = saved
