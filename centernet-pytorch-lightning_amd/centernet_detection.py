@@ -1,7 +1,6 @@
 """`CenterNetDetection` (reference: CenterNet/centernet_detection.py:28-265) — forward / loss / decode / test step on the HIP
 path.  COCO evaluation (pycocotools) and the CLI are outside the hot-path scope."""
 import torch
-import torch.nn.functional as F
 
 from .centernet import CenterNet
 from .decode.ctdet import ctdet_decode
@@ -73,9 +72,7 @@ class CenterNetDetection(CenterNet):
             _, _, height, width = img.shape
             nh, nw = int(height * scale), int(width * scale)
             pad_y, pad_x = post.tta_pad(nh, self.padding), post.tta_pad(nw, self.padding)
-            x = img if (nh, nw) == (height, width) else F.interpolate(img.float(), size=(nh, nw), mode="bilinear",
-                                                                      align_corners=False)   # VF.resize on tensors (no antialias)
-            x = post.tta_prepare(x, self.mean, self.std, pad_x, pad_y, self.test_flip)
+            x = post.tta_prepare_scaled(img, nh, nw, self.mean, self.std, pad_x, pad_y, self.test_flip)   # resize in the same launch
             out = self(x)[-1]
             if self.test_flip:
                 out = {"heatmap": post.flip_merge(out["heatmap"]), "width_height": post.flip_merge(out["width_height"]),

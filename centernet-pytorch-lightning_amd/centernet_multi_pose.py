@@ -1,6 +1,5 @@
 """`CenterNetMultiPose` (reference: CenterNet/centernet_multi_pose.py:29-321) — forward / loss / decode / test step on the HIP path."""
 import torch
-import torch.nn.functional as F
 
 from .centernet import CenterNet
 from .decode.multi_pose import multi_pose_decode
@@ -93,8 +92,7 @@ class CenterNetMultiPose(CenterNet):
             _, _, height, width = img.shape
             nh, nw = int(height * scale), int(width * scale)
             pad_y, pad_x = post.tta_pad(nh, self.padding), post.tta_pad(nw, self.padding)
-            x = img if (nh, nw) == (height, width) else F.interpolate(img.float(), size=(nh, nw), mode="bilinear", align_corners=False)
-            x = post.tta_prepare(x, self.mean, self.std, pad_x, pad_y, self.test_flip)
+            x = post.tta_prepare_scaled(img, nh, nw, self.mean, self.std, pad_x, pad_y, self.test_flip)   # resize in the same launch
             out = self(x)[-1]
             if self.test_flip:
                 kp_perm, kp_sign, hm_perm, hm_sign = self._flip_tables(x.device)

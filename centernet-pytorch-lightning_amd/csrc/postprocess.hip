@@ -9,11 +9,15 @@
 
 // out[b] = pad(normalize(img[b])) ; out[B + b] = hflip(out[b]) when flip.  The reference pads with zeros BEFORE normalising
 // (centernet_detection.py:146-151), so the border holds (0 - mean) / std.
-__global__ __launch_bounds__(256) void tta_prepare_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int H, int W,
-                                                          int pad_x, int pad_y, float m0, float m1, float m2, float s0, float s1,
-                                                          float s2, int flip) {
+// RESIZE: the image is first resized to (H, W) from (SH, SW) — bilinear, half-pixel centres, no antialias, edge clamp: what
+// VF.resize does to a tensor (centernet_detection.py:141; ATen upsample_bilinear2d, align_corners=False) — inside the same launch
+template <bool RESIZE>
+__global__ __launch_bounds__(256) void tta_prepare_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int SH, int SW,
+                                                          int H, int W, int pad_x, int pad_y, float m0, float m1, float m2, float s0,
+                                                          float s1, float s2, int flip) {
     const int PH = H + 2 * pad_y, PW = W + 2 * pad_x;
     const int64_t total = (int64_t)B * 3 * PH * PW;
+    const float rh = (float)SH / (float)H, rw = (float)SW / (float)W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % PW);
         int64_t r = i / PW;
@@ -22,7 +26,20 @@ __global__ __launch_bounds__(256) void tta_prepare_kernel(const float* __restric
         const int c = (int)(r % 3), b = (int)(r / 3);
         const int iy = y - pad_y, ix = x - pad_x;
         const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        const float v = in ? img[(((int64_t)b * 3 + c) * H + iy) * W + ix] : 0.f;
+        const float* __restrict__ src = img + ((int64_t)b * 3 + c) * SH * SW;
+        float v = 0.f;
+        if (in) {
+            if (RESIZE) {
+                const float fy = fmaxf(rh * ((float)iy + 0.5f) - 0.5f, 0.f), fx = fmaxf(rw * ((float)ix + 0.5f) - 0.5f, 0.f);
+                const int y0 = (int)fy, x0 = (int)fx;
+                const int y1 = y0 + (y0 < SH - 1), x1 = x0 + (x0 < SW - 1);
+                const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+                v = hy * (hx * src[(int64_t)y0 * SW + x0] + lx * src[(int64_t)y0 * SW + x1])
+                  + ly * (hx * src[(int64_t)y1 * SW + x0] + lx * src[(int64_t)y1 * SW + x1]);
+            } else {
+                v = src[(int64_t)iy * SW + ix];
+            }
+        }
         const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
         const float o = (v - mean) / sd;
         out[i] = o;
@@ -288,14 +305,23 @@ static int pp_grid(int64_t total) {
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 
+extern "C" int cn_tta_prepare_scaled(const float* img, float* out, int B, int H, int W, int new_h, int new_w, int pad_x, int pad_y,
+                                     float mean0, float mean1, float mean2, float std0, float std1, float std2, int flip, void* stream) {
+    CN_CHECK_ARG(img && out && B > 0 && H > 0 && W > 0 && new_h > 0 && new_w > 0 && pad_x >= 0 && pad_y >= 0, "cn_tta_prepare_scaled: bad args");
+    const int64_t total = (int64_t)B * 3 * (new_h + 2 * pad_y) * (new_w + 2 * pad_x);
+    if (new_h == H && new_w == W)
+        hipLaunchKernelGGL(tta_prepare_kernel<false>, dim3(pp_grid(total)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, H, W,
+                           pad_x, pad_y, mean0, mean1, mean2, std0, std1, std2, flip);
+    else
+        hipLaunchKernelGGL(tta_prepare_kernel<true>, dim3(pp_grid(total)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, new_h,
+                           new_w, pad_x, pad_y, mean0, mean1, mean2, std0, std1, std2, flip);
+    CN_LAUNCH_CHECK("cn_tta_prepare_scaled");
+    return CN_OK;
+}
+
 extern "C" int cn_tta_prepare(const float* img, float* out, int B, int H, int W, int pad_x, int pad_y, float mean0, float mean1,
                               float mean2, float std0, float std1, float std2, int flip, void* stream) {
-    CN_CHECK_ARG(img && out && B > 0 && H > 0 && W > 0 && pad_x >= 0 && pad_y >= 0, "cn_tta_prepare: bad args");
-    const int64_t total = (int64_t)B * 3 * (H + 2 * pad_y) * (W + 2 * pad_x);
-    hipLaunchKernelGGL(tta_prepare_kernel, dim3(pp_grid(total)), dim3(256), 0, (hipStream_t)stream, img, out, B, H, W, pad_x, pad_y,
-                       mean0, mean1, mean2, std0, std1, std2, flip);
-    CN_LAUNCH_CHECK("cn_tta_prepare");
-    return CN_OK;
+    return cn_tta_prepare_scaled(img, out, B, H, W, H, W, pad_x, pad_y, mean0, mean1, mean2, std0, std1, std2, flip, stream);
 }
 
 extern "C" int cn_flip_merge(const float* x, float* out, int B, int C, int H, int W, void* stream) {

@@ -26,6 +26,16 @@ def tta_prepare(img, mean, std, pad_x, pad_y, flip):
     return out
 
 
+def tta_prepare_scaled(img, new_h, new_w, mean, std, pad_x, pad_y, flip):
+    """img fp32 [B,3,H,W] in [0,1] at its original size -> resized to (new_h, new_w) (VF.resize on a tensor: bilinear, no
+    antialias), padded, normalised and mirrored in ONE launch -> fp32 [B*(1+flip),3,new_h+2pad_y,new_w+2pad_x]."""
+    B, _, H, W = img.shape
+    out = torch.empty((B * (2 if flip else 1), 3, new_h + 2 * pad_y, new_w + 2 * pad_x), dtype=torch.float32, device=img.device)
+    call("cn_tta_prepare_scaled", img.float().contiguous(), out, B, H, W, int(new_h), int(new_w), int(pad_x), int(pad_y),
+         float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]), float(std[2]), int(bool(flip)))
+    return out
+
+
 def flip_merge(x):
     """x fp32 [2B,C,H,W] -> (x[:B] + hflip(x[B:])) / 2."""
     B2, C, H, W = x.shape

@@ -312,6 +312,11 @@ int cn_encode_multi_pose(const float* boxes, const float* keypoints, const int* 
  * flip, out[B+b] = hflip(out[b]).  img fp32 [B,3,H,W] (already resized for scales != 1), out fp32 [B*(1+flip),3,H+2pad_y,W+2pad_x]. */
 int cn_tta_prepare(const float* img, float* out, int B, int H, int W, int pad_x, int pad_y, float mean0, float mean1,
                    float mean2, float std0, float std1, float std2, int flip, void* stream);
+/* test_step :139-158 with the multi-scale resize of :139-141 (`VF.resize(img, (new_h, new_w))` on a tensor: bilinear, half-pixel
+ * centres, no antialias, edge clamp = ATen upsample_bilinear2d, align_corners=False) folded into the same launch.  img fp32
+ * [B,3,H,W] at the ORIGINAL size, out fp32 [B*(1+flip),3,new_h+2pad_y,new_w+2pad_x].  new_h == H && new_w == W: cn_tta_prepare. */
+int cn_tta_prepare_scaled(const float* img, float* out, int B, int H, int W, int new_h, int new_w, int pad_x, int pad_y,
+                          float mean0, float mean1, float mean2, float std0, float std1, float std2, int flip, void* stream);
 /* test_step :167-171: out[B,C,H,W] = (x[0:B] + hflip(x[B:2B])) / 2 on NCHW fp32 head maps. */
 int cn_flip_merge(const float* x, float* out, int B, int C, int H, int W, void* stream);
 /* test_step_end :173-225 for a batch: dets fp32 [S,B,K,6] (ctdet_decode output per test scale), meta fp32 [S,4] =

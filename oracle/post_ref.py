@@ -6,8 +6,9 @@ PINNED: soft_nms / soft_nms_39 (tests/golden/soft_nms.npz: utils/nms.py run from
 pose_test_step_end (tests/golden/test_step_end.npz: the reference's method bodies compiled from their source files and run on
 seeded two-scale head maps) — see oracle/gen_golden.py:gen_soft_nms / gen_test_step_end; tests/test_oracle_golden.py and
 tests/test_gpu_post.py hold this file and the HIP path to both.
-PARITY UNPINNED: tta_prepare and flip_merge* (the test_step halves, centernet_detection.py:132-173) — they need
-torchvision.transforms.functional (resize / normalize / hflip), which is absent; checked by known-answer tests only.
+PARITY UNPINNED: resize, tta_prepare and flip_merge* (the test_step halves, centernet_detection.py:132-173) — they need
+torchvision.transforms.functional (resize / normalize / hflip), which is absent; checked by known-answer tests only (`resize` is
+stated as ATen's bilinear interpolate, which is what torchvision's tensor resize of the reference's era calls).
 """
 import numpy as np
 import torch
@@ -17,6 +18,14 @@ import torch.nn.functional as F
 def tta_pad(size, padding):
     """centernet_detection.py:143-144."""
     return ((size | padding) + 1 - size) // 2
+
+
+def resize(img, new_h, new_w):
+    """centernet_detection.py:139-141: `VF.resize(img, (new_h, new_w))` on a tensor = bilinear interpolate, align_corners=False,
+    no antialias (torchvision.transforms.functional_tensor.resize of the reference's era).  img fp32 [B,3,H,W]."""
+    if (new_h, new_w) == tuple(img.shape[-2:]):
+        return img
+    return F.interpolate(img, size=(new_h, new_w), mode="bilinear", align_corners=False)
 
 
 def tta_prepare(img, mean, std, pad_x, pad_y, flip):

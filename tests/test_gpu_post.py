@@ -23,6 +23,24 @@ def test_tta_prepare_bit_exact(cfg):
     assert got.shape == ref.shape and torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 96, 48, 72, 12, 8, True), (1, 50, 38, 62, 47, 0, 0, True), (2, 40, 56, 20, 28, 6, 6, False),
+                                 (1, 33, 65, 99, 195, 14, 2, True), (2, 32, 32, 32, 32, 0, 0, True)])
+def test_tta_prepare_scaled(cfg):
+    """The multi-scale resize of test_step folded into the prepare launch: bilinear (half-pixel centres, no antialias) against
+    ATen's CPU interpolate + the restated pad / normalise / mirror; 2e-6 covers the different summation order of the four
+    corner products divided by std (fp32); equal sizes take the copy path and are bit-exact."""
+    from centernet_amd.utils import post
+    B, H, W, nh, nw, px, py, flip = cfg
+    img = rng.t_uniform(9, f"img{cfg}", (B, 3, H, W))
+    ref = post_ref.tta_prepare(post_ref.resize(img, nh, nw), MEAN, STD, px, py, flip)
+    got = post.tta_prepare_scaled(img.to(DEV), nh, nw, MEAN, STD, px, py, flip).cpu()
+    assert got.shape == ref.shape
+    if (nh, nw) == (H, W):
+        assert torch.equal(got, ref)
+    else:
+        assert torch.allclose(got, ref, rtol=0, atol=2e-6 / min(STD)), float((got - ref).abs().max())
+
+
 def test_flip_merge_bit_exact():
     from centernet_amd.utils import post
     x = rng.t_normal(8, "maps", (6, 5, 12, 20))
@@ -77,6 +95,7 @@ def test_test_step_flip_tta_end_to_end():
     """CenterNetDetection.test_step + test_step_end on a batch (flip TTA, 2 scales) against the restated pipeline run on the
     same network: prepared images, merged head maps, and the per-class results."""
     from centernet_amd.centernet_detection import CenterNetDetection
+    from centernet_amd.utils import post
     m = CenterNetDetection("res_18", compute_dtype=torch.float32, test_flip=True, test_scales=[1, 0.75])
     rng.fill_state_dict(m, 98)
     m = m.to(DEV).eval()
@@ -87,9 +106,13 @@ def test_test_step_flip_tta_end_to_end():
     # the same pipeline from the restatement's pieces (forward on the device network)
     for s_, scale in enumerate([1, 0.75]):
         nh, nw = int(128 * scale), int(160 * scale)
-        x = img.cpu() if scale == 1 else torch.nn.functional.interpolate(img.cpu(), size=(nh, nw), mode="bilinear", align_corners=False)
+        x = post_ref.resize(img.cpu(), nh, nw)
         px, py = post_ref.tta_pad(nw, 31), post_ref.tta_pad(nh, 31)
         xin = post_ref.tta_prepare(x, MEAN, STD, px, py, True)
+        if scale != 1:      # the resized image differs from ATen's CPU bilinear in the last bits (test_tta_prepare_scaled); the
+            xdev = post.tta_prepare_scaled(img, nh, nw, MEAN, STD, px, py, True)      # network below amplifies that, so it is fed
+            assert torch.allclose(xdev.cpu(), xin, rtol=0, atol=1e-5)                 # the device's own prepared input
+            xin = xdev
         with torch.no_grad():
             o = m(xin.to(DEV))[-1]
         hm = post_ref.flip_merge(o["heatmap"].cpu())
