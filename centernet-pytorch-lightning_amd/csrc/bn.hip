@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ x
                                                          const float* __restrict__ invstd, const float* __restrict__ ss,
                                                          float* __restrict__ part, int64_t npix, int C, BnLayout L, int relu,
                                                          int sink_slots) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     constexpr int U = 4;                                   // rows in flight per thread
     __shared__ float red[2][256][V + 1];
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_sink_kernel(const T* __restr
                                                                 float* __restrict__ save_ss, float momentum, float eps,
                                                                 int64_t npix, int C, BnLayout L, int relu,
                                                                 float* __restrict__ clear, int clear_n) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     constexpr int U = 4;
     __shared__ float red[2][256][V + 1];
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const T* __restric
                                                               T* __restrict__ y, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int64_t npix, int C, BnLayout L,
                                                               int relu) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     constexpr int U = 4;
     const int tid = threadIdx.x;
@@ -382,6 +385,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ clear,
                                                            int clear_n) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     constexpr int U = 4;
     __shared__ float red[2][SINK ? 256 : 1][V + 1];

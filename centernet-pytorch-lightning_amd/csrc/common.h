@@ -170,6 +170,13 @@ __device__ static inline unsigned wave_sum_u(unsigned v) {
     return v;
 }
 
+// Wave priority of the launch-stream (critical chain) kernels: the weight-gradient kernels of the side stream stay at 0, so on a
+// CU that hosts workgroups of both streams the chain's waves win the instruction arbitration (measurement: DESIGN 6b)
+#ifndef CN_MAIN_PRIO
+#define CN_MAIN_PRIO 2
+#endif
+#define CN_MAIN_PRIO_SET() do { if (CN_MAIN_PRIO) __builtin_amdgcn_s_setprio(CN_MAIN_PRIO); } while (0)
+
 // ---- BatchNorm statistics in a producer's epilogue (sink protocol: bn.hip, cn_bn_stats_arm) ----
 // a thread adds the 8 bf16 values it is about to store (packed pairs w) to its running (sum, sum of squares)
 __device__ static inline void bn_stat_add(float (&s0)[8], float (&s1)[8], const uint32_t (&w)[4]) {

@@ -17,6 +17,7 @@
 // KS = K / 16 (K steps of one 32x32x16 MFMA), NJ = Co_pad / 32
 template <int KS, int NJ, bool YF32, int RES, bool RELU>
 __global__ __launch_bounds__(S1_NT) void conv1x1_stream_kernel(const ConvGeom g, int64_t npix) {
+    CN_MAIN_PRIO_SET();
     constexpr int K = KS * 16, P = K + 8;                       // LDS pitch of a weight row (elements): rows 16 B apart mod 256 B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* const Ws = reinterpret_cast<bf16_t*>(smem);         // [NJ * 32][P]

@@ -14,6 +14,7 @@
 
 template <typename T, int BN, int CK, int NW = 4>   // NW waves per workgroup: 4 (64x64 wave tiles) or 8 (32x64: twice the waves per SIMD)
 __global__ __launch_bounds__(NW * 64) void conv3x3s1_kernel(const ConvGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int NT = NW * 64;
     constexpr int BM = T3_TH * T3_TW;                  // 128 output pixels
     constexpr int HW_ = T3_TW + 2, HH_ = T3_TH + 2;    // halo tile
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3s1_kernel(const ConvGeom g) {
 // each lane stores 4 consecutive channels of one pixel (8 bytes), a group again being one contiguous 512-byte run.
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define C16_GROUPS 4
-__global__ __launch_bounds__(256, 4) void conv3x3_c16_kernel(const ConvGeom g) {     // <= 128 registers: four waves per SIMD (an HBM stream)
+__global__ __launch_bounds__(256, 4) void conv3x3_c16_kernel(const ConvGeom g) {
+    CN_MAIN_PRIO_SET();     // <= 128 registers: four waves per SIMD (an HBM stream)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, kc = lane >> 4;
     const int half = kc & 1, tsel = kc >> 1;
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256, 4) void conv3x3_c16_kernel(const ConvGeom g) {
 // odd column of a pair land next to each other.
 template <int KC, int NB>      // dy channels = 32*KC, dx channels = 16*NB  (1,1: DLA level1; 2,2: level2's 32 <- 64)
 __global__ __launch_bounds__(256) void dgrad_s2_c32to16_kernel(const ConvGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int CO = 32 * KC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, kc = lane >> 4;

@@ -46,6 +46,7 @@ extern "C" int ws_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, H
 // is branch-free)
 template <int BN, bool YF32, int RES, bool RELU>
 __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int nblk, int tiles_h, int tiles_w, uint64_t wmap) {
+    CN_MAIN_PRIO_SET();
     constexpr int WGN = BN / 32, WGM = 8 / WGN, WM = 256 / WGM, MI = WM / 32;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[WS_LDS];
     float* const bias_l = reinterpret_cast<float*>(lds + 3 * WS_HALO);
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int
     __builtin_amdgcn_s_barrier();
     if (wave >= 4) {
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);        // the later-dispatched half loses every VALU arbitration against its SIMD partner otherwise
+        __builtin_amdgcn_s_setprio(CN_MAIN_PRIO + 1);        // the later-dispatched half loses every VALU arbitration against its SIMD partner otherwise
     }
     int bufbase = 0;
 #pragma unroll 1

@@ -20,6 +20,7 @@
 
 template <typename T, int BN, int BK, bool DOM = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int BM = 128;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int VPR = BK / VEC;         // 16-byte vectors per tile row

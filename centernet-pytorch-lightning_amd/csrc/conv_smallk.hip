@@ -69,6 +69,7 @@ __device__ static inline void smallk_body(const ConvGeom& g, const uint4 (&wr)[1
 
 template <int KE>
 __global__ __launch_bounds__(256) void conv1x1_smallk_kernel(const ConvGeom g, int ppb, int64_t P) {
+    CN_MAIN_PRIO_SET();
     const int cpg = g.Co / 8;
     const int cg = threadIdx.x % cpg, pr = threadIdx.x / cpg;
     const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(g.w);      // [co_pad][16], columns >= K are zero padding
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void conv1x1_smallk_kernel(const ConvGeom g, i
 // the result leaves through a per-wave LDS tile so that the mask is read and the output written as 16-byte vectors.
 template <int KS>      // K_pad / 16
 __global__ __launch_bounds__(256, 2) void conv1x1_midk_kernel(const ConvGeom g, int64_t P, int ngroups_per_block) {
+    CN_MAIN_PRIO_SET();
     constexpr int KP = KS * 16, WP = KP + 8, CO = 256, EP = 128 + 8;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     bf16_t* const Ws = lds;                                  // [256][WP]

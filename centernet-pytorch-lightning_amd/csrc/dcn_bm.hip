@@ -54,6 +54,7 @@ __device__ static inline int bm_lds_ofs(int wr, int wc, int c) {
 
 template <int NCB>   // 32-channel output blocks (Co = 32 * NCB)
 __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
+    CN_MAIN_PRIO_SET();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Xw = smem;                                   // [16][24] pixels x 128 B
     unsigned char* const Ws = smem + BM_WR * BM_WC * BM_PIXB;         // 2 x [4 k-steps][2 halves][32*NCB co][8] bf16
@@ -439,6 +440,7 @@ struct DxBmGeom {
 
 template <int NCB>   // 32-channel blocks of dx (Ci = 32 * NCB); dY has 64 channels
 __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
+    CN_MAIN_PRIO_SET();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Yw = smem;                                   // halo image of dY [16][24] x 128 B; later: geometry table | T tiles
     float* const Tab = reinterpret_cast<float*>(smem);                // [14*22 sources][27]

@@ -64,6 +64,7 @@ __device__ static inline float half_sum(float v) {      // v(lane) + v(lane ^ 32
 
 template <int COP>   // channels of dY (contraction length of the first product): 64 or 128
 __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int KS = COP / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Xw = smem;                                              // [16][24] pixels x 128 B (chunk-swizzled)

@@ -29,6 +29,7 @@ extern "C" int dx_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, H
 
 template <typename T, int BN, int CK>
 __global__ __launch_bounds__(256) void dcn_bwd_dx_kernel(const ConvGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int BM = DX_TH * DX_TW;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int PITCH = CK + Mma<T>::PAD;
@@ -262,6 +263,7 @@ void dcn_bwd_dx_launch(const ConvGeom& g, int dtype, hipStream_t st) {
 //   3. MFMA against the tap's weight slice (register-prefetched one step ahead).
 template <typename T, int BN, int CK>
 __global__ __launch_bounds__(256) void dcn_fwd_kernel(const ConvGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int BM = DX_TH * DX_TW;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int PITCH = CK + Mma<T>::PAD;
@@ -475,6 +477,7 @@ __device__ static inline float quad_sum(float v) {        // sum over the 4 lane
 //   d off_y  = m ((1-lw)(D10-D00) + lw (D11-D01)),   d off_x = m ((1-lh)(D01-D00) + lh (D11-D10)).
 template <int COP>   // padded Co (contraction length): 64 or 128
 __global__ __launch_bounds__(512) void dcn_bwd_dom_kernel(const DomGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int BM = DX_TH * DX_TW, BN = 64;
     constexpr int AP = COP + 8;                 // dY tile / weight slice pitch
     constexpr int DP = BN + 8;                  // dcol tile / halo pitch

@@ -43,6 +43,7 @@ __device__ static inline void blend16(f32x2_t (&acc)[8], const uint4& lo, const 
 
 template <int BN>   // output channels per workgroup: 64 or 128
 __global__ __launch_bounds__(512) void dcn_fwd_tile_kernel(const FwdTileGeom g) {
+    CN_MAIN_PRIO_SET();
     constexpr int BM = FT_TH * FT_TW;           // 128 pixels
     constexpr int CP = 64 + 8;                  // pitch of the halo / A / weight tiles (bf16 elements)
     constexpr int NJ = BN / 64;                 // 32-channel MFMA blocks per wave

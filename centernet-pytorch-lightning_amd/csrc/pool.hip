@@ -6,6 +6,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx,
                                                           int N, int H, int W, int CV, int k, int s, int p, int OH, int OW) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * OH * OW * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -51,6 +52,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ dy,
                                                           const T* __restrict__ acc, T* __restrict__ dx, int N, int H, int W,
                                                           int CV, int k, int s, int p, int OH, int OW) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     const int64_t total = (int64_t)N * H * W * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -108,6 +110,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwdeconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ res,
                                                            T* __restrict__ y, int N, int H, int W, int CV, int k, int s,
                                                            int p, int OH, int OW) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int C = CV * V;
@@ -190,6 +193,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwdeconv_bwd_input_kernel(const T* __restrict__ dy, const float* __restrict__ w,
                                                                  T* __restrict__ dx, int N, int H, int W, int CV, int k,
                                                                  int s, int p, int OH, int OW) {
+    CN_MAIN_PRIO_SET();
     constexpr int V = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float wl[];
     const int C = CV * V;

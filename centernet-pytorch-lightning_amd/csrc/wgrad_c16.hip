@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
                                                         int N, int Ci, int H, int W, int Co, int y_ld, int OH, int OW, int tiles_h,
                                                         int tiles_w, int iters, const float* __restrict__ scale, const float* __restrict__ bias,
                                                         int relu, float* __restrict__ bn_part, int bn_slots) {
+    CN_MAIN_PRIO_SET();
     constexpr int HH = (C16_TH - 1) * S + 7, HWD = (C16_TW - 1) * S + 8, HP = HH * HWD;   // +1 column: the 8th (masked) kw slot
     constexpr int XV = (HP + 63) / 64;
     __shared__ __attribute__((aligned(16))) uint4 wfrag[ST7_MAXCB * 7 * 64];
