@@ -7,8 +7,6 @@ tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python bench.py --steps 20 --warmup 5 --probe-detail $out/ops_by_shape.txt > $out/bench.log 2>&1
-tail -1 $out/bench.log > $out/bench_line.json
 rm -rf $out/kt
 timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt -o p -- python bench.py --no-cpu-baseline --no-inference --no-extras --steps 10 --warmup 3 > $out/kt.log 2>&1
 db=$(ls $out/kt/*.db 2>/dev/null | head -1)
@@ -26,6 +24,11 @@ PY
 done
 rm -rf $out/pmc
 python tools/pmc_traffic_json.py $out/pmc_traffic_raw.txt > $out/pmc_traffic.json
+# the bench line comes AFTER the counter passes: `roofline.traffic` is read from profiles/<tag>_pmc_traffic.json (stamped with the
+# kernel source's blob hash), so the line of this run carries the traffic measured on this very tree
+cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
+python bench.py --steps 20 --warmup 5 --probe-detail $out/ops_by_shape.txt > $out/bench.log 2>&1
+tail -1 $out/bench.log > $out/bench_line.json
 python tools/opbench.py decode bn conv > $out/opbench.txt 2>&1
 DCN_SHAPES=3 python tools/opbench.py dcn >> $out/opbench.txt 2>&1
 python tools/wgrad_bench.py 256 384 > $out/wgrad_bench.txt 2>&1
