@@ -16,6 +16,7 @@ import torch.nn as nn
 from .. import nn as hnn
 from .. import ops
 
+_FUSED_NODE = not __import__("os").environ.get("CN_DISABLE_HEAD_FN")      # A/B: the head as three separate autograd nodes
 PRIOR_LOGIT = -2.19          # sigmoid^-1(0.1): bias of every `heatmap*` head's last conv (heads.py:45-50)
 
 
@@ -42,8 +43,13 @@ class HeadConv(nn.Module):
         self.fc = nn.Sequential(hidden, nn.Identity(), out)
 
     def forward(self, x):
-        h = self.fc[0](x, relu=True, defer_relu_bwd=True)      # ReLU in the epilogue; its backward is owed to ...
-        y = self.fc[2](h, mask_dx=True)                        # ... this conv's data-gradient epilogue
+        hidden, out = self.fc[0], self.fc[2]
+        if (_FUSED_NODE and torch.is_grad_enabled() and x.is_cuda and (x.requires_grad or hidden.weight.requires_grad)
+                and hidden.k == 3 and hidden.stride == 1 and hidden.padding == 1 and hidden.bias is not None and out.bias is not None):
+            # one autograd node per head: its backward works on the gathered rows when the loss is a gather-type one (ops.HeadFn)
+            return ops.HeadFn.apply(x, hidden.weight, hidden.bias, out.weight, out.bias)
+        h = hidden(x, relu=True, defer_relu_bwd=True)          # ReLU in the epilogue; its backward is owed to ...
+        y = out(h, mask_dx=True)                               # ... this conv's data-gradient epilogue
         return ops.ToNCHWFn.apply(y, self.out_channels)
 
     def fill_fc_weights(self):

@@ -202,12 +202,13 @@ class GradCell:
     content to the producer.  A consumer without an epilogue slot (DCNv2's sampling gradient, a pass-through residual) that finds
     the cell occupied pays one cn_add; consumers that know nothing about cells return their gradient as usual and are summed in
     `ShareFn.backward` — the result is the same sum in every case (bf16 rounding of partial sums as with autograd's own adds)."""
-    __slots__ = ("partial",)
+    __slots__ = ("partial", "sparse")
     enabled = not _os.environ.get("CN_DISABLE_GRAD_CELLS")
     adds = 0            # cn_add launches spent on cells (tests / profiling)
 
     def __init__(self):
         self.partial = None
+        self.sparse = []      # closures fn(total) that scatter-add a consumer's few non-zero gradient rows into the finished sum (HeadFn)
 
     def take(self, like=None):
         """-> the gradient accumulated so far (None if nothing), handing its ownership to the caller; with `like` given only when
@@ -246,6 +247,7 @@ class ShareFn(Function):
     @staticmethod
     def forward(ctx, x, cell):
         ctx.cell = cell
+        ctx.meta = (x.shape, x.dtype, x.device)
         ctx.set_materialize_grads(False)
         return x.view_as(x)
 
@@ -254,6 +256,14 @@ class ShareFn(Function):
         total = ctx.cell.take()
         if g is not None:
             total = g if total is None else _add_tensors(total, g)
+        if ctx.cell.sparse:
+            fns, ctx.cell.sparse = ctx.cell.sparse, []
+            if total is None:
+                total = torch.zeros(ctx.meta[0], dtype=ctx.meta[1], device=ctx.meta[2])
+            elif total is g:
+                total = g.clone()                 # autograd's tensor is not ours to modify
+            for fn in fns:
+                fn(total)
         return total, None
 
 
@@ -537,51 +547,60 @@ class Conv2dFn(Function):
                 dskip = ctx.cell.give(dskip)
             return dskip, None, None, None, None, None, None, None, None, None
         stride, pad, relu, has_bias = ctx.cfg
-        Co, Ci, KH, KW = weight.shape
-        N, H, W, Cx = x.shape
         dy = dy.contiguous()
         if relu:
             g = torch.empty_like(dy)
             call("cn_relu_bwd", dy, y, g, dy.numel(), dtype_code(dy.dtype))
             dy = g
-        dx = dw = db = None
-        if ctx.needs_input_grad[1] and Cx == Ci and SideGrads.usable(weight, ctx.bias_ref):
-            def side_work(x=x, dy=dy, bias=ctx.bias_ref):
-                _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=weight.grad, db_into=bias.grad if has_bias else None)
-                GradReady.note(weight, bias)
-            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), x, dy, claims=(weight, ctx.bias_ref))
-        elif ctx.needs_input_grad[1]:
-            dw, db = _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, want_bias=has_bias and ctx.needs_input_grad[2])
-        if ctx.needs_input_grad[0]:
-            wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
-            if Cx != Ci:
-                raise RuntimeError("data gradient through a channel-padded conv input is not supported")
-            small = Co <= 4 and Ci in _SMALLK_WIDTHS                     # 1- / 2-channel heads -> streaming VALU kernel
-            mid = 4 < Co <= 96 and Ci == 256 and dy.shape[-1] <= 96      # class / keypoint heads -> streaming MFMA kernel
-            if (KH == 1 and KW == 1 and stride == 1 and pad == 0 and (small or mid) and x.dtype == torch.bfloat16
-                    and not _os.environ.get("CN_DISABLE_CONV_SMALLK")):
-                # a short contraction with a 256-wide output is epilogue / overhead bound on the GEMM kernel
-                dx = torch.empty((N, H, W, Ci), dtype=x.dtype, device=x.device)
-                call("cn_conv1x1_smallk", dy, wpd, x if ctx.mask_dx else None, dx, N * H * W, Co, dy.shape[-1], Ci, Ci,
-                     x.shape[-1] if ctx.mask_dx else 0, 2 if ctx.mask_dx else 0, dtype_code(x.dtype))
-            elif ctx.mask_dx:
-                dx = _igemm(dy, wpd, None, x, Ci, KH, KW, stride, pad, True, 2, H, W)
-            else:
-                skip = dskip.contiguous() if (dskip is not None and dskip.dtype == x.dtype and dskip.shape == x.shape) else None
-                if skip is not None:
-                    dskip = None                                  # folded into the epilogue
-                elif ctx.cell is not None and not (stride == 2 and KH == 3 and (Co, Ci) in ((32, 16), (64, 32))):
-                    # x is shared: what its other consumers sent rides in the epilogue's residual slot (the two stride-2 shapes
-                    # with a dedicated data-gradient kernel keep it: that kernel has no residual input)
-                    skip = ctx.cell.take(like=x)
-                dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
-            if dskip is not None:
-                dx = _add_tensors(dx, dskip)
-        elif dskip is not None:
-            dx = dskip
-        if ctx.cell is not None:
-            dx = ctx.cell.give(dx)
+        dx, dw, db = _conv2d_bwd(x, weight, ctx.bias_ref, dy, stride, pad, has_bias, ctx.mask_dx, ctx.cell, ctx.order,
+                                 ctx.needs_input_grad[:3], dskip)
         return dx, dw, db, None, None, None, None, None, None, None
+
+
+def _conv2d_bwd(x, weight, bias_ref, dy, stride, pad, has_bias, mask_dx, cell, order, needs, dskip=None):
+    """Backward of one NHWC convolution for the output gradient dy (ReLU already undone): -> (dx, dw, db).  Weight / bias gradients
+    go to the side stream and straight into `.grad` inside a TrainStep (then dw = db = None); dx goes to x's GradCell when it has one
+    (then dx = None).  needs = (dx?, dw?, db?).  Shared by Conv2dFn and HeadFn."""
+    Co, Ci, KH, KW = weight.shape
+    N, H, W, Cx = x.shape
+    dx = dw = db = None
+    if needs[1] and Cx == Ci and SideGrads.usable(weight, bias_ref):
+        def side_work(x=x, dy=dy, bias=bias_ref):
+            _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=weight.grad, db_into=bias.grad if has_bias else None)
+            GradReady.note(weight, bias)
+        SideGrads.submit(SideGrads.wide_if_tail(side_work, order), x, dy, claims=(weight, bias_ref))
+    elif needs[1]:
+        dw, db = _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, want_bias=has_bias and needs[2])
+    if needs[0]:
+        wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
+        if Cx != Ci:
+            raise RuntimeError("data gradient through a channel-padded conv input is not supported")
+        small = Co <= 4 and Ci in _SMALLK_WIDTHS                     # 1- / 2-channel heads -> streaming VALU kernel
+        mid = 4 < Co <= 96 and Ci == 256 and dy.shape[-1] <= 96      # class / keypoint heads -> streaming MFMA kernel
+        if (KH == 1 and KW == 1 and stride == 1 and pad == 0 and (small or mid) and x.dtype == torch.bfloat16
+                and not _os.environ.get("CN_DISABLE_CONV_SMALLK")):
+            # a short contraction with a 256-wide output is epilogue / overhead bound on the GEMM kernel
+            dx = torch.empty((N, H, W, Ci), dtype=x.dtype, device=x.device)
+            call("cn_conv1x1_smallk", dy, wpd, x if mask_dx else None, dx, N * H * W, Co, dy.shape[-1], Ci, Ci,
+                 x.shape[-1] if mask_dx else 0, 2 if mask_dx else 0, dtype_code(x.dtype))
+        elif mask_dx:
+            dx = _igemm(dy, wpd, None, x, Ci, KH, KW, stride, pad, True, 2, H, W)
+        else:
+            skip = dskip.contiguous() if (dskip is not None and dskip.dtype == x.dtype and dskip.shape == x.shape) else None
+            if skip is not None:
+                dskip = None                                  # folded into the epilogue
+            elif cell is not None and not (stride == 2 and KH == 3 and (Co, Ci) in ((32, 16), (64, 32))):
+                # x is shared: what its other consumers sent rides in the epilogue's residual slot (the two stride-2 shapes
+                # with a dedicated data-gradient kernel keep it: that kernel has no residual input)
+                skip = cell.take(like=x)
+            dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
+        if dskip is not None:
+            dx = _add_tensors(dx, dskip)
+    elif dskip is not None:
+        dx = dskip
+    if cell is not None:
+        dx = cell.give(dx)
+    return dx, dw, db
 
 
 def _cat_args(xs):
@@ -1278,6 +1297,125 @@ class SigmoidFocalFn(Function):
         return dz, None, None
 
 
+class SparseRows:
+    """Side channel next to autograd for gradients that are dense tensors by contract but zero outside a few known pixels: the
+    backward of a gather-type loss `note`s (its dense gradient map, the gathered indices); a consumer that can work on rows
+    (`HeadFn.backward`) `take`s the indices when the tensor autograd hands it IS that very map, unmodified — same Python object
+    (the registry's reference keeps it alive, so the engine neither frees nor accumulates into it in place) and same version
+    counter.  Anything else (the map was summed with another gradient, a different tensor) finds nothing and runs dense."""
+    entries = []
+    enabled = not _os.environ.get("CN_DISABLE_SPARSE_HEAD_BWD")
+
+    @classmethod
+    def note(cls, t, ind):
+        if not cls.enabled or t.dim() != 4 or not t.is_cuda:
+            return
+        if len(cls.entries) >= 16:
+            cls.entries.pop(0)
+        cls.entries.append((t, t._version, ind))
+
+    @classmethod
+    def take(cls, g):
+        for i, (t, v, ind) in enumerate(cls.entries):
+            if t is g:
+                cls.entries.pop(i)
+                return ind if g._version == v else None
+        return None
+
+
+class HeadFn(Function):
+    """One task head (heads.py:4-25): conv3x3 + bias -> ReLU -> conv1x1 + bias -> public NCHW fp32 map, as ONE autograd node.
+
+    Forward: the two conv launches (ReLU in the first one's epilogue) + the layout change, as the separate nodes did.  Backward:
+    when the incoming gradient is the map of a gather-type loss (`SparseRows`: zero except at ind[b, :], <= 128 of the 16 384
+    pixels of a 512x512 image) everything is computed on the R = B*M rows that can be non-zero — csrc/head_sparse.hip: compact
+    operands by cn_head_sparse_gather, both weight gradients and the nine-tap data gradient as small 1x1 GEMMs over R "pixels",
+    the data gradient scattered into the shared input's gradient sum — instead of pushing a 537 MB hidden-layer gradient through
+    two dense convolutions per head.  Any other gradient takes the dense path (`_conv2d_bwd` twice, exactly what the separate
+    nodes ran).  The sums are the reference's (heads.py under autograd), taken in a different order."""
+
+    sparse_runs = 0       # backward passes that took the row path (tests / profiling)
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        Ch, Ci, KH, KW = w1.shape
+        C = w2.shape[0]
+        N, H, W, Cx = x.shape
+        assert (KH, KW) == (3, 3) and tuple(w2.shape[1:]) == (Ch, 1, 1) and Cx == rup(Ci, 16)
+        h = _igemm(x, pack_weight(w1, 1, x.dtype), b1, None, Ch, 3, 3, 1, 1, False, True, H, W)
+        y = _igemm(h, pack_weight(w2, 1, x.dtype), b2, None, C, 1, 1, 1, 0, False, False, H, W)
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+        call("cn_nhwc_to_nchw", y, out, N, C, H, W, y.shape[-1], dtype_code(y.dtype))
+        ctx.save_for_backward(x, h, w1, w2)
+        ctx.refs = (b1, b2)
+        ctx.ld2 = y.shape[-1]
+        ctx.orders = (SideGrads.next_order(), SideGrads.next_order())
+        ctx.cell = cell_of(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h, w1, w2 = ctx.saved_tensors
+        b1, b2 = ctx.refs
+        need = ctx.needs_input_grad
+        N, H, W, Cx = x.shape
+        Ch, Ci = w1.shape[:2]
+        C = w2.shape[0]
+        ind = SparseRows.take(g)
+        if (ind is not None and g.dtype == torch.float32 and g.is_contiguous() and ind.shape[0] == N and C <= 64 and Cx == Ci
+                and h.shape[-1] == Ch and 4 * ind.shape[1] <= H * W):
+            return HeadFn._backward_rows(ctx, g, ind.contiguous())
+        dyn = torch.empty((N, H, W, ctx.ld2), dtype=x.dtype, device=x.device)
+        call("cn_nchw_to_nhwc", g.contiguous().float(), dyn, N, C, H, W, ctx.ld2, dtype_code(x.dtype))
+        dh, dw2, db2 = _conv2d_bwd(h, w2, b2, dyn, 1, 0, True, True, None, ctx.orders[1], (need[0] or need[1] or need[2], need[3], need[4]))
+        dx = dw1 = db1 = None
+        if dh is not None:
+            dx, dw1, db1 = _conv2d_bwd(x, w1, b1, dh, 1, 1, True, False, ctx.cell, ctx.orders[0], need[:3])
+        return dx, dw1, db1, dw2, db2
+
+    @staticmethod
+    def _backward_rows(ctx, g, ind):
+        x, h, w1, w2 = ctx.saved_tensors
+        b1, b2 = ctx.refs
+        need = ctx.needs_input_grad
+        N, H, W, Cx = x.shape
+        Ch, Ci = w1.shape[:2]
+        C, M = w2.shape[0], ind.shape[1]
+        R, K, Cq, dt = N * M, 9 * Ci, rup(C, 16), x.dtype
+        HeadFn.sparse_runs += 1
+        hg = torch.empty((1, 1, R, Ch), dtype=dt, device=x.device)
+        dhc = torch.empty((1, 1, R, Ch), dtype=dt, device=x.device)
+        xg = torch.empty((1, 1, R, K), dtype=dt, device=x.device)
+        gq = torch.empty((1, 1, R, Cq), dtype=dt, device=x.device)
+        call("cn_head_sparse_gather", h, x, ind, g, w2.detach().contiguous(), hg, dhc, xg, gq, N, M, C, H, W, Ch, h.shape[-1], Ci, Cx,
+             Cq, dtype_code(dt))
+        dw1 = db1 = dw2 = db2 = dx = None
+        if need[1] or need[3]:
+            if SideGrads.usable(w1, b1, w2, b2):
+                def side_work():
+                    _wgrad_param(hg, gq, C, Ch, 1, 1, 1, 0, into=w2.grad, db_into=b2.grad)
+                    _wgrad_param(xg, dhc, Ch, K, 1, 1, 1, 0, into=w1.grad.view(Ch, K, 1, 1), db_into=b1.grad)   # K = ci*9 + tap: w1's own layout
+                    GradReady.note(w1, b1, w2, b2)
+                SideGrads.submit(side_work, hg, gq, xg, dhc, claims=(w1, b1, w2, b2))
+            else:
+                dw2, db2 = _wgrad_param(hg, gq, C, Ch, 1, 1, 1, 0, want_bias=True)
+                dw1, db1 = _wgrad_param(xg, dhc, Ch, K, 1, 1, 1, 0, want_bias=True)
+                dw1 = dw1.view(Ch, Ci, 3, 3)
+        if need[0]:
+            # the nine-tap data gradient of the rows = the data gradient of the 1x1 convolution whose weight is w1 read as [Ch, Ci*9]
+            wpd = pack_weight(w1.detach().view(Ch, K, 1, 1), 0, dt)
+            dxc = _igemm(dhc, wpd, None, None, K, 1, 1, 1, 0, True, False, 1, R, out_dtype=torch.float32)
+
+            def scatter(total, dxc=dxc):
+                call("cn_scatter3x3_add", dxc, ind, total, N, M, H, W, Ci, total.shape[-1], dtype_code(total.dtype))
+            if ctx.cell is not None:
+                ctx.cell.sparse.append(scatter)       # applied to the finished sum of x's consumers (ShareFn.backward)
+            else:
+                dx = torch.zeros_like(x)
+                scatter(dx)
+        return dx, dw1, db1, dw2, db2
+
+
 class GatherL1Fn(Function):
     """utils/losses.py:53-63 / 81-91: masked L1 between rows gathered at `ind` and the targets."""
 
@@ -1304,6 +1442,7 @@ class GatherL1Fn(Function):
         dfeat = torch.zeros_like(feat)
         call("cn_gather_l1_bwd", feat, ind, mask8, target, out, g.contiguous().float().reshape(1), dfeat, B, C,
              feat[0, 0].numel(), ind.shape[1], ctx.has_c)
+        SparseRows.note(dfeat, ind)       # zero outside ind[b, :]: a HeadFn behind `feat` works on those rows only
         return dfeat, None, None, None
 
 

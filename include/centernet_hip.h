@@ -289,6 +289,22 @@ int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uint8_t* mask,
                      const float* out3, const float* gout, float* dfeat,
                      int B, int C, int64_t HW, int N, int mask_has_c, void* stream);
 
+/* ---- backward of a head whose loss gathers its output at `ind` (heads.py:4-25 under RegL1Loss / RegWeightedL1Loss,
+ * utils/losses.py:53-63, 81-91): the output gradient is zero except at ind[b, :], so autograd's dense conv1x1 <- ReLU <- conv3x3
+ * backward reduces to sums over the R = B*M rows.  cn_head_sparse_gather builds the compact operands (dtype = the head's
+ * activation dtype): h [B,H,W,h_ld] hidden activation (post-ReLU), x [B,H,W,x_ld] head input, ind int64 [B,M] (pixel index
+ * y*W + x), dout fp32 NCHW [B,C,H,W] (the dense output gradient; read at ind only, repeated indices counted once), w2 fp32
+ * [C,Ch] (the 1x1 conv's parameter).  Outputs: hg [R,Ch] = h rows, dhc [R,Ch] = (h > 0) * (w2^T g), xg [R,9*Ci] = the 3x3 input
+ * patch of every row in PARAMETER order (column ci*9 + kh*3 + kw, zeros outside the image), gq [R,Cq] = g rows zero-padded to
+ * Cq channels.  C <= 64. */
+int cn_head_sparse_gather(const void* h, const void* x, const int64_t* ind, const float* dout, const float* w2, void* hg, void* dhc,
+                          void* xg, void* gq, int B, int M, int C, int H, int W, int Ch, int h_ld, int Ci, int x_ld, int Cq, int dtype,
+                          void* stream);
+/* dx[b, p + (kh-1, kw-1), ci] += dxc[r, ci*9 + kh*3 + kw] for p = ind[r] (r = b*M + m), taps outside the image dropped; dx
+ * [B,H,W,dx_ld] in `dtype` (fp32: atomic add; bf16: compare-and-swap on the containing word), dxc fp32 [R, 9*Ci]. */
+int cn_scatter3x3_add(const float* dxc, const int64_t* ind, void* dx, int B, int M, int H, int W, int Ci, int dx_ld, int dtype,
+                      void* stream);
+
 /* ---- ground-truth encoding (replaces the per-sample host loop of sample/ctdet.py:39-90) -------------- */
 /* boxes fp32 [B][M][4] = COCO (x, y, w, h) in input pixels, cls int32 [B][M], nobj int32 [B] (objects beyond nobj[b] are
  * ignored).  heatmap fp32 [B][C][OH][OW] must be ZEROED by the caller (gaussians are max-splatted into it);

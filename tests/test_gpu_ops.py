@@ -789,3 +789,86 @@ def test_shared_tensor_gradient_cells_small_graph(dt):
     close(g1, g0, dt, "d x through shared-tensor cells vs autograd accumulation")
     for u, v in zip(p1, p0):
         close(u, v, dt, "parameter gradient", scale=max(1e-6, float(v.abs().max())))
+
+
+# ---------------------------------------------------------------------------------------------- head backward on gathered rows
+def _head_reference(x, w1, b1, w2, b2, ind, mask, target):
+    """heads.py:4-25 + RegL1Loss (utils/losses.py:53-63) in plain torch (NCHW fp32, autograd's dense backward)."""
+    import torch.nn.functional as F
+    h = F.relu(F.conv2d(x, w1, b1, padding=1))
+    out = F.conv2d(h, w2, b2)
+    B, C = out.shape[:2]
+    pred = out.view(B, C, -1).gather(2, ind.unsqueeze(1).expand(B, C, ind.shape[1])).permute(0, 2, 1)
+    m = mask.unsqueeze(2).expand_as(pred).float()
+    return F.l1_loss(pred * m, target * m, reduction="sum") / (m.sum() + 1e-4)
+
+
+@pytest.mark.parametrize("dt,C,M,hw", [(torch.float32, 2, 16, 24), (torch.float32, 34, 12, 16), (torch.bfloat16, 2, 32, 32)])
+def test_head_backward_on_gathered_rows(dt, C, M, hw):
+    """ops.HeadFn under a gather-type loss: the row path (csrc/head_sparse.hip) against torch's dense autograd of the same head —
+    input gradient (through a shared-tensor cell next to a dense sibling), both weight and bias gradients; repeated indices,
+    border pixels and masked slots included.  fp32 mode 2e-5 of the largest element; bf16 5e-2 (operands rounded to bf16)."""
+    from centernet_amd import ops
+    from centernet_amd.utils.losses import RegL1Loss
+    B, Ci, Ch = 3, 64, 256
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Ci, hw, hw, generator=g)
+    w1 = torch.randn(Ch, Ci, 3, 3, generator=g) * 0.05
+    b1 = torch.randn(Ch, generator=g) * 0.1
+    w2 = torch.randn(C, Ch, 1, 1, generator=g) * 0.1
+    b2 = torch.randn(C, generator=g) * 0.1
+    ind = torch.randint(0, hw * hw, (B, M), generator=g)
+    ind[:, 0] = 0                       # corner pixel
+    ind[:, 1] = hw * hw - 1             # opposite corner
+    ind[:, 3] = ind[:, 2]               # repeated index
+    mask = (torch.rand(B, M, generator=g) > 0.3)
+    mask[:, :4] = True
+    target = torch.randn(B, M, C, generator=g)
+    if dt == torch.bfloat16:
+        x, w1, w2 = x.bfloat16().float(), w1.bfloat16().float(), w2.bfloat16().float()
+    # reference: a dense sibling consumer (sum of squares of a 1x1 projection) shares x with the head
+    xr, w1r, b1r, w2r, b2r = (t.clone().requires_grad_() for t in (x, w1, b1, w2, b2))
+    lr = _head_reference(xr, w1r, b1r, w2r, b2r, ind, mask, target) + 0.01 * (xr * xr).sum()
+    lr.backward()
+    # HIP: NHWC engine tensors, x shared between the head and the dense sibling
+    xd = x.to(DEV).requires_grad_()
+    params = [t.to(DEV).requires_grad_() for t in (w1, b1, w2, b2)]
+    xn = ops.share(ops.FromNCHWFn.apply(xd, dt))
+    before = ops.HeadFn.sparse_runs
+    out = ops.HeadFn.apply(xn, *params)
+    sib = ops.ToNCHWFn.apply(xn, Ci)
+    loss = RegL1Loss()(out, mask.to(DEV), ind.to(DEV), target.to(DEV)) + 0.01 * (sib * sib).sum()
+    loss.backward()
+    assert ops.HeadFn.sparse_runs == before + 1, "the row path did not run"
+    tol = 2e-5 if dt == torch.float32 else 5e-2
+    assert float(loss) == pytest.approx(float(lr), rel=1e-5 if dt == torch.float32 else 2e-2)
+    for name, got, ref in [("x", xd.grad, xr.grad), ("w1", params[0].grad, w1r.grad), ("b1", params[1].grad, b1r.grad),
+                           ("w2", params[2].grad, w2r.grad), ("b2", params[3].grad, b2r.grad)]:
+        err = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err < tol, (name, err)
+
+
+def test_head_backward_dense_fallback_matches_rows():
+    """A gradient HeadFn cannot tie to a gather (here: the same map plus a dense term) takes the dense path; both paths agree."""
+    from centernet_amd import ops
+    from centernet_amd.utils.losses import RegL1Loss
+    B, Ci, Ch, C, M, hw = 2, 64, 256, 2, 8, 16
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, Ci, hw, hw, generator=g).to(DEV)
+    ws = [(torch.randn(Ch, Ci, 3, 3, generator=g) * 0.05), torch.randn(Ch, generator=g) * 0.1,
+          torch.randn(C, Ch, 1, 1, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1]
+    ind = torch.randint(0, hw * hw, (B, M), generator=g).to(DEV)
+    mask = torch.ones(B, M, dtype=torch.bool, device=DEV)
+    target = torch.randn(B, M, C, generator=g).to(DEV)
+    grads = {}
+    for mode in ("rows", "dense"):
+        ps = [w.clone().to(DEV).requires_grad_() for w in ws]
+        xd = x.clone().requires_grad_()
+        out = ops.HeadFn.apply(ops.FromNCHWFn.apply(xd, torch.float32), *ps)
+        before = ops.HeadFn.sparse_runs
+        loss = RegL1Loss()(out, mask, ind, target) + (0.0 * out.sum() if mode == "dense" else 0.0)   # + 0 * sum: autograd adds a second gradient
+        loss.backward()
+        assert ops.HeadFn.sparse_runs == before + (mode == "rows")
+        grads[mode] = [xd.grad] + [p.grad for p in ps]
+    for a, b in zip(grads["rows"], grads["dense"]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
