@@ -431,3 +431,26 @@ def test_bn_statistics_sink_chain_bookkeeping():
         assert all(float(b.abs().max()) == 0.0 for ring in B._rings.values() for b in ring) and not B._state
     finally:
         B.ns, B._rings, B._state, B.slots, B.fused = saved
+
+
+def test_sparse_rows_registry_only_matches_the_untouched_tensor():
+    """ops.SparseRows (the side channel that lets HeadFn.backward work on gathered rows): `take` hands out the indices only for the
+    very tensor that was noted, and only while its version counter is unchanged — a gradient autograd accumulated into in place,
+    a copy, or any other tensor must fall back to the dense path; the registry stays bounded."""
+    import torch
+    from centernet_amd import ops
+    reg = ops.SparseRows
+    saved, reg.entries = reg.entries, []
+    try:
+        t, ind = torch.zeros(2, 3, 4, 4), torch.arange(6).view(2, 3)
+        reg.entries.append((t, t._version, ind))
+        assert reg.take(t.clone()) is None and len(reg.entries) == 1          # another tensor with the same values
+        assert reg.take(t) is ind and not reg.entries                         # the noted tensor itself: consumed
+        assert reg.take(t) is None                                            # only once
+        reg.entries.append((t, t._version, ind))
+        t.add_(1.0)                                                           # what autograd's in-place accumulation does
+        assert reg.take(t) is None and not reg.entries                        # stale: dense path, entry dropped
+        reg.note(torch.zeros(1, 1, 2, 2), ind)                                # CPU tensors are never registered (no row path there)
+        assert not reg.entries
+    finally:
+        reg.entries = saved
