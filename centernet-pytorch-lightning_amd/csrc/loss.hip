@@ -268,6 +268,66 @@ extern "C" int cn_focal_fwd(const float* pred, const float* gt, float* out4, int
     return CN_OK;
 }
 
+// sigmoid_clamp_fwd_vec_kernel + focal_fwd_vec_kernel in ONE pass over the class heat map: x <- sigmoid(x), y <- clamp(x), focal
+// partial sums of y against gt (same grid, same per-thread order as focal_fwd_vec_kernel: the partials are bit-identical to the
+// two-kernel sequence, which re-read the 335 MB of y it had just written)
+__global__ __launch_bounds__(256) void sigmoid_clamp_focal_fwd_vec_kernel(float4* __restrict__ x, float4* __restrict__ y,
+                                                                          const float4* __restrict__ gt, float* __restrict__ part,
+                                                                          int64_t n4, float lo) {
+    const float hi = 1.f - lo;
+    float pos = 0.f, neg = 0.f, np = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = x[i];
+        const float4 gv = gt[i];
+        float* e = &v.x;
+        const float* ge = &gv.x;
+        float4 c;
+        float* ce = &c.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sg = 1.f / (1.f + expf(-e[j]));
+            e[j] = sg;
+            const float p = fminf(fmaxf(sg, lo), hi), g = ge[j];
+            ce[j] = p;
+            if (g == 1.f) {
+                const float q = 1.f - p;
+                pos += logf(p) * q * q;
+                np += 1.f;
+            } else if (g < 1.f) {
+                const float w = 1.f - g;
+                const float w2 = w * w;
+                neg += logf(1.f - p) * p * p * (w2 * w2);
+            }
+        }
+        x[i] = v;
+        y[i] = c;
+    }
+    __shared__ float red[3][4];
+    pos = wave_sum(pos); neg = wave_sum(neg); np = wave_sum(np);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wv] = pos; red[1][wv] = neg; red[2][wv] = np; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 3 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[blockIdx.x * 3 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        part[blockIdx.x * 3 + 2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    }
+}
+
+extern "C" int cn_sigmoid_clamp_focal_fwd(float* x, float* y, const float* gt, float* out4, int64_t n, float lo, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    CN_CHECK_ARG(x && y && gt && out4 && ws && n > 0, "cn_sigmoid_clamp_focal_fwd: bad args");
+    if (ws_bytes < cn_focal_workspace_bytes(0)) { cn_set_error("cn_sigmoid_clamp_focal_fwd: workspace too small"); return CN_EWORKSPACE; }
+    if (!loss_vec_ok(x, y, gt, n)) CN_UNSUPPORTED("cn_sigmoid_clamp_focal_fwd: needs n %% 4 == 0 and 16-byte aligned maps (use the two-kernel sequence)");
+    const int grid = focal_grid(n);
+    hipLaunchKernelGGL(sigmoid_clamp_focal_fwd_vec_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float4*)x, (float4*)y,
+                       (const float4*)gt, (float*)ws, n / 4, lo);
+    CN_LAUNCH_CHECK("cn_sigmoid_clamp_focal_fwd");
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, grid, out4);
+    CN_LAUNCH_CHECK("cn_sigmoid_clamp_focal_fwd(finalize)");
+    return CN_OK;
+}
+
 extern "C" int cn_focal_bwd(const float* pred, const float* gt, const float* out4, const float* gout, float* dpred, int B,
                             int C, int64_t HW, int gtB, int gtC, void* stream) {
     CN_CHECK_ARG(pred && gt && out4 && gout && dpred && B > 0 && C > 0 && HW > 0, "cn_focal_bwd: bad args");

@@ -1268,14 +1268,18 @@ class SigmoidFocalFn(Function):
     def forward(ctx, x, gt, lo):
         assert x.dtype == torch.float32 and x.is_contiguous()
         y = torch.empty_like(x)
-        call("cn_sigmoid_clamp_fwd", x, y, x.numel(), float(lo))
         gt = gt.contiguous().float()
         B, C = x.shape[:2]
         HW = x[0, 0].numel()
         out = torch.empty(4, dtype=torch.float32, device=x.device)
         n = _hip.query("cn_focal_workspace_bytes", x.numel())
         ws = _hip.workspace(n, x.device, "focal")
-        call("cn_focal_fwd", y, gt, out, B, C, HW, gt.shape[0], gt.shape[1], ws, n)
+        if (gt.shape == x.shape and x.numel() % 4 == 0 and not ((x.data_ptr() | y.data_ptr() | gt.data_ptr()) & 15)
+                and not _os.environ.get("CN_DISABLE_FUSED_FOCAL_FWD")):
+            call("cn_sigmoid_clamp_focal_fwd", x, y, gt, out, x.numel(), float(lo), ws, n)      # one pass instead of two
+        else:
+            call("cn_sigmoid_clamp_fwd", x, y, x.numel(), float(lo))
+            call("cn_focal_fwd", y, gt, out, B, C, HW, gt.shape[0], gt.shape[1], ws, n)
         ctx.mark_dirty(x)
         ctx.mark_non_differentiable(y)
         ctx.set_materialize_grads(False)

@@ -280,6 +280,11 @@ int cn_focal_bwd(const float* pred, const float* gt, const float* out4, const fl
  * x_sig = sigmoid(logits) as left in place by cn_sigmoid_clamp_fwd, out4 / gout as for cn_focal_bwd, dz = d loss / d logits. */
 int cn_sigmoid_focal_bwd(const float* x_sig, const float* gt, const float* out4, const float* gout, float* dz, int B, int C,
                          int64_t HW, int gtB, int gtC, float lo, void* stream);
+/* cn_sigmoid_clamp_fwd + cn_focal_fwd in one pass (centernet_detection.py:103-106: `sigmoid_clamped` then FocalLoss): x fp32 [n]
+ * becomes sigmoid(x) in place, y its clamped copy, out4 as for cn_focal_fwd on (y, gt); gt has x's shape (no broadcast), n % 4
+ * == 0, 16-byte aligned pointers (CN_EUNSUPPORTED otherwise: run the two entry points).  Results are bit-identical to the pair. */
+int cn_sigmoid_clamp_focal_fwd(float* x, float* y, const float* gt, float* out4, int64_t n, float lo, void* ws, size_t ws_bytes,
+                               void* stream);
 /* masked gather-L1 (utils/losses.py:53-63, 81-91): feat NCHW fp32 [B,C,HW]; ind int64 [B,N]; mask uint8 [B,N]
  * (mask_has_c == 0) or [B,N,C]; target fp32 [B,N,C].  out[0] = loss, out[1] = sum|.|, out[2] = sum(mask). */
 int cn_gather_l1_fwd(const float* feat, const int64_t* ind, const uint8_t* mask, const float* target, float* out3,
