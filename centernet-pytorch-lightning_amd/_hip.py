@@ -104,6 +104,17 @@ def call(name, *args):
         raise RuntimeError(f"{name} failed (status {rc}): {L.cn_last_error().decode()}")
 
 
+def try_call(name, *args):
+    """Like `call`, for entry points that decline shapes: -> False on CN_EUNSUPPORTED (the caller runs its general path)."""
+    L = lib()
+    rc = getattr(L, name)(*[_arg(a) for a in args], stream_ptr())
+    if rc == -2:
+        return False
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (status {rc}): {L.cn_last_error().decode()}")
+    return True
+
+
 def query(name, *args):
     """size_t / int queries without a stream argument."""
     return getattr(lib(), name)(*args)

@@ -15,7 +15,10 @@
 #define S1_NT 256
 
 // KS = K / 16 (K steps of one 32x32x16 MFMA), NJ = Co_pad / 32
-template <int KS, int NJ, bool YF32, int RES, bool RELU>
+// NCHW: the output is the public fp32 map [N][Co][OH*OW] with the Co real channels (a head's last conv, heads.py:15-17 — the
+// reference's layout): every accumulator register is one channel of 32 consecutive pixels, i.e. a 128-byte run of that channel's
+// plane, stored straight from the accumulators (no NHWC bf16 intermediate, no layout-change pass).  OH*OW % 32 == 0.
+template <int KS, int NJ, bool YF32, int RES, bool RELU, bool NCHW = false>
 __global__ __launch_bounds__(S1_NT) void conv1x1_stream_kernel(const ConvGeom g, int64_t npix) {
     CN_MAIN_PRIO_SET();
     constexpr int K = KS * 16, P = K + 8;                       // LDS pitch of a weight row (elements): rows 16 B apart mod 256 B
@@ -74,6 +77,21 @@ __global__ __launch_bounds__(S1_NT) void conv1x1_stream_kernel(const ConvGeom g,
 
         const int64_t p = s * 32 + (lane & 31);
         const bool live = p < npix;
+        if constexpr (NCHW) {
+            if (live) {
+                const int64_t hw = (int64_t)g.OH * g.OW;
+                const int64_t b = p / hw, pix = p - b * hw;
+                float* const dst = reinterpret_cast<float*>(g.y) + b * g.Co * hw + pix;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (ch < g.Co) dst[(int64_t)ch * hw] = acc[j][r];
+                    }
+            }
+            continue;
+        }
         const int chl = 8 * (lane >> 5);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -128,6 +146,41 @@ static bool s1_go(const ConvGeom& g, int64_t npix, int grid, int dev, hipStream_
     else S1_GO(false, 2, false);
 #undef S1_GO
     return true;
+}
+
+// y = public NCHW fp32 map [N][Co][H*W] (g.y; g.y_ld is ignored), bias in, no residual / ReLU.  K = 256 (the heads' hidden width)
+bool conv1x1_stream_nchw_launch(const ConvGeom& g, int dtype, hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_CONV1X1_STREAM") != nullptr || getenv("CN_DISABLE_CONV1X1_NCHW") != nullptr;
+    static int cus_of[CN_MAX_DEVICES] = {};
+    if (disabled || dtype != CN_BF16 || g.nsrc != 0 || g.res != nullptr || g.relu != 0 || (g.x_ld & 7)) return false;
+    if ((reinterpret_cast<uintptr_t>(g.x) | reinterpret_cast<uintptr_t>(g.w)) & 15) return false;
+    const int K = g.Ci, nj = (g.Co + 31) / 32;
+    const int64_t hw = (int64_t)g.OH * g.OW, npix = (int64_t)g.N * hw;
+    if (K != 256 || K != g.ktot || nj < 1 || nj > 4 || g.co_pad < nj * 32 || hw % 32 != 0 || npix < 64 * 1024) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CN_MAX_DEVICES) return false;
+    if (cus_of[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return false;
+        cus_of[dev] = v;
+    }
+    const int grid = (int)std::min<int64_t>(2 * (int64_t)cus_of[dev], (npix / 32 + 3) / 4);
+#define S1_NCHW(NJ_)                                                                                                     \
+    do {                                                                                                                 \
+        auto kfn = conv1x1_stream_kernel<16, NJ_, true, 0, false, true>;                                                 \
+        static bool attr[CN_MAX_DEVICES] = {};                                                                           \
+        if (!attr[dev]) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; } \
+        const size_t smem = (size_t)NJ_ * 32 * (16 * 16 + 8) * 2 + (size_t)NJ_ * 32 * 4;                                 \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(S1_NT), smem, st, g, npix);                                             \
+        return true;                                                                                                     \
+    } while (0)
+    switch (nj) {
+        case 1: S1_NCHW(1);
+        case 2: S1_NCHW(2);
+        case 3: S1_NCHW(3);
+        default: S1_NCHW(4);
+    }
+#undef S1_NCHW
 }
 
 // caller guarantees: 1x1 / stride 1 / pad 0 geometry (normal or transposed: one tap, no shift), OH == H, OW == W

@@ -493,6 +493,22 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     return CN_OK;
 }
 
+bool conv1x1_stream_nchw_launch(const ConvGeom& g, int dtype, hipStream_t st);
+
+extern "C" int cn_conv1x1_nchw_fwd(const void* x, const void* wp, const float* bias, float* y, int N, int H, int W, int Ci, int x_ld,
+                                   int Co, int dtype, void* stream) {
+    CN_CHECK_ARG(x && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && x_ld >= Ci, "cn_conv1x1_nchw_fwd: bad args");
+    ConvGeom g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.w = wp; g.bias = bias; g.y = y;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = Co;
+    g.ktot = Ci; g.co_pad = (Co + 31) / 32 * 32; g.y_f32 = 1;
+    if (!conv1x1_stream_nchw_launch(g, dtype, (hipStream_t)stream))
+        CN_UNSUPPORTED("cn_conv1x1_nchw_fwd: shape not handled (bf16, Ci == 256, Co <= 128, H*W %% 32 == 0, >= 64 Ki pixels): run cn_conv2d_fwd + cn_nhwc_to_nchw");
+    CN_LAUNCH_CHECK("cn_conv1x1_nchw_fwd");
+    return CN_OK;
+}
+
 // 1x1 / stride 1 conv over the channel concatenation of up to CN_MAX_SRC NHWC tensors (each contiguous: pitch = its channel count)
 extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
                                   int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,

@@ -49,6 +49,8 @@ class HeadConv(nn.Module):
             # one autograd node per head: its backward works on the gathered rows when the loss is a gather-type one (ops.HeadFn)
             return ops.HeadFn.apply(x, hidden.weight, hidden.bias, out.weight, out.bias)
         h = hidden(x, relu=True, defer_relu_bwd=True)          # ReLU in the epilogue; its backward is owed to ...
+        if not (torch.is_grad_enabled() and (h.requires_grad or out.weight.requires_grad)) and _FUSED_NODE:
+            return out.infer_nchw(h)                           # no-grad: the last conv writes the public NCHW fp32 map itself
         y = out(h, mask_dx=True)                               # ... this conv's data-gradient epilogue
         return ops.ToNCHWFn.apply(y, self.out_channels)
 

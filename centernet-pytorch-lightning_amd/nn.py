@@ -44,8 +44,8 @@ class Conv2d(nn.Module):
             return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, False, False, False, True, bn_stats=bn_stats)
         return self.forward(x), x
 
-    def infer(self, x, scale, shift, residual, relu, out_dtype=None):
-        """No-grad path: y = act(conv(x)*scale + shift + residual); packed (folded) weights are cached."""
+    def infer_key(self, x, scale=None, shift=None):
+        """-> the cache entry {wp: packed (folded) weights, b: folded bias} for x's dtype and the current parameter versions"""
         key = (x.dtype, self.weight._version, None if self.bias is None else self.bias._version, ops.WeightsEpoch.value,
                None if scale is None else (scale.data_ptr(), scale._version))
         hit = self._cache.get("k")
@@ -55,11 +55,20 @@ class Conv2d(nn.Module):
             if shift is not None:
                 b = shift if b is None else (b * scale + shift)   # tiny [Co] host-side fold (once per weight version)
             self._cache = {"k": key, "wp": wp, "b": b}
-        c = self._cache
+        return self._cache
+
+    def infer(self, x, scale, shift, residual, relu, out_dtype=None):
+        """No-grad path: y = act(conv(x)*scale + shift + residual); packed (folded) weights are cached."""
+        c = self.infer_key(x, scale, shift)
         Co, _, KH, KW = self.weight.shape
         N, H, W, _ = x.shape
         OH, OW = ops.conv_out(H, KH, self.stride, self.padding), ops.conv_out(W, KW, self.stride, self.padding)
         return ops._igemm(x, c["wp"], c["b"], residual, Co, KH, KW, self.stride, self.padding, False, relu, OH, OW, out_dtype)
+
+    def infer_nchw(self, x):
+        """No-grad 1x1 conv + bias straight into the public fp32 NCHW layout (a head's last layer); packed weights cached as in `infer`."""
+        self.infer_key(x)
+        return ops.conv1x1_to_nchw(x, self._cache["wp"], self._cache["b"], self.weight.shape[0])
 
 
 class BatchNorm2d(nn.BatchNorm2d):

@@ -1301,6 +1301,18 @@ class SigmoidFocalFn(Function):
         return dz, None, None
 
 
+def conv1x1_to_nchw(h, wp, bias, C):
+    """A head's last conv straight into the public layout: fp32 NCHW [N,C,H,W] = conv1x1(h) + bias.  One launch where the
+    streaming kernel takes the shape (cn_conv1x1_nchw_fwd), else the NHWC conv followed by the layout change."""
+    N, H, W, Ch = h.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=h.device)
+    if h.dtype == torch.bfloat16 and _hip.try_call("cn_conv1x1_nchw_fwd", h, wp, bias, out, N, H, W, Ch, Ch, C, dtype_code(h.dtype)):
+        return out
+    y = _igemm(h, wp, bias, None, C, 1, 1, 1, 0, False, False, H, W)
+    call("cn_nhwc_to_nchw", y, out, N, C, H, W, y.shape[-1], dtype_code(y.dtype))
+    return out
+
+
 class SparseRows:
     """Side channel next to autograd for gradients that are dense tensors by contract but zero outside a few known pixels: the
     backward of a gather-type loss `note`s (its dense gradient map, the gathered indices); a consumer that can work on rows
@@ -1347,12 +1359,10 @@ class HeadFn(Function):
         N, H, W, Cx = x.shape
         assert (KH, KW) == (3, 3) and tuple(w2.shape[1:]) == (Ch, 1, 1) and Cx == rup(Ci, 16)
         h = _igemm(x, pack_weight(w1, 1, x.dtype), b1, None, Ch, 3, 3, 1, 1, False, True, H, W)
-        y = _igemm(h, pack_weight(w2, 1, x.dtype), b2, None, C, 1, 1, 1, 0, False, False, H, W)
-        out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
-        call("cn_nhwc_to_nchw", y, out, N, C, H, W, y.shape[-1], dtype_code(y.dtype))
+        out = conv1x1_to_nchw(h, pack_weight(w2, 1, x.dtype), b2, C)
         ctx.save_for_backward(x, h, w1, w2)
         ctx.refs = (b1, b2)
-        ctx.ld2 = y.shape[-1]
+        ctx.ld2 = rup(C, 16)
         ctx.orders = (SideGrads.next_order(), SideGrads.next_order())
         ctx.cell = cell_of(x)
         return out

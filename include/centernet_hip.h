@@ -203,6 +203,12 @@ int cn_dwdeconv_bwd_input(const void* dy, const float* w, void* dx, int N, int H
 int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp32 [C,k,k] */, int N, int H, int W,
                            int C, int k, int stride, int pad, int OH, int OW, int dtype, void* stream);
 
+/* A head's last layer (heads.py:15-17: nn.Conv2d(head_conv, out_channels, 1) on the hidden activation) straight into the public
+ * layout: y fp32 NCHW [N,Co,H,W] = conv1x1(x) + bias, x [N,H,W,x_ld] in `dtype`, wp = cn_pack_weight(mode 1).  Replaces
+ * cn_conv2d_fwd (NHWC bf16 out) + cn_nhwc_to_nchw.  bf16, Ci == 256, Co <= 128, H*W % 32 == 0, N*H*W >= 65536; anything else
+ * -> CN_EUNSUPPORTED (run the pair). */
+int cn_conv1x1_nchw_fwd(const void* x, const void* wp, const float* bias, float* y, int N, int H, int W, int Ci, int x_ld, int Co,
+                        int dtype, void* stream);
 /* 1x1 / stride-1 convolution over the channel CONCATENATION of nsrc (<= 6) NHWC tensors of the same N,H,W — DLA's Root:
  * `conv(torch.cat(x, 1))`, pose_dla_dcn.py:180-188 — without materialising the concatenation: the K loop of the implicit GEMM
  * walks the sources.  x_i: contiguous [N,H,W,c_i] (c_i a multiple of 16; unused slots NULL / 0); wp = cn_pack_weight mode 1 of

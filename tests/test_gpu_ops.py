@@ -872,3 +872,28 @@ def test_head_backward_dense_fallback_matches_rows():
         grads[mode] = [xd.grad] + [p.grad for p in ps]
     for a, b in zip(grads["rows"], grads["dense"]):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("C", [2, 34, 80])
+def test_conv1x1_into_public_nchw_layout(C):
+    """cn_conv1x1_nchw_fwd (a head's last conv writing the fp32 NCHW map itself) against torch's conv on the same bf16-rounded
+    operands: fp32 accumulation, no bf16 rounding of the result -> 1e-5 of the largest element; and the entry point declines
+    what the streaming kernel does not take (fp32 activations) so that the caller runs conv + layout change."""
+    from centernet_amd import _hip, ops
+    N, H, W, Ch = 4, 128, 128, 256
+    g = torch.Generator().manual_seed(9)
+    h = torch.randn(N, H, W, Ch, generator=g).bfloat16()
+    w = (torch.randn(C, Ch, 1, 1, generator=g) * 0.1)
+    b = torch.randn(C, generator=g)
+    ref = torch.nn.functional.conv2d(h.float().permute(0, 3, 1, 2), w.bfloat16().float(), b)
+    hd, wd, bd = h.to(DEV), w.to(DEV), b.to(DEV)
+    wp = ops.pack_weight(wd, 1, torch.bfloat16)
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=DEV)
+    assert _hip.try_call("cn_conv1x1_nchw_fwd", hd, wp, bd, out, N, H, W, Ch, Ch, C, _hip.CN_BF16)
+    err = float((out.cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 1e-5, err
+    assert torch.equal(ops.conv1x1_to_nchw(hd, wp, bd, C), out)
+    h32 = hd.float()
+    assert not _hip.try_call("cn_conv1x1_nchw_fwd", h32, ops.pack_weight(wd, 1, torch.float32), bd, out, N, H, W, Ch, Ch, C, _hip.CN_F32)
+    out32 = ops.conv1x1_to_nchw(h32, ops.pack_weight(wd, 1, torch.float32), bd, C)      # general path
+    assert float((out32.cpu() - torch.nn.functional.conv2d(h.float().permute(0, 3, 1, 2), w, b)).abs().max()) < 1e-3 * float(ref.abs().max())
