@@ -584,3 +584,38 @@ def test_backbone_output_gradient_is_visible_to_autograd():
     loss.backward()
     g = feats[-1].grad
     assert g is not None and g.shape == feats[-1].shape and float(g.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("task,arch", [("ctdet", "dla_34"), ("multi_pose", "res_18")])
+def test_row_path_head_backward_equals_dense_on_the_whole_network(task, arch):
+    """Every parameter gradient of a network (fp32 compute) with the heads' backward on the gathered rows (ops.HeadFn + SparseRows:
+    width_height / regression, and keypoints / keypoint offsets for multi_pose) against the same network with the dense head
+    backward: 2e-5 of each gradient's largest element — the sums are the same, taken in a different order."""
+    from centernet_amd import ops
+    m = _model(arch, 71, torch.float32, task).train()
+    if task == "ctdet":
+        x, tgt = synth.ctdet_batch(71, 2, 256, 256)
+    else:
+        x, tgt = synth.pose_batch(71, 2, 256, 256)
+    x, tgt = x.to(DEV), {k: v.to(DEV) for k, v in tgt.items()}
+    grads, runs = {}, {}
+    for rows in (True, False):
+        ops.SparseRows.enabled = rows
+        try:
+            m.zero_grad(set_to_none=True)
+            before = ops.HeadFn.sparse_runs
+            loss, _ = m.loss(m(x), tgt)
+            loss.backward()
+            runs[rows] = ops.HeadFn.sparse_runs - before
+            grads[rows] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ops.SparseRows.enabled = True
+    # (the keypoint-offset head gathers 128 x 17 rows: more than a 64x64 map has room for under the row path's 4 M <= H W rule)
+    assert runs[False] == 0 and runs[True] == (2 if task == "ctdet" else 3), runs
+    assert grads[True].keys() == grads[False].keys()
+    # floor of the scale: the bias of a DCN conv in front of a batch-statistic BN has an identically-zero gradient (both runs hold
+    # rounding noise there, a few 1e-9 of the network's largest gradient element)
+    top = max(float(g.abs().max()) for g in grads[False].values())
+    worst = {n: float((grads[True][n] - grads[False][n]).abs().max()) / max(float(grads[False][n].abs().max()), 1e-3 * top) for n in grads[True]}
+    bad = {n: round(v, 8) for n, v in worst.items() if v > 2e-5}
+    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:8])
