@@ -1342,7 +1342,8 @@ class SparseRows:
 class HeadFn(Function):
     """One task head (heads.py:4-25): conv3x3 + bias -> ReLU -> conv1x1 + bias -> public NCHW fp32 map, as ONE autograd node.
 
-    Forward: the two conv launches (ReLU in the first one's epilogue) + the layout change, as the separate nodes did.  Backward:
+    Forward: two launches — the 3x3 conv with the ReLU in its epilogue, and the 1x1 conv writing the public NCHW fp32 map itself
+    (`conv1x1_to_nchw`; where that kernel declines the shape: NHWC conv + layout change, as the separate nodes did).  Backward:
     when the incoming gradient is the map of a gather-type loss (`SparseRows`: zero except at ind[b, :], <= 128 of the 16 384
     pixels of a 512x512 image) everything is computed on the R = B*M rows that can be non-zero — csrc/head_sparse.hip: compact
     operands by cn_head_sparse_gather, both weight gradients and the nine-tap data gradient as small 1x1 GEMMs over R "pixels",
