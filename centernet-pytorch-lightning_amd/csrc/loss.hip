@@ -244,6 +244,59 @@ __global__ __launch_bounds__(256) void sigmoid_focal_bwd_vec_kernel(const float4
     }
 }
 
+// sigmoid_focal_bwd_vec_kernel that ALSO leaves d loss / d logits in the layout its usual consumer wants (NHWC, compute dtype bf16,
+// channels zero-padded to `ld`): a workgroup owns 64 consecutive pixels of one image x all C channels — fp32 NCHW rows out as they
+// are computed (256-byte runs per channel), the bf16 transpose staged in LDS and written as whole pixel rows.  Saves the consumer's
+// cn_nchw_to_nhwc pass (read 4 B + write 2 B per element) for one extra 2 B write here.  HW % 64 == 0, ld % 8 == 0, C <= ld <= 256.
+__global__ __launch_bounds__(256) void sigmoid_focal_bwd_dual_kernel(const float* __restrict__ s, const float* __restrict__ gt,
+                                                                     const float* __restrict__ out4, const float* __restrict__ gout,
+                                                                     float* __restrict__ dz, bf16_t* __restrict__ dz_nhwc, int C,
+                                                                     int64_t HW, int ld, float lo) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t tile[];          // [64 px][ld + 8]
+    const int P = ld + 8;
+    const float np = out4[3], hi = 1.f - lo;
+    const float scale = -gout[0] / (np == 0.f ? 1.f : np);
+    const int64_t blocks_per_img = HW / 64;
+    const int64_t b = blockIdx.x / blocks_per_img, p0 = (blockIdx.x - b * blocks_per_img) * 64;
+    const int tid = threadIdx.x, px4 = tid & 15, crow = tid >> 4;
+    for (int i = tid; i < 64 * (ld - C); i += 256) tile[(i / (ld - C)) * P + C + i % (ld - C)] = 0;      // channel padding
+    for (int c = crow; c < C; c += 16) {
+        const int64_t off = (b * C + c) * HW + p0 + 4 * px4;
+        const float4 sv4 = *reinterpret_cast<const float4*>(s + off), gv4 = *reinterpret_cast<const float4*>(gt + off);
+        const float* se = &sv4.x;
+        const float* ge = &gv4.x;
+        float4 o;
+        float* oe = &o.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sv = se[j], g = ge[j];
+            float d = 0.f;
+            if (sv >= lo && sv <= hi) {
+                const float p = sv;
+                if (g == 1.f) {
+                    const float q = 1.f - p;
+                    d = q * q / p - 2.f * q * logf(p);
+                } else if (g < 1.f) {
+                    const float w = 1.f - g;
+                    const float w2 = w * w;
+                    d = (w2 * w2) * (2.f * p * logf(1.f - p) - p * p / (1.f - p));
+                }
+                d = (d * scale) * p * (1.f - p);
+            }
+            oe[j] = d;
+            tile[(4 * px4 + j) * P + c] = f2bf(d);
+        }
+        *reinterpret_cast<float4*>(dz + off) = o;
+    }
+    __syncthreads();
+    const int vpp = ld / 8;                                                // 16-byte vectors per pixel
+    bf16_t* const dst = dz_nhwc + (b * HW + p0) * ld;
+    for (int v = tid; v < 64 * vpp; v += 256) {
+        const int px = v / vpp, cv = v - px * vpp;
+        st16(dst + (int64_t)px * ld + cv * 8, *reinterpret_cast<const uint4*>(tile + px * P + cv * 8));
+    }
+}
+
 static int focal_grid(int64_t n) {
     int64_t g = (n + 256 * 8 - 1) / (256 * 8);
     return (int)(g > FOCAL_MAX_BLOCKS ? FOCAL_MAX_BLOCKS : (g < 1 ? 1 : g));
@@ -356,6 +409,19 @@ extern "C" int cn_sigmoid_focal_bwd(const float* x_sig, const float* gt, const f
     hipLaunchKernelGGL(sigmoid_focal_bwd_kernel, dim3((int)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, x_sig, gt, out4,
                        gout, dz, n, HW, C, gtB, gtC, (int)(gtB == B && gtC == C), lo);
     CN_LAUNCH_CHECK("cn_sigmoid_focal_bwd");
+    return CN_OK;
+}
+
+extern "C" int cn_sigmoid_focal_bwd_dual(const float* x_sig, const float* gt, const float* out4, const float* gout, float* dz,
+                                         void* dz_nhwc, int B, int C, int64_t HW, int ld, float lo, void* stream) {
+    CN_CHECK_ARG(x_sig && gt && out4 && gout && dz && dz_nhwc && B > 0 && C > 0 && HW > 0, "cn_sigmoid_focal_bwd_dual: bad args");
+    if (HW % 64 != 0 || (ld & 7) || ld < C || ld > 256 || B * (HW / 64) > 0x7fffffffLL ||
+        ((((uintptr_t)x_sig | (uintptr_t)gt | (uintptr_t)dz | (uintptr_t)dz_nhwc)) & 15))
+        CN_UNSUPPORTED("cn_sigmoid_focal_bwd_dual: needs HW %% 64 == 0, C <= ld <= 256, ld %% 8 == 0, 16-byte aligned maps");
+    const size_t smem = (size_t)64 * (ld + 8) * sizeof(bf16_t);
+    hipLaunchKernelGGL(sigmoid_focal_bwd_dual_kernel, dim3((unsigned)(B * (HW / 64))), dim3(256), smem, (hipStream_t)stream, x_sig, gt,
+                       out4, gout, dz, (bf16_t*)dz_nhwc, C, HW, ld, lo);
+    CN_LAUNCH_CHECK("cn_sigmoid_focal_bwd_dual");
     return CN_OK;
 }
 

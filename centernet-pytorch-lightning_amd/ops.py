@@ -1296,8 +1296,15 @@ class SigmoidFocalFn(Function):
             return None, None, None
         B, C = s.shape[:2]
         dz = torch.empty_like(s)
-        call("cn_sigmoid_focal_bwd", s, gt, out, g.contiguous().float().reshape(1), dz, B, C, s[0, 0].numel(), gt.shape[0], gt.shape[1],
-             ctx.lo)
+        gout = g.contiguous().float().reshape(1)
+        if DualLayout.enabled and s.dim() == 4 and gt.shape == s.shape:
+            # the usual consumer is a head's backward, which wants NHWC in the compute dtype: leave that copy next to the fp32 map
+            # (the consumer recognises `dz` itself — DualLayout — and skips its layout-change pass)
+            alt = torch.empty((B, s.shape[2], s.shape[3], rup(C, 16)), dtype=torch.bfloat16, device=s.device)
+            if _hip.try_call("cn_sigmoid_focal_bwd_dual", s, gt, out, gout, dz, alt, B, C, s[0, 0].numel(), alt.shape[-1], ctx.lo):
+                DualLayout.note(dz, alt)
+                return dz, None, None
+        call("cn_sigmoid_focal_bwd", s, gt, out, gout, dz, B, C, s[0, 0].numel(), gt.shape[0], gt.shape[1], ctx.lo)
         return dz, None, None
 
 
@@ -1337,6 +1344,13 @@ class SparseRows:
                 cls.entries.pop(i)
                 return ind if g._version == v else None
         return None
+
+
+class DualLayout(SparseRows):
+    """The same side channel for a gradient map whose producer also left it in a second layout: note(fp32 NCHW map, NHWC copy in
+    the compute dtype); `take` hands the copy to the consumer that receives that very map."""
+    entries = []
+    enabled = not _os.environ.get("CN_DISABLE_DUAL_LAYOUT_GRAD")
 
 
 class HeadFn(Function):
@@ -1380,8 +1394,10 @@ class HeadFn(Function):
         if (ind is not None and g.dtype == torch.float32 and g.is_contiguous() and ind.shape[0] == N and C <= 64 and Cx == Ci
                 and h.shape[-1] == Ch and 4 * ind.shape[1] <= H * W):
             return HeadFn._backward_rows(ctx, g, ind.contiguous())
-        dyn = torch.empty((N, H, W, ctx.ld2), dtype=x.dtype, device=x.device)
-        call("cn_nchw_to_nhwc", g.contiguous().float(), dyn, N, C, H, W, ctx.ld2, dtype_code(x.dtype))
+        dyn = DualLayout.take(g)          # the loss's backward may have left the map in this layout already (SigmoidFocalFn)
+        if dyn is None or dyn.dtype != x.dtype or tuple(dyn.shape) != (N, H, W, ctx.ld2):
+            dyn = torch.empty((N, H, W, ctx.ld2), dtype=x.dtype, device=x.device)
+            call("cn_nchw_to_nhwc", g.contiguous().float(), dyn, N, C, H, W, ctx.ld2, dtype_code(x.dtype))
         dh, dw2, db2 = _conv2d_bwd(h, w2, b2, dyn, 1, 0, True, True, None, ctx.orders[1], (need[0] or need[1] or need[2], need[3], need[4]))
         dx = dw1 = db1 = None
         if dh is not None:

@@ -286,6 +286,11 @@ int cn_focal_bwd(const float* pred, const float* gt, const float* out4, const fl
  * x_sig = sigmoid(logits) as left in place by cn_sigmoid_clamp_fwd, out4 / gout as for cn_focal_bwd, dz = d loss / d logits. */
 int cn_sigmoid_focal_bwd(const float* x_sig, const float* gt, const float* out4, const float* gout, float* dz, int B, int C,
                          int64_t HW, int gtB, int gtC, float lo, void* stream);
+/* cn_sigmoid_focal_bwd that also writes dz as the head's backward wants it: dz_nhwc bf16 [B,HW,ld] (channels C..ld-1 zero), next to
+ * the fp32 NCHW dz — the consumer (heads.py:15-17 backwards) then skips its cn_nchw_to_nhwc pass.  gt has the maps' shape; HW % 64
+ * == 0, C <= ld <= 256, ld % 8 == 0, else CN_EUNSUPPORTED (run cn_sigmoid_focal_bwd).  dz is bit-identical to cn_sigmoid_focal_bwd's. */
+int cn_sigmoid_focal_bwd_dual(const float* x_sig, const float* gt, const float* out4, const float* gout, float* dz, void* dz_nhwc,
+                              int B, int C, int64_t HW, int ld, float lo, void* stream);
 /* cn_sigmoid_clamp_fwd + cn_focal_fwd in one pass (centernet_detection.py:103-106: `sigmoid_clamped` then FocalLoss): x fp32 [n]
  * becomes sigmoid(x) in place, y its clamped copy, out4 as for cn_focal_fwd on (y, gt); gt has x's shape (no broadcast), n % 4
  * == 0, 16-byte aligned pointers (CN_EUNSUPPORTED otherwise: run the two entry points).  Results are bit-identical to the pair. */

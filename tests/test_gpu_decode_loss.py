@@ -422,6 +422,13 @@ def test_fused_sigmoid_focal_matches_two_step():
     assert la.item() == lb.item()
     assert float((yb == 1e-4).float().mean()) > 0.01 and float((yb == 1 - 1e-4).float().mean()) > 1e-4
     assert torch.equal(a.grad, b.grad), "single-pass backward is bit-identical to the two kernels"
+    # the backward also left d loss / d logits as NHWC bf16 for a head's backward (ops.DualLayout): exactly the layout change of dz
+    from centernet_amd import ops
+    from centernet_amd._hip import call, CN_BF16
+    dz, _, alt = ops.DualLayout.entries.pop()
+    ref = torch.empty_like(alt)
+    call("cn_nchw_to_nhwc", dz, ref, 2, 80, 128, 128, 80, CN_BF16)
+    assert alt.dtype == torch.bfloat16 and tuple(alt.shape) == (2, 128, 128, 80) and torch.equal(alt, ref)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
