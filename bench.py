@@ -370,13 +370,15 @@ def dry_run(args, rank, world):
     """The launch contract without a GPU: RANK / WORLD_SIZE parsing, per-rank batch offsets (`start=rank * nuniq` below is the
     expression the real run uses), the MAX-over-ranks reduction of the timing and the rank-0-only JSON line."""
     from centernet_amd import synth
-    nuniq = min(args.batch, 8)
-    x, tgt = synth.ctdet_batch(1234, nuniq, 64, 64, start=rank * nuniq)
+    nuniq = args.batch
+    x, tgt = synth.ctdet_batch(1234, min(nuniq, 8), 64, 64, start=rank * nuniq)
     mine = {"rank": rank, "first_image_index": rank * nuniq, "checksum": round(float(x.double().sum()), 6),
             "objects": int(tgt["regression_mask"].sum())}
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     per_rank = [mine]
+    backend = {"backend": None, "backend_world_size": 1}
     if dist.is_initialized():
+        backend = {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size()}
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         per_rank = [None] * world
@@ -387,7 +389,27 @@ def dry_run(args, rank, world):
         print(json.dumps({"metric": "images/sec (train step + decode) DLA-34 512\u00d7512 bs=64 at 1/2/4/8 MI355X", "value": None,
                           "unit": "images/s", "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "scaling": "weak", "max_over_ranks": float(t.item()),
-                          "config": {"global_batch": args.batch * world, "parallelism": f"dp{world}"}, "ranks": per_rank}), flush=True)
+                          "config": {"global_batch": args.batch * world, "parallelism": f"dp{world}"}, "ranks": per_rank, **backend}), flush=True)
+
+
+def spawn_ranks(n):
+    """Re-run this very command line as `n` ranks of one node (python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same flags>); the children see WORLD_SIZE and take the normal path.
+    stdout / stderr are inherited, so rank 0's ONE JSON line is this process's JSON line; the exit status is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        sys.exit(rc)
 
 
 def main():
@@ -420,6 +442,12 @@ def main():
     ap.add_argument("--probe-detail", default=None, help="write a per-shape table of every launch of a step to this file")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher (the shape of the driver's N = 1 command): become the launcher — one rank per
+        # GPU under torch.distributed.run on a free local port, like the reference's one-command DDP launch
+        # (centernet_detection.py:405-409, Trainer flags -> DDP).  Rank 0 of the children prints the JSON line; it passes through.
+        return spawn_ranks(args.gpus)
+
     from centernet_amd import _hip, synth
     from centernet_amd.centernet_detection import CenterNetDetection
     from centernet_amd.decode.ctdet import ctdet_decode
@@ -438,12 +466,12 @@ def main():
     model = CenterNetDetection(args.arch, compute_dtype=dt).to(dev).train()
     if args.dcn_offsets == "trained":
         set_trained_offsets(model)
-    # one synthetic COCO-like batch per rank (different images per rank), resident in HBM before timing starts
-    nuniq = min(args.batch, 8)
+    # one synthetic COCO-like batch per rank, every image of it different (and different from every other rank's), resident in HBM
+    # before timing starts: top-K / decode cost is data dependent, and repeated images could be served from L2 / MALL
+    nuniq = args.batch
     x, tgt = synth.ctdet_batch(1234, nuniq, args.size, args.size, start=rank * nuniq)
-    rep = (args.batch + nuniq - 1) // nuniq
-    x = x.repeat(rep, 1, 1, 1)[:args.batch].to(dev)
-    tgt = {k: v.repeat(rep, *([1] * (v.dim() - 1)))[:args.batch].to(dev) for k, v in tgt.items()}
+    x = x.to(dev)
+    tgt = {k: v.to(dev) for k, v in tgt.items()}
     batch = (x, tgt)
     if args.host_input != "none":        # PCIe-inclusive variant: the step's input copy becomes host -> device
         batch = (x.cpu().pin_memory(), {k: v.cpu().pin_memory() for k, v in tgt.items()} if args.host_input == "full" else tgt)
@@ -494,10 +522,18 @@ def main():
     if feed is not None:
         step = run
     elapsed = time.perf_counter() - t0
+    ranks_info = None
     if dist.is_initialized():
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        # value = all ranks' images / the SLOWEST rank's time; each rank's own rate and the world the backend itself reports go
+        # into the line next to it (all_gather over RCCL: the collective path is exercised even when a rank's step is local)
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks_info = {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size(),
+                      "per_rank_images_per_s": [round(args.batch * args.steps / float(e.item()), 2) for e in every]}
     det = step.post_out
     assert det.shape == (args.batch, 100, 6) and bool(torch.isfinite(det).all())
 
@@ -679,6 +715,8 @@ def main():
                 "roofline": roof,
                 "inference": inference,
                 "cpu_baseline": None}
+        if ranks_info:
+            line["ranks"] = ranks_info
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)

@@ -449,6 +449,7 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
                              int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
                              int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype,
                              void* stream) {
+    const BnSink sink = bn_sink_take();   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm): disarmed before ANY early return
     CN_CHECK_ARG(x && wp && y, "cn_conv2d_fwd: null pointer");
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0, "cn_conv2d_fwd: bad dims");
     if (Ci % 16 != 0 || Ci <= 0) CN_UNSUPPORTED("cn_conv2d_fwd: Ci=%d must be a positive multiple of 16", Ci);
@@ -468,10 +469,8 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     CN_CHECK_ARG(!(residual && out_dtype != dtype), "cn_conv2d_fwd: residual needs out_dtype == dtype");
     int ncls = build_geom(g, KH, KW, stride, pad, transposed);
     if (ncls < 0) CN_UNSUPPORTED("cn_conv2d_fwd: kernel %dx%d stride %d not supported", KH, KW, stride);
-    {   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm): honoured by the kernels that have the hook
-        const BnSink sink = bn_sink_take();
-        if (sink.part && dtype == CN_BF16 && out_dtype == dtype && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
-    }
+    // the sink is honoured by the kernels that have the hook
+    if (sink.part && dtype == CN_BF16 && out_dtype == dtype && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
     if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);
     if (transposed && dtype == CN_BF16 && out_dtype == dtype && KH == 3 && KW == 3 && stride == 2 && pad == 1 && ((Ci == 32 && Co == 16) || (Ci == 64 && Co == 32)) &&
         OH == 2 * H && OW == 2 * W && !bias && !residual && !relu && dgrad_s2_c32to16_launch(g, (hipStream_t)stream)) {
@@ -514,6 +513,7 @@ extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2
                                   int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
                                   const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
                                   int dtype, void* stream) {
+    const BnSink sink = bn_sink_take();   // armed statistics sink: disarmed before any early return
     const void* xs[CN_MAX_SRC] = {x0, x1, x2, x3, x4, x5};
     const int cs[CN_MAX_SRC] = {c0, c1, c2, c3, c4, c5};
     CN_CHECK_ARG(nsrc >= 1 && nsrc <= CN_MAX_SRC && wp && y && N > 0 && H > 0 && W > 0 && Co > 0 && y_ld >= Co,
@@ -535,10 +535,7 @@ extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2
     g.N = N; g.H = H; g.W = W; g.Ci = k; g.x_ld = cs[0]; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld; g.res_ld = res_ld;
     g.ktot = k; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu;
     const int ncls = build_geom(g, 1, 1, 1, 0, 0);
-    {   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm)
-        const BnSink sink = bn_sink_take();
-        if (sink.part && dtype == CN_BF16 && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
-    }
+    if (sink.part && dtype == CN_BF16 && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
     // tile choice of dispatch_igemm with the K slice bounded by the smallest source granule
     ConvGeom gp = g;
     gp.Ci = div;                                // pick_tile() only looks at divisibility
@@ -649,6 +646,7 @@ extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
 // wp = cn_pack_weight mode 1 of the layer weight ([Co_pad32][tap*Ci + ci]); om fp32 [P][om_ld]; bias fp32[Co] nullable.
 extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,
                           int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, void* stream) {
+    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (the blend-matrix kernel has the hook)
     CN_CHECK_ARG(x && om && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "cn_dcn_fwd: bad args");
     if (Ci % 16 != 0) CN_UNSUPPORTED("cn_dcn_fwd: Ci=%d must be a multiple of 16", Ci);
     if (N > 65535) CN_UNSUPPORTED("cn_dcn_fwd: batch %d", N);
@@ -660,7 +658,6 @@ extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const 
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld;
     g.ktot = 9 * Ci; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu; g.so = 1; g.sm = 1;
     g.dcn_om = om; g.dcn_omld = om_ld;
-    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (the blend-matrix kernel has the hook)
     const bool sink_ok = sink.part && dtype == CN_BF16 && sink.C == y_ld;
     if (dtype == CN_BF16 && dcn_fwd_bm_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
                                               sink.slots, (hipStream_t)stream)) {

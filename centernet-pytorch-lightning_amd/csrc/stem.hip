@@ -218,10 +218,10 @@ static int stem_check(int Ci, int KH, int KW, int stride) {
 
 extern "C" int cn_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H,
                                 int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream) {
+    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm); disarmed first
     CN_CHECK_ARG(x && w && y && N > 0 && Co > 0, "cn_stem_conv_fwd: bad args");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
-    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm)
     const bool sink_ok = sink.part && dtype == CN_BF16 && sink.C == Co;
     if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H + 6 - 7) / stride + 1 && OW == (W + 6 - 7) / stride + 1 &&
         stem7_fwd_launch(x, w, scale, bias, relu, y, N, Ci, H, W, Co, stride, OH, OW, sink_ok ? sink.part : nullptr, sink.slots, (hipStream_t)stream)) {

@@ -400,7 +400,18 @@ class TrainStep:
         PackArena.current = None
 
     def _eager(self, batch, batch_idx=0):
-        ops.BnStats.ns = self._ns              # this step's chain of BatchNorm statistics sinks (kept apart from other steps' graphs)
+        # this step's chain of BatchNorm statistics sinks, kept apart from every other chain in the process.  Once a graph has
+        # been captured its namespace belongs to the REPLAYS (the graph's baked-in sink pointers assume that nothing else dirties
+        # or retires those sinks): eager steps of the same TrainStep (the bench's probe steps, the capture-failure fallback) get a
+        # namespace of their own, and the previous namespace comes back on exit, so BN passes outside any step (a train-mode
+        # forward under no_grad, recalibration) never touch a step's rings (round-3 ADVICE).
+        ns_was, ops.BnStats.ns = ops.BnStats.ns, (self._ns if self._g1 is None else self._ns + ("eager",))
+        try:
+            return self._eager_body(batch, batch_idx)
+        finally:
+            ops.BnStats.ns = ns_was
+
+    def _eager_body(self, batch, batch_idx=0):
         self.opt.zero_grad()
         self._begin_packs()
         try:
@@ -487,22 +498,25 @@ class TrainStep:
         mode = "thread_local" if (dist.is_initialized() or os.environ.get("CN_CAPTURE_THREAD_LOCAL")) else "global"
         # capture on the stream the warm-up steps ran on: `_hip.workspace` is keyed by stream, so the capture replays into the
         # buffers the warm-up sized instead of allocating a second set from the graph's private pool
-        ops.BnStats.ns = self._ns
-        with torch.cuda.graph(self._g1, stream=side, capture_error_mode=mode):
-            self.opt.zero_grad()
-            self._begin_packs()
-            loss = self.model.training_step(static, 0)
-            self._fork_post_forward()
-            if self.sync is not None and not self._between:
-                self.sync.begin()
-            SideGrads.active = self.side
-            loss.backward()
-            SideGrads.join()
-            self._end_packs()
-            self._join_post_forward()
-            if self.sync is not None and not self._between:
-                self.sync.finish()         # the bucketed all-reduces are part of the captured graph
-            self._loss = loss.detach()
+        ns_was, ops.BnStats.ns = ops.BnStats.ns, self._ns
+        try:
+            with torch.cuda.graph(self._g1, stream=side, capture_error_mode=mode):
+                self.opt.zero_grad()
+                self._begin_packs()
+                loss = self.model.training_step(static, 0)
+                self._fork_post_forward()
+                if self.sync is not None and not self._between:
+                    self.sync.begin()
+                SideGrads.active = self.side
+                loss.backward()
+                SideGrads.join()
+                self._end_packs()
+                self._join_post_forward()
+                if self.sync is not None and not self._between:
+                    self.sync.finish()         # the bucketed all-reduces are part of the captured graph
+                self._loss = loss.detach()
+        finally:
+            ops.BnStats.ns = ns_was
         for m in self._bns:
             m._pending -= 1          # the capture pass ran host code only; nothing executed on the device
         with torch.cuda.graph(self._g2, pool=self._g1.pool(), stream=side, capture_error_mode=mode):

@@ -47,7 +47,9 @@ class HeadConv(nn.Module):
         if (_FUSED_NODE and torch.is_grad_enabled() and x.is_cuda and (x.requires_grad or hidden.weight.requires_grad)
                 and hidden.k == 3 and hidden.stride == 1 and hidden.padding == 1 and hidden.bias is not None and out.bias is not None):
             # one autograd node per head: its backward works on the gathered rows when the loss is a gather-type one (ops.HeadFn)
-            return ops.HeadFn.apply(x, hidden.weight, hidden.bias, out.weight, out.bias)
+            y = ops.HeadFn.apply(x, hidden.weight, hidden.bias, out.weight, out.bias)
+            y._cn_head_dtype = x.dtype          # SigmoidFocalFn leaves a second-layout gradient only for a bf16 HeadFn (ops.DualLayout)
+            return y
         h = hidden(x, relu=True, defer_relu_bwd=True)          # ReLU in the epilogue; its backward is owed to ...
         if not (torch.is_grad_enabled() and (h.requires_grad or out.weight.requires_grad)) and _FUSED_NODE:
             return out.infer_nchw(h)                           # no-grad: the last conv writes the public NCHW fp32 map itself

@@ -87,10 +87,13 @@ class BnStats:
     _rings, _state = {}, {}
 
     @classmethod
-    def _st(cls):
-        st = cls._state.get(cls.ns)
+    def _st(cls, device):
+        """dirty set + retired chain of (namespace, device): a launch on one device is never asked to clear another device's sink
+        (round-3 ADVICE).  A namespace runs on ONE stream per device (a TrainStep's launch stream) — the chain is a stream order."""
+        key = (cls.ns, str(device))
+        st = cls._state.get(key)
         if st is None:
-            st = cls._state[cls.ns] = {"dirty": set(), "retired": []}
+            st = cls._state[key] = {"dirty": set(), "retired": []}
         return st
 
     @classmethod
@@ -101,7 +104,7 @@ class BnStats:
             # 43.0 / 42.7 / 42.1 / 42.1 / 42.2 ms with 128 / 64 / 32 / 16 / 8 rows; finalize launches + 128 rows: 42.9)
             cls.slots = 32 if cls.fused else int(_hip.query("cn_bn_stats_slots"))
         ring = cls._rings.setdefault((cls.ns, kind, int(C), str(device)), [])
-        st = cls._st()
+        st = cls._st(device)
         for buf in ring:
             if buf.data_ptr() not in st["dirty"]:
                 break
@@ -114,12 +117,12 @@ class BnStats:
     @classmethod
     def release(cls, buf):
         """the sink was handed out but nothing wrote to it (or its consumer cleared it itself)"""
-        cls._st()["dirty"].discard(buf.data_ptr())
+        cls._st(buf.device)["dirty"].discard(buf.data_ptr())
 
     @classmethod
     def retire(cls, buf):
         """buf was just consumed by a *_sink launch -> (sink that launch should clear | None).  Call BEFORE the launch."""
-        st = cls._st()
+        st = cls._st(buf.device)
         clear = st["retired"].pop(0) if st["retired"] else None
         while st["retired"]:                       # (does not happen in a regular step: at most one sink waits to be cleared)
             extra = st["retired"].pop(0)
@@ -136,7 +139,9 @@ class BnStats:
         if not (want and cls.enabled and y.dtype == torch.bfloat16):
             return call(name, *args)
         part = cls.acquire("f", y.shape[-1], y.device)
-        _hip.query("cn_bn_stats_arm", part.data_ptr(), part.shape[0], part.shape[2])
+        if _hip.query("cn_bn_stats_arm", part.data_ptr(), part.shape[0], part.shape[2]) != 0:
+            cls.release(part)                # refused (width not a multiple of 8, ...): nothing is armed, BN reads x itself
+            return call(name, *args)
         try:
             call(name, *args)
         except BaseException:
@@ -1285,6 +1290,9 @@ class SigmoidFocalFn(Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, gt, out)
         ctx.lo = float(lo)
+        # the second (NHWC, compute dtype) copy of d loss / d logits is only worth writing when the map comes out of a bf16 HeadFn,
+        # the one consumer that takes it (fp32 parity mode and foreign heads discard it: round-3 ADVICE)
+        ctx.dual = getattr(x, "_cn_head_dtype", None) == torch.bfloat16
         return x, y, out[0]
 
     @staticmethod
@@ -1297,7 +1305,7 @@ class SigmoidFocalFn(Function):
         B, C = s.shape[:2]
         dz = torch.empty_like(s)
         gout = g.contiguous().float().reshape(1)
-        if DualLayout.enabled and s.dim() == 4 and gt.shape == s.shape:
+        if DualLayout.enabled and ctx.dual and s.dim() == 4 and gt.shape == s.shape:
             # the usual consumer is a head's backward, which wants NHWC in the compute dtype: leave that copy next to the fp32 map
             # (the consumer recognises `dz` itself — DualLayout — and skips its layout-change pass)
             alt = torch.empty((B, s.shape[2], s.shape[3], rup(C, 16)), dtype=torch.bfloat16, device=s.device)
@@ -1328,22 +1336,38 @@ class SparseRows:
     counter.  Anything else (the map was summed with another gradient, a different tensor) finds nothing and runs dense."""
     entries = []
     enabled = not _os.environ.get("CN_DISABLE_SPARSE_HEAD_BWD")
+    _lock = __import__("threading").Lock()      # autograd may run backward nodes of several graphs on several threads
 
     @classmethod
     def note(cls, t, ind):
         if not cls.enabled or t.dim() != 4 or not t.is_cuda:
             return
-        if len(cls.entries) >= 16:
-            cls.entries.pop(0)
-        cls.entries.append((t, t._version, ind))
+        with cls._lock:
+            if len(cls.entries) >= 16:
+                cls.entries.pop(0)
+            first = not cls.entries
+            cls.entries.append((t, t._version, ind))
+        if first:
+            # an entry nobody takes (the consumer is not a HeadFn: a plain-torch head, CN_DISABLE_HEAD_FN) must not pin its
+            # gradient map (335 MB at C3) beyond the backward pass that made it: drop what is left when this pass ends
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.clear)
+            except RuntimeError:              # not inside a backward pass (tests calling backward() of a Function by hand)
+                pass
 
     @classmethod
     def take(cls, g):
-        for i, (t, v, ind) in enumerate(cls.entries):
-            if t is g:
-                cls.entries.pop(i)
-                return ind if g._version == v else None
+        with cls._lock:
+            for i, (t, v, ind) in enumerate(cls.entries):
+                if t is g:
+                    cls.entries.pop(i)
+                    return ind if g._version == v else None
         return None
+
+    @classmethod
+    def clear(cls):
+        with cls._lock:
+            del cls.entries[:]
 
 
 class DualLayout(SparseRows):
@@ -1351,6 +1375,7 @@ class DualLayout(SparseRows):
     the compute dtype); `take` hands the copy to the consumer that receives that very map."""
     entries = []
     enabled = not _os.environ.get("CN_DISABLE_DUAL_LAYOUT_GRAD")
+    _lock = __import__("threading").Lock()
 
 
 class HeadFn(Function):

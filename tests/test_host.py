@@ -378,8 +378,28 @@ def test_bench_launch_contract_two_processes():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and d["dry_run"] is True
     assert d["max_over_ranks"] == 2.0
-    assert [x["rank"] for x in d["ranks"]] == [0, 1] and [x["first_image_index"] for x in d["ranks"]] == [0, 8]
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and [x["first_image_index"] for x in d["ranks"]] == [0, 64]
     assert d["ranks"][0]["checksum"] != d["ranks"][1]["checksum"], "ranks must draw different images"
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with NO torchrun around it (the shape of the driver's N = 1 command; round-3 VERDICT item 1): the
+    process becomes the launcher (torch.distributed.run, free local port), two ranks join, rank 0's single JSON line comes out of
+    the parent's stdout with n_gpus = 2 and the world size the backend itself reports."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["backend_world_size"] == 2 and d["backend"] == "gloo" and d["dry_run"] is True
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and d["max_over_ranks"] == 2.0
 
 
 def test_bench_refuses_a_world_size_that_differs_from_gpus():
