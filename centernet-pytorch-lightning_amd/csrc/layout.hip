@@ -140,6 +140,30 @@ extern "C" int cn_add(const void* a, const void* b, void* out, int64_t n, int dt
     return CN_OK;
 }
 
+// zero a buffer: 16-byte stores over the aligned body, byte stores for the ragged head / tail (any pointer, any size)
+__global__ __launch_bounds__(256) void zero_kernel(unsigned char* __restrict__ p, int64_t nbytes) {
+    const int64_t head = (int64_t)((16 - ((uintptr_t)p & 15)) & 15);
+    const int64_t h = head < nbytes ? head : nbytes;
+    const int64_t nvec = (nbytes - h) / 16;
+    uint4* v = (uint4*)(p + h);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) v[i] = z;
+    if (blockIdx.x == 0) {
+        const int64_t tail0 = h + nvec * 16;
+        for (int64_t i = threadIdx.x; i < h; i += blockDim.x) p[i] = 0;
+        for (int64_t i = tail0 + threadIdx.x; i < nbytes; i += blockDim.x) p[i] = 0;
+    }
+}
+
+extern "C" int cn_zero(void* p, int64_t nbytes, void* stream) {
+    CN_CHECK_ARG(p && nbytes > 0, "cn_zero: bad args");
+    int64_t g = (nbytes / 16 + 255) / 256;
+    int grid = (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, nbytes);
+    CN_LAUNCH_CHECK("cn_zero");
+    return CN_OK;
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

@@ -53,7 +53,10 @@ class FlatAdam(torch.optim.Optimizer):
         self._lr_dev = None
 
     def zero_grad(self, set_to_none=False):
-        self.flat_g.zero_()
+        if self.flat_g.is_cuda:
+            ops.call("cn_zero", self.flat_g, self.flat_g.numel() * 4)      # no ATen fill inside the (captured) step
+        else:
+            self.flat_g.zero_()
         for p, o in zip(self.params, self.offsets):   # autograd may have replaced .grad (e.g. after set_to_none elsewhere)
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view_as(p)

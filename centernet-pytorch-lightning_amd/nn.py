@@ -227,7 +227,7 @@ class DCN(nn.Module):
         om = self.conv_offset_mask.infer(x, None, None, None, False, out_dtype=torch.float32)
         Co = self.weight.shape[0]
         cp = ops.rup(Co, 16)
-        y = (torch.empty if cp == Co else torch.zeros)((N, H, W, cp), dtype=x.dtype, device=x.device)
+        y = torch.empty((N, H, W, cp), dtype=x.dtype, device=x.device) if cp == Co else ops.zeros((N, H, W, cp), x.dtype, x.device)
         ops.call("cn_dcn_fwd", x, om, self._cache["wp"], self._cache["b"], y, N, H, W, Ci, Ci, Co, cp, om.shape[-1], int(relu),
                  ops.dtype_code(x.dtype))
         return y

@@ -32,6 +32,20 @@ class WeightsEpoch:
         cls.value += 1
 
 
+def zeros(shape, dtype, device):
+    """torch.zeros on the device without an ATen launch: torch.empty + cn_zero on the current stream (CPU tensors: torch.zeros)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if not t.is_cuda:
+        return t.zero_()
+    if t.numel():
+        call("cn_zero", t, t.numel() * t.element_size())
+    return t
+
+
+def zeros_like(t, dtype=None):
+    return zeros(t.shape, dtype or t.dtype, t.device)
+
+
 def _empty_like_shape(x, shape):
     return torch.empty(shape, dtype=x.dtype, device=x.device)
 
@@ -264,7 +278,7 @@ class ShareFn(Function):
         if ctx.cell.sparse:
             fns, ctx.cell.sparse = ctx.cell.sparse, []
             if total is None:
-                total = torch.zeros(ctx.meta[0], dtype=ctx.meta[1], device=ctx.meta[2])
+                total = zeros(ctx.meta[0], ctx.meta[1], ctx.meta[2])
             elif total is g:
                 total = g.clone()                 # autograd's tensor is not ours to modify
             for fn in fns:
@@ -486,8 +500,8 @@ def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=None):
     `db_into`: fp32[Co] buffer the bias gradient is ACCUMULATED into (e.g. bias.grad)."""
     N, H, W, Ci = x.shape
     _, OH, OW, ld = dy.shape
-    dwp = torch.zeros((rup(Co, 32), KH * KW * Ci), dtype=torch.float32, device=x.device)
-    db = db_into if db_into is not None else (torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None)
+    dwp = zeros((rup(Co, 32), KH * KW * Ci), torch.float32, x.device)
+    db = db_into if db_into is not None else (zeros((Co,), torch.float32, x.device) if want_bias else None)
     call("cn_conv2d_wgrad", x, dy, dwp, db, N, H, W, Ci, Ci, OH, OW, Co, ld, KH, KW, stride, pad, dtype_code(x.dtype))
     return dwp, db
 
@@ -504,7 +518,7 @@ def _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=None, want_bias=False,
         if n:
             ws = _hip.workspace(n, x.device, "wgrad_slabs")
             dw = into if into is not None else torch.empty((Co, Ci, KH, KW), dtype=torch.float32, device=x.device)
-            db = db_into if db_into is not None else (torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None)
+            db = db_into if db_into is not None else (zeros((Co,), torch.float32, x.device) if want_bias else None)
             call("cn_conv2d_wgrad_direct", x, dy, dw, db, int(into is not None), ws, n, N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW,
                  stride, pad, dt)
             return dw, db
@@ -658,7 +672,7 @@ class Conv1x1CatFn(Function):
         if ctx.needs_input_grad[0]:
             side = SideGrads.usable(weight)
             if not side:
-                dw = torch.zeros((Co, Ct), dtype=torch.float32, device=dy.device)
+                dw = zeros((Co, Ct), torch.float32, dy.device)
 
             def wgrads(into):
                 for x, c, k0 in zip(xs, chans, offs):
@@ -769,7 +783,7 @@ class StemConvFn(Function):
                 GradReady.note(weight)
             SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy, claims=(weight,))
             return None, None, None, None, None, None
-        dw = torch.zeros_like(weight, dtype=torch.float32)
+        dw = zeros_like(weight, torch.float32)
         call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))
         return None, dw, None, None, None, None
 
@@ -870,7 +884,7 @@ class ScaleShiftActFn(Function):
             call("cn_relu_bwd", dy, y, g, dy.numel(), dtype_code(dy.dtype))
             dy = g
         dx = torch.empty_like(dy)
-        zero = torch.zeros_like(scale)
+        zero = zeros_like(scale)
         call("cn_scale_shift_act", dy, None, dx, scale, zero, dy.numel() // C, C, 0, dtype_code(dy.dtype))
         return dx, None, None, (dy if has_res else None), None
 
@@ -939,7 +953,7 @@ class DwDeconvFn(Function):
                 GradReady.note(weight)
             SideGrads.submit(side_work, x, dy, claims=(weight,))
         elif ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(weight, dtype=torch.float32)
+            dw = zeros_like(weight, torch.float32)
             call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
         dres = dy if ctx.has_res else None
         if ctx.cells[0] is not None and dx is not None:
@@ -1105,7 +1119,7 @@ class DCNv2Fn(Function):
         else:
             # fused: bilinear sampling writes the MFMA operand tile in LDS, no column tensor
             cp = rup(Co, 16)
-            y = (torch.empty if cp == Co else torch.zeros)((N, H, W, cp), dtype=x.dtype, device=x.device)
+            y = torch.empty((N, H, W, cp), dtype=x.dtype, device=x.device) if cp == Co else zeros((N, H, W, cp), x.dtype, x.device)
             BnStats.launch(bn_stats, y, "cn_dcn_fwd", x, om, wp, bias.detach(), y, N, H, W, Ci, Ci, Co, cp, om.shape[-1], 0, dt)
             col = None
         ctx.save_for_backward(x, om, col, weight, om_weight)
@@ -1126,9 +1140,9 @@ class DCNv2Fn(Function):
         def main_wgrad(db_into, want_bias):
             """dW / db of the deformable conv: fused re-sampling kernel in bf16, im2col + GEMM in fp32 parity mode"""
             if x.dtype == torch.bfloat16 and not _DCN_UNFUSED:
-                dwp_ = torch.zeros((rup(Co, 32), 9 * Ci), dtype=torch.float32, device=x.device)
+                dwp_ = zeros((rup(Co, 32), 9 * Ci), torch.float32, x.device)
                 call("cn_dcn_wgrad", x, om, dy, dwp_, N, H, W, Ci, Ci, Co, dy.shape[-1], om.shape[-1], dt)
-                db_ = db_into if db_into is not None else (torch.zeros((Co,), dtype=torch.float32, device=x.device) if want_bias else None)
+                db_ = db_into if db_into is not None else (zeros((Co,), torch.float32, x.device) if want_bias else None)
                 if db_ is not None:
                     call("cn_colsum", dy, db_, N * H * W, Co, dy.shape[-1], dt)
                 return dwp_, db_
@@ -1149,8 +1163,8 @@ class DCNv2Fn(Function):
             dw = unpack_wgrad(dwp, Co, Ci, 3, 3)
         dx_s = torch.empty_like(x)
         if _DCN_UNFUSED:
-            dx_far = torch.zeros((N, H, W, Ci), dtype=torch.float32, device=x.device)
-            dom32 = torch.zeros_like(om)
+            dx_far = zeros((N, H, W, Ci), torch.float32, x.device)
+            dom32 = zeros_like(om)
             # reference pipeline kept for A/B profiling: materialise dcol, then source + gather kernels
             wpd = pack_weight(weight, 2, x.dtype)                 # [9*Ci][Co]
             dcol = _igemm(dy, wpd, None, None, 9 * Ci, 1, 1, 1, 0, False, False, H, W)
@@ -1166,7 +1180,7 @@ class DCNv2Fn(Function):
             # dx_far (samples displaced > 3 px: rare) follows the lazy protocol of the header: one persistent all-zero
             # buffer per shape + a per-call flag, instead of clearing and re-reading 4*P*Ci bytes per layer per step
             dx_far = _far_buffer((N, H, W, Ci), x.device)
-            far_flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+            far_flag = zeros((1,), torch.int32, x.device)
             slabs = _hip.query("cn_dcn_bwd_dom_slabs", int(Ci), int(dy.shape[-1]), dt)
             direct = (x.dtype == torch.bfloat16 and Ci == 64 and slabs == 1 and dy.shape[-1] in (64, 128)
                       and not _os.environ.get("CN_DISABLE_DOM_TILE"))
@@ -1177,7 +1191,7 @@ class DCNv2Fn(Function):
                 # tile kernel: one fp32 copy of dom per 64-channel block of x, plain stores (no atomics, nothing to clear)
                 dom32 = torch.empty((slabs,) + tuple(om.shape), dtype=torch.float32, device=x.device)
             else:
-                slabs, dom32 = 1, torch.zeros_like(om)
+                slabs, dom32 = 1, zeros_like(om)
             call("cn_dcn_bwd_dom", dy, pack_weight(weight, 2, x.dtype), x, om, dom32, slabs, dx_far, far_flag, N, H, W, Ci, Co,
                  dy.shape[-1], Ci, om.shape[-1], dt)
             call("cn_dcn_bwd_dx", dy, pack_weight(weight, 0, x.dtype), om, dx_far, far_flag, dx_s, N, H, W, Ci,
@@ -1467,7 +1481,7 @@ class HeadFn(Function):
             if ctx.cell is not None:
                 ctx.cell.sparse.append(scatter)       # applied to the finished sum of x's consumers (ShareFn.backward)
             else:
-                dx = torch.zeros_like(x)
+                dx = zeros_like(x)
                 scatter(dx)
         return dx, dw1, db1, dw2, db2
 
@@ -1495,7 +1509,7 @@ class GatherL1Fn(Function):
     def backward(ctx, g):
         feat, ind, mask8, target, out = ctx.saved_tensors
         B, C = feat.shape[:2]
-        dfeat = torch.zeros_like(feat)
+        dfeat = zeros_like(feat)
         call("cn_gather_l1_bwd", feat, ind, mask8, target, out, g.contiguous().float().reshape(1), dfeat, B, C,
              feat[0, 0].numel(), ind.shape[1], ctx.has_c)
         SparseRows.note(dfeat, ind)       # zero outside ind[b, :]: a HeadFn behind `feat` works on those rows only

@@ -42,6 +42,10 @@ int cn_copy_channels(const void* src, int src_ld, int src_off, void* dst, int ds
                      int64_t npix, int nch, int dtype, void* stream);
 /* out = a + b (pose_dla_dcn.py:488 `layers[i] + layers[i-1]`); accumulate: out += a */
 int cn_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
+/* p[0 .. nbytes) = 0 (any alignment).  Replaces the ATen fills (`torch.zeros`, `.zero_()`) in front of the split-K weight-gradient
+ * accumulators, the DCN far-sample buffers and the flat gradient buffer (engine.FlatAdam.zero_grad): same position in the stream,
+ * so the accumulator is still L2-resident for the atomics that follow, but the step holds no at::native launch. */
+int cn_zero(void* p, int64_t nbytes, void* stream);
 int cn_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
 /* ---- dense convolution engine (replaces nn.Conv2d / nn.ConvTranspose2d + their backward) -- */

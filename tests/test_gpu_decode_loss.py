@@ -414,18 +414,25 @@ def test_fused_sigmoid_focal_matches_two_step():
     ya = sigmoid_clamped(xa)
     la = FocalLoss()(ya, gt)
     (3.0 * la).backward()
+    from centernet_amd import ops
     b = logits.to(DEV).requires_grad_(True)
     xb = b.clone()
-    yb, lb = FocalLoss().on_logits(xb, gt)
-    (3.0 * lb).backward()
+    xb._cn_head_dtype = torch.bfloat16       # what models/heads.py tags a bf16 HeadFn's map with: only then is the second layout written
+    noted = []
+    ops.DualLayout.note = classmethod(lambda cls, t, alt: noted.append((t, alt)))
+    try:
+        yb, lb = FocalLoss().on_logits(xb, gt)
+        (3.0 * lb).backward()
+    finally:
+        del ops.DualLayout.note              # back to the inherited SparseRows.note
     assert torch.equal(ya, yb) and torch.equal(xa, xb), "clamped copy and in-place sigmoid"
     assert la.item() == lb.item()
     assert float((yb == 1e-4).float().mean()) > 0.01 and float((yb == 1 - 1e-4).float().mean()) > 1e-4
     assert torch.equal(a.grad, b.grad), "single-pass backward is bit-identical to the two kernels"
     # the backward also left d loss / d logits as NHWC bf16 for a head's backward (ops.DualLayout): exactly the layout change of dz
-    from centernet_amd import ops
     from centernet_amd._hip import call, CN_BF16
-    dz, _, alt = ops.DualLayout.entries.pop()
+    (dz, alt), = noted
+    assert not ops.DualLayout.entries and not ops.SparseRows.entries      # nothing stays pinned after a backward pass
     ref = torch.empty_like(alt)
     call("cn_nchw_to_nhwc", dz, ref, 2, 80, 128, 128, 80, CN_BF16)
     assert alt.dtype == torch.bfloat16 and tuple(alt.shape) == (2, 128, 128, 80) and torch.equal(alt, ref)
