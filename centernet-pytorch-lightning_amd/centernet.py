@@ -57,6 +57,21 @@ class CenterNet(_Base):
         y = sigmoid_clamped(x)
         return y, criterion(y, target)
 
+    @staticmethod
+    def _sum_terms(ts):
+        from . import ops
+        return ops.weighted_sum(ts, [1.0] * len(ts))
+
+    @staticmethod
+    def _weighted_total(groups, weights, num_stacks):
+        """sum_g weights[g] * sum(groups[g]) / num_stacks as one device launch (<= 8 terms), else in chunks"""
+        from . import ops
+        ts = [t for g in groups for t in g]
+        ws = [w / num_stacks for g, w in zip(groups, weights) for _ in g]
+        while len(ts) > 8:
+            ts, ws = [ops.weighted_sum(ts[:8], ws[:8])] + ts[8:], [1.0] + ws[8:]
+        return ops.weighted_sum(ts, ws)
+
     @property
     def compute_dtype(self):
         return self.backbone.compute_dtype

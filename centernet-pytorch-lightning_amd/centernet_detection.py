@@ -40,17 +40,20 @@ class CenterNetDetection(CenterNet):
         return [head(out) for head, out in zip(self.heads, self.backbone(x))]
 
     def loss(self, outputs, target):
-        hm_loss, wh_loss, off_loss = 0, 0, 0
+        hm, wh, off = [], [], []
         num_stacks = len(outputs)
         for output in outputs:
-            output["heatmap"], hm = self._sigmoid_focal(self.criterion, output["heatmap"], target["heatmap"])
-            hm_loss = hm_loss + hm
-            wh_loss = wh_loss + self.criterion_width_height(output["width_height"], target["regression_mask"],
-                                                            target["indices"], target["width_height"])
-            off_loss = off_loss + self.criterion_regression(output["regression"], target["regression_mask"],
-                                                            target["indices"], target["regression"])
-        loss = (self.hparams.hm_weight * hm_loss + self.hparams.wh_weight * wh_loss
-                + self.hparams.off_weight * off_loss) / num_stacks
+            output["heatmap"], t = self._sigmoid_focal(self.criterion, output["heatmap"], target["heatmap"])
+            hm.append(t)
+            wh.append(self.criterion_width_height(output["width_height"], target["regression_mask"], target["indices"],
+                                                  target["width_height"]))
+            off.append(self.criterion_regression(output["regression"], target["regression_mask"], target["indices"],
+                                                 target["regression"]))
+        # centernet_detection.py:108-116: per-term sums over the stacks, then the weighted total / num_stacks — one launch
+        # (ops.weighted_sum) instead of a dozen scalar ATen kernels; with one stack a term's sum IS the term
+        h = self.hparams
+        hm_loss, wh_loss, off_loss = (ts[0] if num_stacks == 1 else self._sum_terms(ts) for ts in (hm, wh, off))
+        loss = self._weighted_total([hm, wh, off], [h.hm_weight, h.wh_weight, h.off_weight], num_stacks)
         return loss, {"loss": loss, "hm_loss": hm_loss, "wh_loss": wh_loss, "off_loss": off_loss}
 
     @torch.no_grad()

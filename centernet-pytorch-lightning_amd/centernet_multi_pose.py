@@ -38,26 +38,27 @@ class CenterNetMultiPose(CenterNet):
         return [head(out) for head, out in zip(self.heads, self.backbone(x))]
 
     def loss(self, outputs, target):
-        hm_loss = wh_loss = off_loss = kp_loss = hm_kp_loss = hm_offset_loss = 0
+        hm, wh, off, kp, hm_kp, hm_off = [], [], [], [], [], []
         num_stacks = len(outputs)
         for output in outputs:
-            output["heatmap"], hm = self._sigmoid_focal(self.criterion, output["heatmap"], target["heatmap"])
-            output["heatmap_keypoints"], hm_kp = self._sigmoid_focal(self.criterion_heatmap_keypoints, output["heatmap_keypoints"],
-                                                                     target["heatmap_keypoints"])
-            hm_loss = hm_loss + hm
-            wh_loss = wh_loss + self.criterion_width_height(output["width_height"], target["regression_mask"],
-                                                            target["indices"], target["width_height"])
-            off_loss = off_loss + self.criterion_regression(output["regression"], target["regression_mask"],
-                                                            target["indices"], target["regression"])
-            kp_loss = kp_loss + self.criterion_keypoints(output["keypoints"], target["keypoints_mask"], target["indices"],
-                                                         target["keypoints"])
-            hm_kp_loss = hm_kp_loss + hm_kp
-            hm_offset_loss = hm_offset_loss + self.criterion_regression(
-                output["heatmap_keypoints_offset"], target["heatmap_keypoints_mask"], target["heatmap_keypoints_indices"],
-                target["heatmap_keypoints_offset"])
+            output["heatmap"], t = self._sigmoid_focal(self.criterion, output["heatmap"], target["heatmap"])
+            output["heatmap_keypoints"], t_kp = self._sigmoid_focal(self.criterion_heatmap_keypoints, output["heatmap_keypoints"],
+                                                                    target["heatmap_keypoints"])
+            hm.append(t)
+            wh.append(self.criterion_width_height(output["width_height"], target["regression_mask"], target["indices"],
+                                                  target["width_height"]))
+            off.append(self.criterion_regression(output["regression"], target["regression_mask"], target["indices"],
+                                                 target["regression"]))
+            kp.append(self.criterion_keypoints(output["keypoints"], target["keypoints_mask"], target["indices"], target["keypoints"]))
+            hm_kp.append(t_kp)
+            hm_off.append(self.criterion_regression(output["heatmap_keypoints_offset"], target["heatmap_keypoints_mask"],
+                                                    target["heatmap_keypoints_indices"], target["heatmap_keypoints_offset"]))
         h = self.hparams
-        loss = (h.hm_weight * hm_loss + h.wh_weight * wh_loss + h.off_weight * off_loss + h.hp_weight * kp_loss
-                + h.hm_hp_weight * hm_kp_loss + h.off_weight * hm_offset_loss) / num_stacks
+        groups = [hm, wh, off, kp, hm_kp, hm_off]
+        hm_loss, wh_loss, off_loss, kp_loss, hm_kp_loss, hm_offset_loss = (
+            ts[0] if num_stacks == 1 else self._sum_terms(ts) for ts in groups)
+        # centernet_multi_pose.py:126-140: the weighted total / num_stacks, one launch (ops.weighted_sum)
+        loss = self._weighted_total(groups, [h.hm_weight, h.wh_weight, h.off_weight, h.hp_weight, h.hm_hp_weight, h.off_weight], num_stacks)
         return loss, {"loss": loss, "hm_loss": hm_loss, "kp_loss": kp_loss, "hm_kp_loss": hm_kp_loss,
                       "hm_offset_loss": hm_offset_loss, "wh_loss": wh_loss, "off_loss": off_loss}
 

@@ -498,3 +498,36 @@ extern "C" int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uin
     CN_LAUNCH_CHECK("cn_gather_l1_bwd");
     return CN_OK;
 }
+
+// ---- loss assembly (centernet_detection.py:108-116, centernet_multi_pose.py:126-140): total = sum_i w_i * term_i over <= 8 scalar
+// loss terms, and its backward d term_i = w_i * g, one single-thread launch each (the reference leaves this to ~16 ATen scalar
+// kernels per step, launched at the forward / backward seam where nothing overlaps them) ----
+struct WsumArgs { const float* t[8]; float w[8]; };
+__global__ void weighted_sum_kernel(WsumArgs a, int n, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += a.w[i] * a.t[i][0];
+    out[0] = s;
+}
+__global__ void weighted_sum_bwd_kernel(WsumArgs a, int n, const float* __restrict__ g, float* __restrict__ out) {
+    if ((int)threadIdx.x < n) out[threadIdx.x] = a.w[threadIdx.x] * g[0];
+}
+
+extern "C" int cn_weighted_sum(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4, const float* t5,
+                               const float* t6, const float* t7, float w0, float w1, float w2, float w3, float w4, float w5, float w6,
+                               float w7, int n, float* out, void* stream) {
+    CN_CHECK_ARG(n >= 1 && n <= 8 && out, "cn_weighted_sum: 1 <= n <= 8 terms");
+    WsumArgs a = {{t0, t1, t2, t3, t4, t5, t6, t7}, {w0, w1, w2, w3, w4, w5, w6, w7}};
+    for (int i = 0; i < n; ++i) CN_CHECK_ARG(a.t[i] != nullptr, "cn_weighted_sum: term %d is null", i);
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, a, n, out);
+    CN_LAUNCH_CHECK("cn_weighted_sum");
+    return CN_OK;
+}
+
+extern "C" int cn_weighted_sum_bwd(const float* g, float w0, float w1, float w2, float w3, float w4, float w5, float w6, float w7,
+                                   int n, float* out, void* stream) {
+    CN_CHECK_ARG(n >= 1 && n <= 8 && out && g, "cn_weighted_sum_bwd: bad args");
+    WsumArgs a = {{nullptr}, {w0, w1, w2, w3, w4, w5, w6, w7}};
+    hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, n, g, out);
+    CN_LAUNCH_CHECK("cn_weighted_sum_bwd");
+    return CN_OK;
+}

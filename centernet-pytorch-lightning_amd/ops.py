@@ -1495,7 +1495,8 @@ class GatherL1Fn(Function):
         B, C = feat.shape[:2]
         HW = feat[0, 0].numel()
         N = ind.shape[1]
-        mask8 = mask.contiguous().to(torch.uint8)
+        mask8 = mask.contiguous()
+        mask8 = mask8.view(torch.uint8) if mask8.dtype == torch.bool else mask8.to(torch.uint8)    # bool is one byte: no copy kernel
         has_c = int(mask.dim() == 3)
         ind = ind.contiguous().long()
         target = target.contiguous().float()
@@ -1514,6 +1515,45 @@ class GatherL1Fn(Function):
              feat[0, 0].numel(), ind.shape[1], ctx.has_c)
         SparseRows.note(dfeat, ind)       # zero outside ind[b, :]: a HeadFn behind `feat` works on those rows only
         return dfeat, None, None, None
+
+
+class WeightedSumFn(Function):
+    """total = sum_i w_i * term_i over scalar loss terms: ONE launch forward and ONE backward (cn_weighted_sum) instead of the ~16
+    ATen scalar kernels of `hm_weight * hm_loss + wh_weight * wh_loss + ...` (centernet_detection.py:108-116), which sit at the
+    forward / backward seam of a step where nothing overlaps them."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ctx.weights = tuple(float(w) for w in weights)
+        n = len(terms)
+        out = torch.empty((), dtype=torch.float32, device=terms[0].device)
+        pad = [None] * (8 - n)
+        call("cn_weighted_sum", *terms, *pad, *ctx.weights, *([0.0] * (8 - n)), n, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.weights)
+        out = torch.empty((8,), dtype=torch.float32, device=g.device)
+        call("cn_weighted_sum_bwd", g.contiguous().float(), *ctx.weights, *([0.0] * (8 - n)), n, out)
+        return (None,) + tuple(out[i] for i in range(n))
+
+
+def weighted_sum(terms, weights):
+    """sum_i weights[i] * terms[i] for scalar tensors (python numbers among the terms are folded on the host)"""
+    ts, ws, const = [], [], 0.0
+    for t, w in zip(terms, weights):
+        if isinstance(t, torch.Tensor):
+            ts.append(t); ws.append(w)
+        else:
+            const += float(t) * float(w)
+    dev_ok = (0 < len(ts) <= 8 and all(t.is_cuda and t.dim() == 0 and t.dtype == torch.float32 for t in ts))
+    if not dev_ok or const != 0.0:
+        tot = const
+        for t, w in zip(ts, ws):
+            tot = tot + w * t
+        return tot
+    return WeightedSumFn.apply(tuple(ws), *ts)
 
 
 # ------------------------------------------------------------------------------------------------ functional aliases

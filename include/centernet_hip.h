@@ -308,6 +308,13 @@ int cn_gather_l1_fwd(const float* feat, const int64_t* ind, const uint8_t* mask,
 int cn_gather_l1_bwd(const float* feat, const int64_t* ind, const uint8_t* mask, const float* target,
                      const float* out3, const float* gout, float* dfeat,
                      int B, int C, int64_t HW, int N, int mask_has_c, void* stream);
+/* loss assembly (centernet_detection.py:108-116 `hm_weight * hm_loss + wh_weight * wh_loss + off_weight * off_loss`;
+ * centernet_multi_pose.py:126-140): out[0] = sum_{i<n} w_i * t_i[0] over n <= 8 scalar terms; backward out[i] = w_i * g[0]. */
+int cn_weighted_sum(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4, const float* t5,
+                    const float* t6, const float* t7, float w0, float w1, float w2, float w3, float w4, float w5, float w6,
+                    float w7, int n, float* out, void* stream);
+int cn_weighted_sum_bwd(const float* g, float w0, float w1, float w2, float w3, float w4, float w5, float w6, float w7,
+                        int n, float* out, void* stream);
 
 /* ---- backward of a head whose loss gathers its output at `ind` (heads.py:4-25 under RegL1Loss / RegWeightedL1Loss,
  * utils/losses.py:53-63, 81-91): the output gradient is zero except at ind[b, :], so autograd's dense conv1x1 <- ReLU <- conv3x3

@@ -14,9 +14,13 @@ torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
     step((x, t)); torch.cuda.synchronize()
-c = collections.Counter(); tm = collections.Counter()
-for e in prof.events():
-    if e.name in ("aten::add", "aten::add_", "aten::fill_", "aten::zero_", "aten::copy_", "aten::cat", "aten::mul", "aten::sum", "aten::clone", "aten::contiguous"):
-        k = (e.name, str(e.input_shapes)[:90]); c[k] += 1; tm[k] += e.device_time_total
-for k, n in sorted(c.items(), key=lambda kv: -tm[kv[0]])[:40]:
-    print(f"{tm[k]:9.0f} us {n:4d}  {k[0]:14s} {k[1]}")
+rows = [a for a in prof.key_averages(group_by_input_shape=True) if a.key.startswith("aten::") and a.self_device_time_total > 0]
+for a in sorted(rows, key=lambda a: -a.self_device_time_total)[:60]:
+    print(f"{a.self_device_time_total:9.0f} us {a.count:4d}  {a.key:22s} {str(a.input_shapes)[:100]}")
+# where they come from: python stacks of the aten ops that launch device work themselves
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step((x, t)); torch.cuda.synchronize()
+rows = [a for a in prof.key_averages(group_by_stack_n=12) if a.key.startswith("aten::") and a.self_device_time_total > 0]
+for a in sorted(rows, key=lambda a: -a.count)[:70]:
+    st = [f.split("/")[-1] for f in a.stack if ("centernet" in f or "engine" in f or "bench" in f)]
+    print(f"{a.count:4d} {a.self_device_time_total:8.0f} us {a.key:20s} " + " <- ".join(st[:4]))
