@@ -438,6 +438,9 @@ def main():
                     help="NOT the headline: hand the step pinned HOST buffers (image, or image + dense targets like the reference's "
                          "dataloader) so that the PCIe copy is inside the timed region; DESIGN.md quotes these rates")
     ap.add_argument("--no-prefetch", action="store_true", help="with --host-input: copy on the launch stream (no HostFeed overlap)")
+    ap.add_argument("--stamps", action="store_true",
+                    help="capture four device wall-clock stamps (cn_stamp) into the step's graph: where the launch-stream chain and the "
+                         "weight-gradient stream end in a REPLAYED step, no profiler attached -> `stream_tail` in the line")
     ap.add_argument("--probe-steps", type=int, default=2)
     ap.add_argument("--probe-detail", default=None, help="write a per-shape table of every launch of a step to this file")
     args = ap.parse_args()
@@ -491,6 +494,9 @@ def main():
 
     # decode overlaps backward; the resident synthetic batch IS the graph's static input (no per-step device-to-device copy of
     # inputs that are already in HBM — with --host-input the copy is host -> device and stays in the timed region)
+    if args.stamps:
+        import centernet_amd.ops as _ops
+        _ops.SideGrads.stamps = torch.zeros(4, dtype=torch.int64, device=dev)
     step = TrainStep(model, lr=1e-4, graph=not args.no_graph, post_forward=decode, adopt_batch=args.host_input == "none")
     side_grid = int(__import__("centernet_amd.ops", fromlist=["SideGrads"]).SideGrads.thin)      # what the timed steps and the probe run with
 
@@ -536,6 +542,13 @@ def main():
                       "per_rank_images_per_s": [round(args.batch * args.steps / float(e.item()), 2) for e in every]}
     det = step.post_out
     assert det.shape == (args.batch, 100, 6) and bool(torch.isfinite(det).all())
+    stream_tail = None
+    if args.stamps:
+        st_ = _ops.SideGrads.stamps.cpu().tolist()           # the LAST timed step's stamps (10 ns ticks)
+        _ops.SideGrads.stamps = None
+        stream_tail = {"launch_stream_done_ms": round((st_[1] - st_[0]) / 1e5, 3), "weight_gradient_stream_done_ms": round((st_[2] - st_[0]) / 1e5, 3),
+                       "joined_ms": round((st_[3] - st_[0]) / 1e5, 3),
+                       "what": "device wall clock (cn_stamp) inside the last replayed step, from the step's first launch; the optimizer graph follows the join"}
 
     probe = None
     tn = "bf16" if dt == torch.bfloat16 else "f32"
@@ -717,6 +730,8 @@ def main():
                 "cpu_baseline": None}
         if ranks_info:
             line["ranks"] = ranks_info
+        if stream_tail:
+            line["stream_tail"] = stream_tail
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(full=args.cpu_baseline_full)

@@ -141,7 +141,8 @@ extern "C" int cn_add(const void* a, const void* b, void* out, int64_t n, int dt
 }
 
 // zero a buffer: 16-byte stores over the aligned body, byte stores for the ragged head / tail (any pointer, any size)
-__global__ __launch_bounds__(256) void zero_kernel(unsigned char* __restrict__ p, int64_t nbytes) {
+__global__ __launch_bounds__(256) void zero_kernel(unsigned char* __restrict__ p, int64_t nbytes, long long* stamp) {
+    if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = (long long)wall_clock64();       // measurement aid (cn_zero_stamps)
     const int64_t head = (int64_t)((16 - ((uintptr_t)p & 15)) & 15);
     const int64_t h = head < nbytes ? head : nbytes;
     const int64_t nvec = (nbytes - h) / 16;
@@ -155,12 +156,33 @@ __global__ __launch_bounds__(256) void zero_kernel(unsigned char* __restrict__ p
     }
 }
 
+// measurement aid: while a buffer is registered, the k-th cn_zero launch (host order, i.e. capture order) also stores the device wall
+// clock at which it starts into buf[k] — a timeline of both streams of a replayed step without adding a single graph node
+static long long* zero_stamp_buf = nullptr;
+static int zero_stamp_n = 0, zero_stamp_i = 0;
+extern "C" int cn_zero_stamps(int64_t* buf, int n) {
+    zero_stamp_buf = (long long*)buf; zero_stamp_n = buf ? n : 0; zero_stamp_i = 0;
+    return CN_OK;
+}
+extern "C" int cn_zero_stamps_used(void) { return zero_stamp_i; }
+
 extern "C" int cn_zero(void* p, int64_t nbytes, void* stream) {
     CN_CHECK_ARG(p && nbytes > 0, "cn_zero: bad args");
     int64_t g = (nbytes / 16 + 255) / 256;
     int grid = (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
-    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, nbytes);
+    long long* stamp = (zero_stamp_buf && zero_stamp_i < zero_stamp_n) ? zero_stamp_buf + zero_stamp_i++ : nullptr;
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, nbytes, stamp);
     CN_LAUNCH_CHECK("cn_zero");
+    return CN_OK;
+}
+
+// measurement aid: the constant-rate (100 MHz) wall clock at the moment this one-thread kernel runs on its stream, e.g. where the
+// launch stream and the weight-gradient stream end inside a REPLAYED hipGraph (the profiler's per-kernel overhead distorts that)
+__global__ void stamp_kernel(long long* dst) { *dst = (long long)wall_clock64(); }
+extern "C" int cn_stamp(int64_t* dst, void* stream) {
+    CN_CHECK_ARG(dst, "cn_stamp: null pointer");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (long long*)dst);
+    CN_LAUNCH_CHECK("cn_stamp");
     return CN_OK;
 }
 

@@ -53,6 +53,8 @@ class FlatAdam(torch.optim.Optimizer):
         self._lr_dev = None
 
     def zero_grad(self, set_to_none=False):
+        if self.flat_g.is_cuda and SideGrads.stamps is not None and not os.environ.get("CN_STAMP_END_ONLY"):
+            ops.call("cn_stamp", SideGrads.stamps)
         if self.flat_g.is_cuda:
             ops.call("cn_zero", self.flat_g, self.flat_g.numel() * 4)      # no ATen fill inside the (captured) step
         else:

@@ -466,13 +466,21 @@ class SideGrads:
             with torch.cuda.stream(st):
                 fn()
 
+    stamps = None         # int64[4] device tensor (tools/tail_stamps.py): [step start, launch-stream end, side-stream end, joined]
+
     @classmethod
     def join(cls):
         if cls.stream is not None:
             cls._flush()
         if cls.active and cls.stream is not None:
+            if cls.stamps is not None:
+                call("cn_stamp", cls.stamps[1:])
+                with torch.cuda.stream(cls.stream):
+                    call("cn_stamp", cls.stamps[2:])
             for st in cls.all_streams():
                 torch.cuda.current_stream().wait_stream(st)
+            if cls.stamps is not None and not _os.environ.get("CN_STAMP_END_ONLY"):
+                call("cn_stamp", cls.stamps[3:])
         cls.active = False
         cls.rr = 0
 

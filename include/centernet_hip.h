@@ -46,6 +46,11 @@ int cn_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* 
  * accumulators, the DCN far-sample buffers and the flat gradient buffer (engine.FlatAdam.zero_grad): same position in the stream,
  * so the accumulator is still L2-resident for the atomics that follow, but the step holds no at::native launch. */
 int cn_zero(void* p, int64_t nbytes, void* stream);
+/* measurement aid (tools/tail_stamps.py): *dst = the device's constant-rate wall clock (100 MHz ticks) when this launch runs */
+int cn_stamp(int64_t* dst, void* stream);
+/* measurement aid: while buf != NULL the k-th cn_zero launch (host order) also stores the wall clock at which it starts in buf[k] */
+int cn_zero_stamps(int64_t* buf, int n);
+int cn_zero_stamps_used(void);
 int cn_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
 /* ---- dense convolution engine (replaces nn.Conv2d / nn.ConvTranspose2d + their backward) -- */

@@ -63,6 +63,16 @@ for k in range(nst, 0, -1):
         print("  by kernel class (names; a replayed graph has no stream ids):")
         for k, (s, e, run, n) in sorted(per.items(), key=lambda kv: kv[1][1]):
             print(f"    {k:26s} {n:4d} kernels, kernel time {run / 1e6:7.3f} ms, first start +{(s - t0) / 1e6:7.3f} ms, last end +{(e - t0) / 1e6:7.3f} ms ({(e - t1) / 1e6:+.3f} vs step end)")
+        # hardware queues: which kernel classes share a queue (kernels of one queue run strictly one after the other)
+        perq = {}
+        for n, s, e, st, q in seg:
+            d = perq.setdefault(q, {})
+            c_ = d.setdefault(cls(n), [0, 0, s, e])
+            c_[0] += 1; c_[1] += e - s; c_[2] = min(c_[2], s); c_[3] = max(c_[3], e)
+        print("  hardware queues (kernel class: launches, kernel time, first start .. last end):")
+        for q, d in sorted(perq.items()):
+            for k, (n, run, s, e) in sorted(d.items(), key=lambda kv: -kv[1][1]):
+                print(f"    queue {q}: {k:26s} {n:4d} kernels {run / 1e6:7.3f} ms   +{(s - t0) / 1e6:7.3f} .. +{(e - t0) / 1e6:7.3f} ms")
         # how long does each class run with nothing of the OTHER main class in flight?
         marks = sorted([(s, 1, cls(n)) for n, s, e, st, q in seg] + [(e, -1, cls(n)) for n, s, e, st, q in seg])
         depth, last, alone = {}, t0, {}
@@ -74,6 +84,12 @@ for k in range(nst, 0, -1):
         print("  time by the set of classes in flight:")
         for live, t in sorted(alone.items(), key=lambda kv: -kv[1])[:8]:
             print(f"    {t / 1e6:7.3f} ms  {' + '.join(live) if live else '(idle)'}")
+        import os
+        dump = os.environ.get("REPLAY_DUMP")
+        if dump:
+            with open(dump, "w") as f:
+                for n, s, e, st, q in seg:
+                    f.write(f"{(s - t0) / 1e3:10.1f} us  +{(e - s) / 1e3:8.1f}  q{q}  {short(n)}\n")
         foreign = {}
         for n, s, e, st, q in seg:
             if "at::native" in n or "rocclr" in n or n.startswith("void at::"):
