@@ -93,3 +93,43 @@ class CenterNetDetection(CenterNet):
         dets = [self.decode(o) for o in outputs]
         rows, counts = post.ctdet_merge(dets, metas, self.num_classes, self.down_ratio, self.test_max_per_image)
         return list(zip(image_id, post.results_by_class(rows, counts, self.num_classes)))
+
+    def coco_rows(self, detections):
+        """The aggregation half of test_epoch_end (centernet_detection.py:231-249): [(image_id, {class: [n, 5] x1 y1 x2 y2 score})]
+        -> one float64 array [M, 7] = image id, x, y, w, h, score, COCO category id (`valid_ids`), the `loadRes` input format.
+        The per-class boxes are NOT modified in place (the reference rewrites x2 / y2 of its inputs)."""
+        import numpy as np
+        data = []
+        for image_id, detection in detections:
+            for class_index, box in detection.items():
+                box = np.asarray(box, dtype=np.float64)
+                if box.shape[0] == 0:
+                    continue
+                out = np.empty((box.shape[0], 7), dtype=np.float64)
+                out[:, 0] = image_id
+                out[:, 1:3] = box[:, 0:2]
+                out[:, 3] = box[:, 2] - box[:, 0]
+                out[:, 4] = box[:, 3] - box[:, 1]
+                out[:, 5] = box[:, 4]
+                out[:, 6] = self.valid_ids[class_index - 1]
+                data.append(out)
+        return np.concatenate(data, axis=0) if data else np.zeros((0, 7), dtype=np.float64)
+
+    def test_epoch_end(self, detections):
+        """centernet_detection.py:227-265.  Without a COCO ground-truth handle the detections are returned unchanged (the
+        reference's early return); with one, the rows go through `test_coco.loadRes` and pycocotools' COCOeval, and the six AP
+        numbers are logged under the reference's names.  COCOeval itself is outside the hot path (out of
+        scope) and is imported only here."""
+        if not self.test_coco:
+            return detections
+        data = self.coco_rows(detections)
+        coco_detections = self.test_coco.loadRes(data)
+        from pycocotools.cocoeval import COCOeval      # optional dependency, as in the reference
+        coco_eval = COCOeval(self.test_coco, coco_detections, "bbox")
+        coco_eval.evaluate()
+        coco_eval.accumulate()
+        coco_eval.summarize()
+        prefix = ("multi-scale_" if len(self.test_scales) > 1 else "") + ("flip_" if self.test_flip else "")
+        for num, name in enumerate(["ap", "ap_50", "ap_75", "ap_S", "ap_M", "ap_L"]):
+            self.log(f"test/{prefix}{name}", coco_eval.stats[num], sync_dist=True)
+        return data

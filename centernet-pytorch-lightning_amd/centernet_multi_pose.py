@@ -115,3 +115,37 @@ class CenterNetMultiPose(CenterNet):
         rows, counts = post.pose_merge(dets, metas, self.down_ratio, self.test_max_per_image)
         rows, counts = rows.cpu().numpy(), counts.cpu().numpy()
         return [(i, rows[b, :counts[b]].tolist()) for b, i in enumerate(image_id)]
+
+    @staticmethod
+    def coco_annotations(results):
+        """The aggregation half of test_epoch_end (centernet_multi_pose.py:266-296): [(image_id, rows [n][>= 39])] -> the list of COCO
+        keypoint-annotation dicts `loadRes` takes: bbox as x, y, w, h, 17 keypoints as (x, y, 1) triples, category 1."""
+        import numpy as np
+        data = []
+        for image_id, detections in results:
+            for detection in detections:
+                d = np.asarray(detection, dtype=np.float64)
+                bbox = [float(d[0]), float(d[1]), float(d[2] - d[0]), float(d[3] - d[1])]
+                kps = np.concatenate([d[5:39].astype(np.float32).reshape(-1, 2), np.ones((17, 1), dtype=np.float32)], axis=1)
+                data.append({"image_id": int(image_id), "category_id": 1, "bbox": bbox, "score": float(d[4]),
+                             "keypoints": kps.reshape(51).tolist()})
+        return data
+
+    def test_epoch_end(self, results):
+        """centernet_multi_pose.py:266-318: nothing without a COCO handle (the reference's early return); with one, keypoint and box
+        AP through pycocotools' COCOeval (imported only here: out of the hot path's scope), logged under the reference's names."""
+        if not self.test_coco:
+            return None
+        data = self.coco_annotations(results)
+        coco_detections = self.test_coco.loadRes(data)
+        from pycocotools.cocoeval import COCOeval
+        evals = {}
+        for kind, tag in (("keypoints", "kp"), ("bbox", "bbox")):
+            ev = COCOeval(self.test_coco, coco_detections, kind)
+            ev.evaluate(); ev.accumulate(); ev.summarize()
+            evals[tag] = ev
+        prefix = ("multi-scale_" if len(self.test_scales) > 1 else "") + ("flip_" if self.test_flip else "")
+        for tag in ("kp", "bbox"):
+            for num, name in enumerate(["ap", "ap_50", "ap_75", "ap_S", "ap_M", "ap_L"]):
+                self.log(f"test/{tag}_{prefix}{name}", evals[tag].stats[num], sync_dist=True)
+        return data

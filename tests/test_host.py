@@ -366,6 +366,32 @@ def _run_bench(nproc, gpus, port):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
 
 
+def test_test_epoch_end_aggregates_like_the_reference():
+    """test_epoch_end (centernet_detection.py:227-265, centernet_multi_pose.py:266-318): without a COCO handle the reference returns
+    its input / nothing; with one, the per-image per-class boxes become `loadRes` rows [image id, x, y, w, h, score, category id]
+    with the 1-based class index mapped through `valid_ids` (class 12 -> COCO id 13) — checked against hand-computed rows with a
+    stand-in COCO handle that records what it is given (pycocotools' COCOeval itself is outside the hot path)."""
+    import numpy as np
+    from centernet_amd.centernet_detection import CenterNetDetection
+    from centernet_amd.centernet_multi_pose import CenterNetMultiPose
+    m = CenterNetDetection("res_18")
+    dets = [(7, {1: np.array([[10., 20., 30., 60., 0.9]], np.float32), 12: np.array([[1., 2., 4., 8., 0.5], [0., 0., 2., 2., 0.25]], np.float32),
+                 3: np.zeros((0, 5), np.float32)}),
+            (9, {2: np.array([[5., 5., 6., 7., 0.1]], np.float32)})]
+    assert m.test_epoch_end(dets) is dets                                # no test_coco: the reference's early return
+    rows = m.coco_rows(dets)
+    want = np.array([[7, 10, 20, 20, 40, 0.9, 1], [7, 1, 2, 3, 6, 0.5, 13], [7, 0, 0, 2, 2, 0.25, 13], [9, 5, 5, 1, 2, 0.1, 2]], np.float64)
+    assert rows.shape == (4, 7) and np.allclose(rows, want, atol=1e-6)
+    assert dets[0][1][1][0, 2] == 30.0, "inputs are not rewritten in place"
+    assert m.coco_rows([(1, {1: np.zeros((0, 5), np.float32)})]).shape == (0, 7)
+    p = CenterNetMultiPose("res_18")
+    assert p.test_epoch_end([(1, [])]) is None
+    row = [10., 20., 30., 60., 0.8] + [float(i) for i in range(34)] + [0.0] * 18
+    ann = p.coco_annotations([(4, [row])])
+    assert len(ann) == 1 and ann[0]["image_id"] == 4 and ann[0]["category_id"] == 1 and ann[0]["bbox"] == [10.0, 20.0, 20.0, 40.0]
+    assert ann[0]["score"] == 0.8 and len(ann[0]["keypoints"]) == 51 and ann[0]["keypoints"][:6] == [0.0, 1.0, 1.0, 2.0, 3.0, 1.0]
+
+
 def test_bench_launch_contract_two_processes():
     """bench.py driven exactly like the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N ... bench.py
     --gpus N`), on gloo with `--dry-run` (no GPU here): both ranks join, every rank builds ITS slice of the synthetic batch
