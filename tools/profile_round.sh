@@ -3,7 +3,7 @@
 #   bench line + per-launch table, rocprofv3 kernel-trace summary of the same bench command, FETCH_SIZE / WRITE_SIZE of the
 #   dominant kernel in two separate counter-only passes, isolated op timings.
 # usage: tools/profile_round.sh r03
-tag=${1:-r03}
+tag=${1:-r04}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -32,7 +32,14 @@ tail -1 $out/bench.log > $out/bench_line.json
 python tools/opbench.py decode bn conv > $out/opbench.txt 2>&1
 DCN_SHAPES=3 python tools/opbench.py dcn >> $out/opbench.txt 2>&1
 python tools/wgrad_bench.py 256 384 > $out/wgrad_bench.txt 2>&1
-python tools/gap_check.py $db > $out/gap_check.txt 2>&1 || true
-ls -la $out
 rm -rf $out/kt
+# a REPLAYED step (--no-probe: every timed step of this trace is a graph replay): span, busy share, idle gaps, foreign kernels.  NOTE the
+# profiler distorts the overlap of the two streams (profiles/<tag>_replay_timeline_unprofiled.txt is the unprofiled timeline)
+timeout 600 rocprofv3 --kernel-trace -d $out/kt2 -o p -- python bench.py --no-cpu-baseline --no-inference --no-extras --no-probe --steps 10 --warmup 3 > $out/kt2.log 2>&1
+db2=$(ls $out/kt2/*.db 2>/dev/null | head -1)
+[ -n "$db2" ] && python tools/replay_trace.py $db2 > $out/replay_trace.txt 2>&1
+rm -rf $out/kt2
+python tools/zero_timeline.py > $out/replay_timeline_unprofiled.txt 2>&1
+bash tools/pmc_sq.sh $tag > /dev/null 2>&1; cp gpurun_out/pmc_sq_$tag/pmc_sq.txt $out/pmc_sq.txt
+python tools/bf16_error_growth.py train 16 256 > $out/bf16_error_growth_train.txt 2>&1
 ls -la $out
