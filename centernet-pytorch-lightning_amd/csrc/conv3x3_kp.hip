@@ -61,7 +61,9 @@ __device__ static inline void kp_dma(const char* src, unsigned dst) {
 }
 
 // RES: 0 none, 1 y += res (bf16), 2 ReLU-backward mask y = res > 0 ? y : 0; RELU: y = max(y, 0)
-template <int RES, bool RELU>
+// LOCK: the lockstep form (all eight waves in the same step, fragment ring across steps, ONE barrier per step) instead of the
+// phase-staggered one — see the second half of the kernel body
+template <int RES, bool RELU, bool LOCK>
 __global__ __launch_bounds__(KP_NT) void conv3x3_kp_kernel(const ConvGeom g, int nblk, int tiles_h, int tiles_w, uint64_t wmap) {
     CN_MAIN_PRIO_SET();
     __shared__ __attribute__((aligned(1024))) unsigned char lds[KP_LDS];
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(KP_NT) void conv3x3_kp_kernel(const ConvGeom g, int
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool late = wave >= 4;
+    const bool late = !LOCK && wave >= 4;
     const int wm = (wave & 3) * 64, wn = (wave >> 2) * 64;        // wave tile: 64 pixels (4 tile rows) x 64 output channels
     // waves 0-3 and 4-7 differ in the CHANNEL half, so a SIMD's two waves (w, w + 4) share their pixels' A fragments' LDS lines
     const int xcd = blockIdx.x & 7, rr = blockIdx.x >> 3;
@@ -221,6 +223,108 @@ __global__ __launch_bounds__(KP_NT) void conv3x3_kp_kernel(const ConvGeom g, int
         }
         Vec16<bf16_t>::store(reinterpret_cast<bf16_t*>(ybase + (unsigned)((pixl * g.y_ld + cl) * 2)), v);
     };
+
+    if constexpr (LOCK) {
+        // ======================================= lockstep form =======================================
+        // All eight waves run the same step.  A step's 16 MFMAs go in four groups (K steps kk = 0..3: fragments B j = 0,1 and A i = 0,1);
+        // the fragments of group G + 2 are requested before the MFMAs of group G issue (a ring of three register sets that runs ACROSS
+        // steps: 36 groups per slice = 0 mod 3, so the ring position is a compile-time function of (pos, kk)).  Groups 2, 3 of step s
+        // therefore read slot (s+1) % 4 and — in step 8 of a slice — the other halo buffer: ONE barrier per step, between groups 1 and
+        // 2, in front of which every wave has waited for ITS pieces of W(s+1) (and, in step 8, of the next slice's halo).  Behind that
+        // barrier slot (s-1) % 4 is free (its last reads fed the MFMAs of step s-1): W(s+3) is issued there, two steps ahead of the
+        // barrier that publishes it; the next slice's halo goes out in steps 0..5 (the buffer's last reads fed step 8 of the slice before).
+        Tile cur;
+        cur.n = stream / tiles_img; cur.th = (stream - cur.n * tiles_img) / tiles_w; cur.tw = stream - cur.n * tiles_img - cur.th * tiles_w;
+        if (nitems > 0) {
+            const HaloSrc h0 = halo_src(cur, 0);
+#pragma unroll
+            for (int p = 0; p < 6; ++p) halo_piece(h0, 0, p);
+            for (int s = 0; s < 3 && s < Gtot; ++s) { weight_piece(s, 0, s, 0); weight_piece(s, 0, s, 1); }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bf16x8_t fr[3][4];                       // [ring position][B j = 0, B j = 1, A i = 0, A i = 1]
+        auto request = [&](bf16x8_t (&f)[4], unsigned hbuf, unsigned wslot, int pos_, int kk) {
+            const int ph = pos_ / 3, pw = pos_ % 3;
+            int a0 = ad[0][pw] + (int)hbuf, a1 = ad[1][pw] + (int)hbuf, b0 = bd[0] + (int)wslot, b1 = bd[1] + (int)wslot;
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));     // recomputed per group: hoisted, 9 positions x 4 K steps of addresses pin registers
+            f[0] = *reinterpret_cast<const bf16x8_t*>(lds + (unsigned)(b0 ^ (kk << 5)));
+            f[1] = *reinterpret_cast<const bf16x8_t*>(lds + (unsigned)(b1 ^ (kk << 5)));
+            f[2] = *reinterpret_cast<const bf16x8_t*>(lds + (unsigned)((a0 ^ (kk << 5)) + (ph * KP_HW + pw) * 128));
+            f[3] = *reinterpret_cast<const bf16x8_t*>(lds + (unsigned)((a1 ^ (kk << 5)) + (ph * KP_HW + pw) * 128));
+        };
+        int gstep = 0;
+        unsigned hb = 0;
+        bool has_prev = false;
+        init_acc();
+        request(fr[0], 0u, 0u, 0, 0);
+        request(fr[1], 0u, 0u, 0, 1);
+#pragma unroll 1
+        for (int item = 0; item < nitems; ++item) {
+            const Tile nxt = advance(cur);
+#pragma unroll 1
+            for (int c = 0; c < nsl; ++c) {
+                const bool more = c + 1 < nsl || item + 1 < nitems;
+                const HaloSrc nsrc = halo_src(c + 1 < nsl ? cur : nxt, c + 1 < nsl ? (c + 1) * 64 : 0);
+                const int cnx = c + 1 < nsl ? c + 1 : 0;
+                const unsigned nhb = hb ? 0u : (unsigned)KP_HALO;
+                auto do_step = [&](auto POS_) __attribute__((always_inline)) {
+                    constexpr int pos = decltype(POS_)::value;
+                    const unsigned wsl = (unsigned)(gstep & 3) * KP_WSLOT, wsl1 = (unsigned)((gstep + 1) & 3) * KP_WSLOT;
+                    const unsigned hb1 = pos == 8 ? nhb : hb;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int G = pos * 4 + kk;                       // group index inside the slice; ring position G % 3
+                        if (kk == 2) {
+                            // ---- the step's barrier: W(s+1) (and in step 8 the next slice's halo) published, slot (s-1) % 4 released ----
+                            const int rem = Gtot - 1 - gstep;
+                            constexpr int h1 = (pos >= 1 && pos <= 6) ? 1 : 0, h2 = (pos >= 2 && pos <= 7) ? 1 : 0;
+                            if (rem >= 2) { if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + h2 + h1) : "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            if (gstep + 3 < Gtot) {
+                                weight_piece((pos + 3) % 9, pos + 3 >= 9 ? cnx : c, (gstep + 3) & 3, 0);
+                                weight_piece((pos + 3) % 9, pos + 3 >= 9 ? cnx : c, (gstep + 3) & 3, 1);
+                            }
+                            if (pos <= 5 && more) halo_piece(nsrc, (int)nhb, pos);
+                            if (has_prev && c == 0 && pos < 8) epilogue_chunk(pos);
+                        }
+                        // fragments of group G + 2: K steps 2, 3 of this step, or K steps 0, 1 of the next one
+                        if (kk < 2) request(fr[(G + 2) % 3], hb, wsl, pos, kk + 2);
+                        else request(fr[(G + 2) % 3], hb1, wsl1, (pos + 1) % 9, kk - 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        {
+                            bf16x8_t (&f)[4] = fr[G % 3];
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[j], f[2 + i], acc[j][i], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++gstep;
+                };
+                do_step(std::integral_constant<int, 0>{}); do_step(std::integral_constant<int, 1>{}); do_step(std::integral_constant<int, 2>{});
+                do_step(std::integral_constant<int, 3>{}); do_step(std::integral_constant<int, 4>{}); do_step(std::integral_constant<int, 5>{});
+                do_step(std::integral_constant<int, 6>{}); do_step(std::integral_constant<int, 7>{}); do_step(std::integral_constant<int, 8>{});
+                hb = nhb;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) prev[j][i] = acc[j][i];
+            tile_bases(cur);
+            has_prev = true;
+            init_acc();
+            cur = nxt;
+        }
+        if (has_prev) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) epilogue_chunk(e);
+        }
+        return;
+    }
 
     // ---- prologue: halo slice 0 of the first tile (all waves), weights of steps 0..2 (waves 4-7) ----
     Tile cur;
@@ -431,7 +535,10 @@ bool conv3x3_kp_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     if (grid <= 0) return false;
     const int res = g.res == nullptr ? 0 : (g.relu == 2 ? 2 : 1);
     const dim3 gr(grid), bl(KP_NT);
-#define KP_GO(RES_, RELU_) hipLaunchKernelGGL((conv3x3_kp_kernel<RES_, RELU_>), gr, bl, 0, st, g, nblk, tiles_h, tiles_w, wmap)
+    const char* mode = getenv("CN_CONV_KP_MODE");        // "stagger": the phase-staggered form; default: the lockstep form
+    const bool lock = !(mode && mode[0] == 's');
+#define KP_GO(RES_, RELU_) do { if (lock) hipLaunchKernelGGL((conv3x3_kp_kernel<RES_, RELU_, true>), gr, bl, 0, st, g, nblk, tiles_h, tiles_w, wmap); \
+                               else hipLaunchKernelGGL((conv3x3_kp_kernel<RES_, RELU_, false>), gr, bl, 0, st, g, nblk, tiles_h, tiles_w, wmap); } while (0)
     if (res == 0) { if (g.relu == 1) KP_GO(0, true); else KP_GO(0, false); }
     else if (res == 1) { if (g.relu == 1) KP_GO(1, true); else KP_GO(1, false); }
     else KP_GO(2, false);

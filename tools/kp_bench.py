@@ -28,6 +28,7 @@ else:
         for v in sys.argv[1:]:
             env = dict(os.environ, CN_ENABLE_CONV_KP="1")
             if v == "old": env["CN_DISABLE_CONV_KP"] = "1"
+            elif v == "stagger": env["CN_CONV_KP_MODE"] = "stagger"
             elif v != "cur": env["CN_LIB_PATH"] = os.path.abspath(v)
             r = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
             print(f"round {rnd} {os.path.basename(v):22s} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]}", flush=True)
