@@ -243,8 +243,10 @@ __global__ __launch_bounds__(KP_NT) void conv3x3_kp_kernel(const ConvGeom g, int
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        int gstep = 0;
         bf16x8_t fr[3][4];                       // [ring position][B j = 0, B j = 1, A i = 0, A i = 1]
         auto request = [&](bf16x8_t (&f)[4], unsigned hbuf, unsigned wslot, int pos_, int kk) {
+            if ((KP_ABL & 8) && gstep > 0) return;
             const int ph = pos_ / 3, pw = pos_ % 3;
             int a0 = ad[0][pw] + (int)hbuf, a1 = ad[1][pw] + (int)hbuf, b0 = bd[0] + (int)wslot, b1 = bd[1] + (int)wslot;
             asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));     // recomputed per group: hoisted, 9 positions x 4 K steps of addresses pin registers
@@ -253,7 +255,6 @@ __global__ __launch_bounds__(KP_NT) void conv3x3_kp_kernel(const ConvGeom g, int
             f[2] = *reinterpret_cast<const bf16x8_t*>(lds + (unsigned)((a0 ^ (kk << 5)) + (ph * KP_HW + pw) * 128));
             f[3] = *reinterpret_cast<const bf16x8_t*>(lds + (unsigned)((a1 ^ (kk << 5)) + (ph * KP_HW + pw) * 128));
         };
-        int gstep = 0;
         unsigned hb = 0;
         bool has_prev = false;
         init_acc();
@@ -280,9 +281,10 @@ __global__ __launch_bounds__(KP_NT) void conv3x3_kp_kernel(const ConvGeom g, int
                             // ---- the step's barrier: W(s+1) (and in step 8 the next slice's halo) published, slot (s-1) % 4 released ----
                             const int rem = Gtot - 1 - gstep;
                             constexpr int h1 = (pos >= 1 && pos <= 6) ? 1 : 0, h2 = (pos >= 2 && pos <= 7) ? 1 : 0;
-                            if (rem >= 2) { if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + h2 + h1) : "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                            if (KP_ABL & 4) { }
+                            else if (rem >= 2) { if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + h2 + h1) : "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
                             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
+                            if (!(KP_ABL & 16)) __builtin_amdgcn_s_barrier();
                             if (gstep + 3 < Gtot) {
                                 weight_piece((pos + 3) % 9, pos + 3 >= 9 ? cnx : c, (gstep + 3) & 3, 0);
                                 weight_piece((pos + 3) % 9, pos + 3 >= 9 ? cnx : c, (gstep + 3) & 3, 1);
