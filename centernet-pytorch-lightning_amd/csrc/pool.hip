@@ -299,6 +299,127 @@ __global__ __launch_bounds__(256) void dwdeconv_bwd_weight_kernel(const T* __res
     }
 }
 
+// ---- depthwise up-conv weight gradient, bilinear x2 layers (k = 4, stride 2, pad 1, bf16) — round 4 ---------------------------------
+// The kernel above gives every (tap, channel vector) pair its own lane: per input pixel and channel vector 16 loads of x (one line, 16
+// lanes) and 16 of dy, each dy pixel fetched by the 4 taps that touch it — 1.4 TB/s of algorithmic traffic, the largest single excess
+// over its roofline left in the step (profiles/r04_ops_by_shape.txt).  Here a lane owns a channel vector and walks along ONE dy row oh:
+// that row only meets the two kernel rows kh = kh0, kh0 + 2 (kh0 = (oh + 1) & 1) through the x rows ih = (oh + 1 - kh0) / 2 and ih - 1,
+// and its four kernel columns through a sliding window of four dy pixels (ow = 2 iw - 1 .. 2 iw + 2: two new pixels per x pixel).
+// Every dy pixel is loaded exactly once, every x pixel twice; 64 fp32 accumulators per lane (2 kernel rows x 4 columns x 8 channels).
+// Lanes of a wave = CVW channel vectors x 64 / CVW rows; a lane keeps the PARITY of its rows (even task stride), so its accumulators
+// always mean the same taps; the workgroup folds them through LDS atomics and adds 16 C values to dw.
+template <int CVW>
+__global__ __launch_bounds__(256) void dwdeconv_wgrad_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ ws,
+                                                                  int N, int H, int W, int C, int OH, int OW, int ntasks) {
+    constexpr int TPW = 64 / CVW;                 // dy rows per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cvl = lane % CVW, tslot = lane / CVW;
+    const int cv = blockIdx.y * CVW + cvl;        // channel vector (8 channels)
+    const int slot = (blockIdx.x * 4 + wave) * TPW + tslot, nslots = gridDim.x * 4 * TPW;      // nslots is even: a lane's rows keep their parity
+    float acc[2][4][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[a][b][e] = 0.f;
+    auto unpack = [](const uint4& v, float (&f)[8]) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(w[q] << 16); f[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+    };
+    for (int task = slot; task < ntasks; task += nslots) {
+        const int n = task / OH, oh = task - n * OH;
+        const int kh0 = (oh + 1) & 1, iha = (oh + 1 - kh0) >> 1, ihb = iha - 1;
+        const bool va = iha < H, vb = ihb >= 0;
+        const bf16_t* dr = dy + ((int64_t)(n * OH + oh) * OW) * C + cv * 8;
+        const bf16_t* xa = x + ((int64_t)(n * H + (va ? iha : 0)) * W) * C + cv * 8;
+        const bf16_t* xb = x + ((int64_t)(n * H + (vb ? ihb : 0)) * W) * C + cv * 8;
+        // dy window ow = 2 iw - 1 .. 2 iw + 2 as raw bf16 vectors; the loads of step iw + 4 are issued in step iw (a ring of four
+        // steps x {x row a, x row b, two new dy pixels} = 16 vectors in flight per lane: with one step of lead the walk was latency
+        // bound — 142 us on the 64-channel 64^2 layer, slower than the tap-per-lane kernel it replaces)
+        uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = *reinterpret_cast<const uint4*>(dr), w2 = *reinterpret_cast<const uint4*>(dr + C),
+              w3 = ldg16_masked(dr, (int64_t)2 * C * 2, 2 < OW);
+        uint4 rxa[4], rxb[4], rd0[4], rd1[4];
+        auto issue = [&](int iw, uint4& qa, uint4& qb, uint4& q0, uint4& q1) {
+            const bool in = iw < W;
+            qa = ldg16_masked(xa, (int64_t)iw * C * 2, va && in);
+            qb = ldg16_masked(xb, (int64_t)iw * C * 2, vb && in);
+            q0 = ldg16_masked(dr, (int64_t)(2 * iw + 3) * C * 2, 2 * iw + 3 < OW);
+            q1 = ldg16_masked(dr, (int64_t)(2 * iw + 4) * C * 2, 2 * iw + 4 < OW);
+        };
+#pragma unroll
+        for (int d = 0; d < 4; ++d) issue(d, rxa[d], rxb[d], rd0[d], rd1[d]);
+        for (int iw0 = 0; iw0 < W; iw0 += 4) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint4 cxa = rxa[d], cxb = rxb[d], cd0 = rd0[d], cd1 = rd1[d];
+                issue(iw0 + d + 4, rxa[d], rxb[d], rd0[d], rd1[d]);
+                float fa[8], fb[8], fw[8];
+                unpack(cxa, fa);                  // (x pixels past the row end were loaded as zeros: steps iw >= W add nothing)
+                unpack(cxb, fb);
+                const uint4 wv[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) {
+                    unpack(wv[kw], fw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        acc[0][kw][e] = fmaf(fa[e], fw[e], acc[0][kw][e]);
+                        acc[1][kw][e] = fmaf(fb[e], fw[e], acc[1][kw][e]);
+                    }
+                }
+                w0 = w2; w1 = w3; w2 = cd0; w3 = cd1;     // slide: ow = 2 (iw + 1) - 1 .. 2 (iw + 1) + 2
+            }
+        }
+    }
+    // fold the workgroup's lanes: red[parity of the lane's rows][kernel-row slot][kw][channel of this block]
+    __shared__ float red[2 * 2 * 4 * CVW * 8];
+    for (int i = threadIdx.x; i < 2 * 2 * 4 * CVW * 8; i += 256) red[i] = 0.f;
+    __syncthreads();
+    const int par = slot & 1;                     // parity of oh (OH and nslots are even)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(&red[((par * 2 + a) * 4 + kw) * CVW * 8 + cvl * 8 + e], acc[a][kw][e]);
+    __syncthreads();
+    // the workgroup's 16 x (CVW * 8) sums leave as ONE private slab (plain 4-byte stores, coalesced), folded by dwdeconv_wgrad_reduce_kernel:
+    // same-address fp32 atomics execute at the memory side one after the other (~0.3 us each: 160 workgroups = a 50 us chain per address,
+    // the whole floor of the first version of this kernel)
+    float* slab = ws + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (2 * 2 * 4 * CVW * 8);
+    for (int i = threadIdx.x; i < 2 * 2 * 4 * CVW * 8; i += 256) slab[i] = red[i];
+}
+
+// dw[c][kh][kw] += sum over the nx row-block slabs; slab layout [x block][channel block][row parity][kernel-row slot][kw][channel].
+// 64 outputs per workgroup, four threads per output each folding every fourth slab with eight loads in flight (one thread per
+// output walking 160 slabs one load after the other was 30 us of pure latency: the floor of every small layer)
+__global__ __launch_bounds__(256) void dwdeconv_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int C, int cvw8, int nx) {
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;                       // (c, kh, kw)
+    float s = 0.f;
+    if (i < C * 16) {
+        const int kw = i & 3, kh = (i >> 2) & 3, c = i >> 4;
+        const int yb = c / cvw8, ch = c - yb * cvw8, ny = C / cvw8;
+        const int pr = (kh + 1) & 1, a = kh >> 1;            // rows of parity pr meet kernel rows kh0 = (pr + 1) & 1 and kh0 + 2
+        const float* p = ws + (int64_t)yb * (16 * cvw8) + ((pr * 2 + a) * 4 + kw) * cvw8 + ch;
+        const int64_t pitch = (int64_t)ny * 16 * cvw8;
+        int b = q;
+        for (; b + 28 < nx; b += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(b + 4 * u) * pitch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nx; b += 4) s += p[b * pitch];
+    }
+    part[q][o] = s;
+    __syncthreads();
+    if (q == 0 && i < C * 16) dw[i] += (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+}
+
 // ---- nearest-neighbour x2 up-sampling fused with the hourglass merge (large_hourglass.py:108-125, 196-204) ----------------
 // y[n, oh, ow, :] = a[n, oh, ow, :] + low[n, oh>>1, ow>>1, :]   (a == nullptr: plain nn.Upsample(scale_factor=2)).
 // One thread owns one LOW pixel vector and writes its 2x2 output footprint: low is read once, a/y stream as 16-byte vectors.
@@ -448,6 +569,49 @@ extern "C" int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw, 
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(dwdeconv_bwd_weight_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream,
                                                    (const T*)x, (const T*)dy, dw, N, H, W, C / V, k, stride, pad, OH, OW, chunk));
     CN_LAUNCH_CHECK("cn_dwdeconv_bwd_weight");
+    return CN_OK;
+}
+
+// the x2 layers (k = 4, stride 2, pad 1, OH = 2 H, OW = 2 W, bf16, C in {64, 128, 256} or a multiple of 512) through the row-walking
+// kernel + slab reduction; ws: cn_dwdeconv_wgrad_ws_bytes(N, OH, C) bytes of scratch.  CN_EUNSUPPORTED for any other shape.
+static int dw_rows_grid(int N, int OH, int C, int* cvw_out) {
+    const int CV = C / 8, cvw = CV >= 64 ? 64 : CV, tpw = 64 / cvw;
+    int gx = cn_wgrad_target_blocks() / (CV / cvw);
+    const int need = (N * OH + 4 * tpw - 1) / (4 * tpw);
+    if (gx > need) gx = need;
+    if (gx > 512) gx = 512;
+    if (gx < 1) gx = 1;
+    *cvw_out = cvw;
+    return gx;
+}
+static bool dw_rows_ok(int C, int k, int stride, int pad, int H, int W, int OH, int OW, int dtype) {
+    static const bool no_rows = getenv("CN_DISABLE_DWDECONV_ROWS") != nullptr;
+    return !no_rows && dtype == CN_BF16 && k == 4 && stride == 2 && pad == 1 && OH == 2 * H && OW == 2 * W && OW >= 3 &&
+           (C == 64 || C == 128 || C == 256 || (C > 0 && (C & 511) == 0));
+}
+extern "C" size_t cn_dwdeconv_wgrad_ws_bytes(int N, int OH, int C) {
+    if (C <= 0 || (C & 63)) return 0;
+    return (size_t)512 * 16 * C * sizeof(float);            // the grid is capped at 512 row blocks
+}
+extern "C" int cn_dwdeconv_bwd_weight_rows(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
+                                           int stride, int pad, int OH, int OW, int dtype, void* stream) {
+    CN_CHECK_ARG(x && dy && dw && ws && N > 0 && H > 0 && W > 0, "cn_dwdeconv_bwd_weight_rows: bad args");
+    if (!dw_rows_ok(C, k, stride, pad, H, W, OH, OW, dtype) || (int64_t)N * OH >= (1ll << 30))
+        CN_UNSUPPORTED("cn_dwdeconv_bwd_weight_rows: bf16 k=4 s=2 p=1 layers with 64/128/256/512n channels only");
+    int cvw;
+    const int gx = dw_rows_grid(N, OH, C, &cvw);
+    const int CV = C / 8, ntasks = N * OH;
+    if (ws_bytes < (size_t)gx * 16 * C * sizeof(float)) { cn_set_error("cn_dwdeconv_bwd_weight_rows: workspace too small"); return CN_EWORKSPACE; }
+    dim3 grid(gx, CV / cvw);
+    const bf16_t* xp = (const bf16_t*)x; const bf16_t* dp = (const bf16_t*)dy;
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    if (cvw == 8) hipLaunchKernelGGL(dwdeconv_wgrad_rows_kernel<8>, grid, dim3(256), 0, st, xp, dp, wsf, N, H, W, C, OH, OW, ntasks);
+    else if (cvw == 16) hipLaunchKernelGGL(dwdeconv_wgrad_rows_kernel<16>, grid, dim3(256), 0, st, xp, dp, wsf, N, H, W, C, OH, OW, ntasks);
+    else if (cvw == 32) hipLaunchKernelGGL(dwdeconv_wgrad_rows_kernel<32>, grid, dim3(256), 0, st, xp, dp, wsf, N, H, W, C, OH, OW, ntasks);
+    else hipLaunchKernelGGL(dwdeconv_wgrad_rows_kernel<64>, grid, dim3(256), 0, st, xp, dp, wsf, N, H, W, C, OH, OW, ntasks);
+    hipLaunchKernelGGL(dwdeconv_wgrad_reduce_kernel, dim3((C * 16 + 63) / 64), dim3(256), 0, st, wsf, dw, C, cvw * 8, gx);
+    CN_LAUNCH_CHECK("cn_dwdeconv_bwd_weight_rows");
     return CN_OK;
 }
 

@@ -957,12 +957,12 @@ class DwDeconvFn(Function):
             call("cn_dwdeconv_bwd_input", dy, weight.detach().contiguous(), dx, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
         if ctx.needs_input_grad[1] and SideGrads.usable(weight):
             def side_work(x=x, dy=dy):
-                call("cn_dwdeconv_bwd_weight", x, dy, weight.grad, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+                _dwdeconv_wgrad(x, dy, weight.grad, N, H, W, C, k, stride, pad, OH, OW)
                 GradReady.note(weight)
             SideGrads.submit(side_work, x, dy, claims=(weight,))
         elif ctx.needs_input_grad[1]:
             dw = zeros_like(weight, torch.float32)
-            call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
+            _dwdeconv_wgrad(x, dy, dw, N, H, W, C, k, stride, pad, OH, OW)
         dres = dy if ctx.has_res else None
         if ctx.cells[0] is not None and dx is not None:
             dx = ctx.cells[0].give(dx)
@@ -1523,6 +1523,16 @@ class GatherL1Fn(Function):
              feat[0, 0].numel(), ind.shape[1], ctx.has_c)
         SparseRows.note(dfeat, ind)       # zero outside ind[b, :]: a HeadFn behind `feat` works on those rows only
         return dfeat, None, None, None
+
+
+def _dwdeconv_wgrad(x, dy, dw, N, H, W, C, k, stride, pad, OH, OW):
+    """depthwise up-conv weight gradient: the row-walking slab kernel where it takes the shape (the x2 layers), else the general one"""
+    n = _hip.query("cn_dwdeconv_wgrad_ws_bytes", N, OH, C)
+    if n and x.dtype == torch.bfloat16:
+        ws = _hip.workspace(n, x.device, "dwwgrad")
+        if _hip.try_call("cn_dwdeconv_bwd_weight_rows", x, dy, dw, ws, n, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype)):
+            return
+    call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
 
 
 class WeightedSumFn(Function):

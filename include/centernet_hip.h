@@ -211,6 +211,13 @@ int cn_dwdeconv_bwd_input(const void* dy, const float* w, void* dx, int N, int H
                           int pad, int OH, int OW, int dtype, void* stream);
 int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp32 [C,k,k] */, int N, int H, int W,
                            int C, int k, int stride, int pad, int OH, int OW, int dtype, void* stream);
+/* the same for the bilinear x2 layers of IDAUp (pose_dla_dcn.py:424-432: k = 4, stride 2, pad 1, OH = 2 H, OW = 2 W; bf16; C in
+ * {64, 128, 256} or a multiple of 512): every dy pixel is read once (a lane walks a dy row with a sliding four-pixel window) and the
+ * workgroups' partial sums meet in slabs instead of same-address atomics; dw += the sum.  ws: cn_dwdeconv_wgrad_ws_bytes() of
+ * scratch.  Any other shape -> CN_EUNSUPPORTED (call cn_dwdeconv_bwd_weight). */
+size_t cn_dwdeconv_wgrad_ws_bytes(int N, int OH, int C);
+int cn_dwdeconv_bwd_weight_rows(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
+                                int stride, int pad, int OH, int OW, int dtype, void* stream);
 
 /* A head's last layer (heads.py:15-17: nn.Conv2d(head_conv, out_channels, 1) on the hidden activation) straight into the public
  * layout: y fp32 NCHW [N,Co,H,W] = conv1x1(x) + bias, x [N,H,W,x_ld] in `dtype`, wp = cn_pack_weight(mode 1).  Replaces

@@ -474,7 +474,10 @@ def test_upsample2x_add(cfg, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 2, False), (1, 6, 5, 64, 4, True), (2, 4, 4, 256, 2, True)])
+@pytest.mark.parametrize("cfg", [(2, 8, 8, 64, 2, False), (1, 6, 5, 64, 4, True), (2, 4, 4, 256, 2, True),
+                                 # the row-walking bf16 weight-gradient kernel of the x2 layers (k = 4): odd sizes, every lane layout
+                                 # (8 / 16 / 32 / 64 channel-vector lanes per row), several rows per lane
+                                 (3, 7, 9, 128, 2, False), (1, 5, 6, 512, 2, False), (5, 40, 24, 64, 2, True), (2, 3, 2, 1024, 2, False)])
 def test_depthwise_up(cfg, dt):
     """depthwise bilinear up-conv, optionally with IDAUp's merge add fused into its store (pose_dla_dcn.py:483-488)"""
     N, H, W, C, f, with_res = cfg
