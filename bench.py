@@ -107,6 +107,11 @@ def _kernel_name(hip, name, a, tn):
             if nj in (1, 2, 3, 4, 8) and not (nj == 8 and Ci > 128) and nj * 32 * (Ci + 8) * 2 <= 72 * 1024 and nj * 16 + Ci // 2 <= 200:
                 return f"conv1x1_stream_kernel<{Ci // 16},{nj}>"
         waves8 = os.environ.get("CN_CONV3X3_WAVES", "0") in ("0", "8")      # csrc/conv3x3.hip launch3(): 8 waves on the 128x64 tile
+        if v >= 4000000 and not transposed:
+            return f"conv3x3s1_kernel<{tn},{(v - 4000000) // 1000},32,S=2>"
+        if v >= 4000000:
+            bn, bk = 128 if Co > 64 else (64 if Co > 32 else 32), 32       # strided data gradient: implicit GEMM, parity classes
+            return f"conv_igemm_kernel<{tn},{bn},{bk},transposed>"
         if v >= 3000000:
             if v == 3128064 and tn == "bf16" and waves8:
                 return f"conv3x3s1_kernel<{tn},128,64,8>"

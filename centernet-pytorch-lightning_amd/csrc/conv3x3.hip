@@ -12,13 +12,16 @@
 #define T3_TH 8
 #define T3_TW 16
 
-template <typename T, int BN, int CK, int NW = 4>   // NW waves per workgroup: 4 (64x64 wave tiles) or 8 (32x64: twice the waves per SIMD)
+// S = 2 (round 4): the stride-2 / pad-1 forward convs that open every DLA / ResNet stage (32 -> 64 @256^2 ... 256 -> 512 @32^2) on the same
+// skeleton — a (2*8+1) x (2*16+1) halo tile, every other halo pixel per output pixel; they ran on the generic implicit GEMM, which
+// re-reads the input once per tap (1.5-2.0 TB/s of algorithmic traffic, 0.1-0.25 of the MFMA peak).
+template <typename T, int BN, int CK, int NW = 4, int S = 1>   // NW waves per workgroup: 4 (64x64 wave tiles) or 8 (32x64: twice the waves per SIMD)
 __global__ __launch_bounds__(NW * 64) void conv3x3s1_kernel(const ConvGeom g) {
     CN_MAIN_PRIO_SET();
     constexpr int NT = NW * 64;
     constexpr int BM = T3_TH * T3_TW;                  // 128 output pixels
-    constexpr int HW_ = T3_TW + 2, HH_ = T3_TH + 2;    // halo tile
-    constexpr int HP = HH_ * HW_;                      // 180 halo pixels
+    constexpr int HW_ = T3_TW * S + 3 - S, HH_ = T3_TH * S + 3 - S;    // halo tile: 10 x 18 (stride 1), 17 x 33 (stride 2)
+    constexpr int HP = HH_ * HW_;                      // 180 / 561 halo pixels
     constexpr int VEC = 16 / sizeof(T);
     constexpr int PITCH = CK + Mma<T>::PAD;
     constexpr int VPR = CK / VEC;                      // 16-byte vectors per pixel / weight row
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3s1_kernel(const ConvGeom g) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = wm + i * 32 + (lane & 31);
-        hbase[i] = (m / T3_TW + 1) * RP + ((m % T3_TW) + 1) * PITCH;   // element offset of the centre pixel
+        hbase[i] = ((m / T3_TW) * S + 1) * RP + ((m % T3_TW) * S + 1) * PITCH;   // element offset of the centre pixel
     }
 
     f32x16_t acc[NJ][MI];
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3s1_kernel(const ConvGeom g) {
         for (int p = 0; p < A_PASS; ++p) {
             const int v = tid + p * NT;
             const int hp = v / VPR, col = (v % VPR) * VEC;
-            const int ih = th0 - 1 + hp / HW_, iw = tw0 - 1 + hp % HW_;
+            const int ih = th0 * S - 1 + hp / HW_, iw = tw0 * S - 1 + hp % HW_;
             const bool ok = v < A_VECS && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
             ra[p] = ldg16_masked(X, (((int64_t)ih * g.W + iw) * g.x_ld + c0 + col) * (int64_t)sizeof(T), ok);
         }
@@ -362,6 +365,31 @@ static void launch3(const ConvGeom& g, hipStream_t st) {
         if (nw == 8) { hipLaunchKernelGGL((conv3x3s1_kernel<T, BN, CK, 8>), grid, dim3(512), 0, st, g); return; }
     }
     hipLaunchKernelGGL((conv3x3s1_kernel<T, BN, CK>), grid, dim3(256), 0, st, g);
+}
+
+// 3x3 / stride 2 / pad 1 forward conv (class 0 of g holds the nine taps with dh, dw in {-1, 0, 1} relative to input pixel (2 oh, 2 ow)):
+// bf16, Ci a multiple of 32; returns false when the shape is not handled (the caller runs the implicit GEMM)
+bool conv3x3s2_launch(const ConvGeom& g, int dtype, hipStream_t st) {
+    static const bool disabled = getenv("CN_DISABLE_CONV3X3_S2") != nullptr;
+    if (disabled || dtype != CN_BF16 || g.N > 65535 || (g.Ci & 31) || g.Ci < 32 || g.nsrc != 0 || g.dcn_x != nullptr || g.y_f32 || g.res32) return false;
+    if (g.ntaps[0] != 9 || g.sm != 2 || g.so != 1) return false;
+    for (int t = 0; t < 9; ++t)
+        if (g.dh[0][t] < -1 || g.dh[0][t] > 1 || g.dw[0][t] < -1 || g.dw[0][t] > 1) return false;
+    static const bool no_tile = getenv("CN_DISABLE_EPI_TILE") != nullptr;
+    const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !no_tile) ? 1 : 0;
+    if (g.bn_part) {                                   // BN statistics sink: the LDS-staged epilogue has the hook
+        if (g.epi_tile) bn_sink_mark_taken(); else const_cast<ConvGeom&>(g).bn_part = nullptr;
+    }
+    int bn = 32, bnb = (g.Co + 31) / 32;
+    for (int c : {64, 128}) {
+        int nb = (g.Co + c - 1) / c;
+        if (nb < bnb) { bn = c; bnb = nb; }
+    }
+    dim3 grid(((g.OH + T3_TH - 1) / T3_TH) * ((g.OW + T3_TW - 1) / T3_TW), (g.Co + bn - 1) / bn, g.N);
+    if (bn == 128) hipLaunchKernelGGL((conv3x3s1_kernel<bf16_t, 128, 32, 8, 2>), grid, dim3(512), 0, st, g);
+    else if (bn == 64) hipLaunchKernelGGL((conv3x3s1_kernel<bf16_t, 64, 32, 4, 2>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((conv3x3s1_kernel<bf16_t, 32, 32, 4, 2>), grid, dim3(256), 0, st, g);
+    return true;
 }
 
 bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {

@@ -426,6 +426,11 @@ extern "C" int cn_conv2d_variant(int Ci, int Co, int KH, int KW, int stride, int
         int ck = dtype == CN_BF16 ? (Ci % 64 == 0 ? 64 : (Ci % 32 == 0 ? 32 : 16)) : 16;
         return 3000000 + bn * 1000 + ck;        // conv3x3s1_kernel<T, BN, CK>
     }
+    if (KH == 3 && KW == 3 && stride == 2 && pad == 1 && dtype == CN_BF16 && Ci % 32 == 0 && Ci >= 32 && getenv("CN_DISABLE_CONV3X3_S2") == nullptr) {
+        int b3 = 32, nb3 = (Co + 31) / 32;      // conv3x3s2_launch's tile rule
+        for (int c : {64, 128}) { int nb = (Co + c - 1) / c; if (nb < nb3) { b3 = c; nb3 = nb; } }
+        return 4000000 + b3 * 1000 + 32;        // conv3x3s1_kernel<bf16, BN, 32, NW, S = 2> (forward; the data gradient stays on the implicit GEMM)
+    }
     return bn * 1000 + bk;                      // conv_igemm_kernel<T, BN, BK>
 }
 
@@ -483,6 +488,11 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     }
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && OH == H && OW == W && conv1x1_stream_launch(g, dtype, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_conv2d_fwd(1x1 stream)");
+        return CN_OK;
+    }
+    if (!transposed && KH == 3 && KW == 3 && stride == 2 && pad == 1 && OH == (H - 1) / 2 + 1 && OW == (W - 1) / 2 + 1 &&
+        conv3x3s2_launch(g, dtype, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_conv2d_fwd(3x3 stride 2)");
         return CN_OK;
     }
     if (dtype == CN_F32) dispatch_igemm<float>(g, ncls, (hipStream_t)stream);
