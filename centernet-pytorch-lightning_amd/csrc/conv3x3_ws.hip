@@ -30,7 +30,7 @@
 #define WS_DMA_P ((WS_DMA_I + 7) / 8)         // ... per wave (6, the last one on wave 0 only)
 #define WS_HALO (WS_DMA_I * 1024)             // bytes per halo buffer
 #define WS_NT 512
-#define WS_LDS (3 * WS_HALO + 64 * 4)
+#define WS_LDS (3 * WS_HALO + 64 * 4 + 2 * 64 * 4)     // + bias + the fused head's two weight rows of this channel block
 
 __device__ uint4 ws_zero_page[8];             // 128 zero bytes: DMA source of the halo slots that lie outside the image
 #ifdef WS_PROBE   // development build only (tools/ws_probe.py): per-phase cycle stamps of waves 0 and 4 of every workgroup, first 8 tiles
@@ -44,7 +44,11 @@ extern "C" int ws_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, H
 // BN: output channels per workgroup, 64 (waves 4 x 2, 64-pixel wave tiles) or 32 (8 x 1, 32 pixels); YF32: fp32 output rows;
 // RES: 0 no residual, 1 y += res, 2 ReLU-backward mask y = res > 0 ? y : 0; RELU: y = max(y, 0) (compile-time: the epilogue
 // is branch-free)
-template <int BN, bool YF32, int RES, bool RELU>
+// HEAD = 2 (round 4, cn_head2_fwd): a 2-channel task head in ONE launch (heads.py:9-15: conv3x3 -> ReLU -> conv1x1): the hidden
+// activation never leaves the accumulators — each wave multiplies its 32 hidden channels with the head's two weight rows, the two halves
+// of the wave meet through a lane swap and add one output channel each to the public fp32 NCHW map with fp32 atomics (8 partial sums per
+// pixel and channel: 256 hidden channels / 32).  No 537 MB hidden tensor, no second launch.
+template <int BN, bool YF32, int RES, bool RELU, int HEAD = 0>
 __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int nblk, int tiles_h, int tiles_w, uint64_t wmap) {
     CN_MAIN_PRIO_SET();
     constexpr int WGN = BN / 32, WGM = 8 / WGN, WM = 256 / WGM, MI = WM / 32;
@@ -65,6 +69,10 @@ __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int
     const bf16_t* __restrict__ Wp = reinterpret_cast<const bf16_t*>(g.w);
 
     if (tid < BN) bias_l[tid] = (g.bias && n0 + tid < g.Co) ? g.bias[n0 + tid] : 0.f;
+    float* const head_l = bias_l + 64;        // [2][64]: the fused head's weight rows over this workgroup's hidden channels
+    if constexpr (HEAD == 2) {
+        if (tid < 2 * BN) head_l[(tid / BN) * 64 + tid % BN] = n0 + tid % BN < g.Co ? g.head_w[(int64_t)(tid / BN) * g.Co + n0 + tid % BN] : 0.f;
+    }
 
     // the wave's weight fragments: rows = output channels n0 + wn + (lane & 31), k = tap * 64 + kk * 16 + 8 * (lane >> 5) .. + 7;
     // indexed by WINDOW POSITION pos = (dh + 1) * 3 + (dw + 1); wmap holds the weight tap of each position (4 bits each), so normal
@@ -224,7 +232,30 @@ __global__ __launch_bounds__(WS_NT) void conv3x3_ws_kernel(const ConvGeom g, int
         // than the MFMA phase it hides behind.)  fp32 bias / residual / ReLU, then one rounding, as in conv_epilogue.  Channels
         // Co .. y_ld-1 (the activation's zero padding) come out as zeros without a mask: their weight rows are the zero rows of
         // the packed matrix, their bias is staged as 0 and the residual's own padding is zero.
-        {
+        if constexpr (HEAD == 2) {
+            int lane = tid & 63;
+            asm volatile("" : "+v"(lane));
+            const float* hl = head_l + wn + 4 * (lane >> 5);
+            float* const ymap = reinterpret_cast<float*>(g.y) + ((int64_t)cur.n * 2 + (lane >> 5)) * g.OH * g.OW;     // half 0 -> channel 0, half 1 -> channel 1
+            const float b2 = (n0 + wn == 0) ? g.head_b[lane >> 5] : 0.f;            // the head's bias enters once per pixel and channel
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(hl + 8 * q), w1 = *reinterpret_cast<const float4*>(hl + 64 + 8 * q);
+                    const float v0 = __builtin_amdgcn_fmed3f(acc[i][4 * q], 0.f, INFINITY), v1 = __builtin_amdgcn_fmed3f(acc[i][4 * q + 1], 0.f, INFINITY);
+                    const float v2 = __builtin_amdgcn_fmed3f(acc[i][4 * q + 2], 0.f, INFINITY), v3 = __builtin_amdgcn_fmed3f(acc[i][4 * q + 3], 0.f, INFINITY);
+                    p0 = fmaf(v0, w0.x, fmaf(v1, w0.y, fmaf(v2, w0.z, fmaf(v3, w0.w, p0))));
+                    p1 = fmaf(v0, w1.x, fmaf(v1, w1.y, fmaf(v2, w1.z, fmaf(v3, w1.w, p1))));
+                }
+                // lanes l and l + 32 hold the same pixel: the low half keeps channel 0 (its p0 + the high half's p0), the high half channel 1
+                const float o0 = __shfl_xor(p0, 32, 64), o1 = __shfl_xor(p1, 32, 64);
+                const float mine = (lane >> 5) ? p1 : p0, other = (lane >> 5) ? o1 : o0;
+                const int m = wm + i * 32 + (lane & 31);
+                atomicAdd(ymap + (int64_t)(cur.th * 16 + (m >> 4)) * g.OW + cur.tw * 16 + (m & 15), mine + other + b2);
+            }
+        } else {
             int lane = tid & 63;
             asm volatile("" : "+v"(lane));      // recomputed per tile: hoisted, the per-lane addressing would pin registers
             // tile base in scalar registers, 32-bit per-lane byte offsets (a tile spans < 16 rows of the map)
@@ -290,7 +321,7 @@ bool conv3x3_ws_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     static int cus = 0;
     if (disabled || dtype != CN_BF16 || g.Ci != 64 || (g.x_ld & 7) || (g.H & 15) || (g.W & 15) || g.nsrc != 0 || g.dcn_x != nullptr) return false;
     // what the kernel's own epilogue covers: bf16 or fp32 rows made of 8-channel vectors, optional bf16 residual / ReLU mask
-    if (g.res32 != nullptr || (g.y_ld & 7) || (g.res != nullptr && (g.res_ld & 7))) return false;
+    if (g.res32 != nullptr || (g.head_nc == 0 && (g.y_ld & 7)) || (g.res != nullptr && (g.res_ld & 7))) return false;
     if ((reinterpret_cast<uintptr_t>(g.x) | reinterpret_cast<uintptr_t>(g.w) | reinterpret_cast<uintptr_t>(g.y) | reinterpret_cast<uintptr_t>(g.res)) & 15) return false;
     if (cus == 0) {
         int dev = 0, v = 0;
@@ -321,6 +352,11 @@ bool conv3x3_ws_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     const dim3 gr(grid), bl(WS_NT);
     const int res = g.res == nullptr ? 0 : (g.relu == 2 ? 2 : 1);
     if (g.y_f32 && res != 0) return false;
+    if (g.head_nc != 0) {                     // fused 2-channel task head: 64-wide channel blocks, ReLU, no residual; the map is fp32 NCHW
+        if (g.head_nc != 2 || bn != 64 || (g.Co & 63) || g.relu != 1 || res != 0 || !g.head_w || !g.head_b) return false;
+        hipLaunchKernelGGL((conv3x3_ws_kernel<64, false, 0, true, 2>), gr, bl, 0, st, g, nblk, tiles_h, tiles_w, wmap);
+        return true;
+    }
 #define WS_GO(BN_, F32_, RES_, RELU_) hipLaunchKernelGGL((conv3x3_ws_kernel<BN_, F32_, RES_, RELU_>), gr, bl, 0, st, g, nblk, tiles_h, tiles_w, wmap)
 #define WS_PICK(BN_)                                                          \
     do {                                                                      \

@@ -47,6 +47,11 @@ struct ConvGeom {
     const void* xs[CN_MAX_SRC];
     int xs_c[CN_MAX_SRC];     // channels (= pixel pitch) of each source, multiples of the K slice
     int xs_k0[CN_MAX_SRC];    // first K index of each source
+    // fused task head (cn_head2_fwd; conv3x3_ws_kernel<..., HEAD = 2>): y is the public fp32 NCHW map [N, 2, H, W], all-zero at launch;
+    // every wave adds its 32 hidden channels' share of conv1x1(relu(conv3x3(x) + bias)) with fp32 atomics, head_w = fp32 [2][Co]
+    const float* head_w;
+    const float* head_b;
+    int head_nc;
 };
 
 template <typename T> struct Mma;

@@ -502,6 +502,26 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     return CN_OK;
 }
 
+// A 2-channel task head in one launch (heads.py:9-15 `conv3x3 -> ReLU -> conv1x1`; width_height / regression): out fp32 NCHW
+// [N, 2, H, W] (ALL-ZERO at launch: the kernel adds) = conv1x1(relu(conv3x3(x) + b1)) + b2, x NHWC bf16 with 64 channels, wp1 = the
+// hidden conv's weights packed with mode 1 ([Ch_pad32][9 * 64]), w2 fp32 [2][Ch], Ch a multiple of 64.  The hidden activation is never
+// written.  Shapes the weight-stationary kernel does not take (H, W multiples of 16, enough tiles) -> CN_EUNSUPPORTED.
+extern "C" int cn_head2_fwd(const void* x, const void* wp1, const float* b1, const float* w2, const float* b2, float* out, int N, int H,
+                            int W, int Ci, int x_ld, int Ch, int dtype, void* stream) {
+    CN_CHECK_ARG(x && wp1 && w2 && b2 && out && N > 0 && H > 0 && W > 0, "cn_head2_fwd: bad args");
+    if (dtype != CN_BF16 || Ci != 64 || (Ch & 63) || Ch <= 0) CN_UNSUPPORTED("cn_head2_fwd: bf16, 64 input channels, hidden width a multiple of 64");
+    ConvGeom g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.w = wp1; g.bias = b1; g.y = out;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = H; g.OW = W; g.Co = Ch; g.y_ld = Ch;
+    g.ktot = 9 * Ci; g.co_pad = (Ch + 31) / 32 * 32; g.relu = 1;
+    g.head_w = w2; g.head_b = b2; g.head_nc = 2;
+    if (build_geom(g, 3, 3, 1, 1, 0) < 0 || !conv3x3_ws_launch(g, dtype, (hipStream_t)stream))
+        CN_UNSUPPORTED("cn_head2_fwd: shape not handled by the weight-stationary kernel (H, W multiples of 16, >= 4 tiles per workgroup)");
+    CN_LAUNCH_CHECK("cn_head2_fwd");
+    return CN_OK;
+}
+
 bool conv1x1_stream_nchw_launch(const ConvGeom& g, int dtype, hipStream_t st);
 
 extern "C" int cn_conv1x1_nchw_fwd(const void* x, const void* wp, const float* bias, float* y, int N, int H, int W, int Ci, int x_ld,

@@ -16,6 +16,7 @@ import torch.nn as nn
 from .. import nn as hnn
 from .. import ops
 
+_NO_HEAD2 = bool(__import__("os").environ.get("CN_DISABLE_HEAD2"))      # A/B: the one-launch 2-channel head of the no-grad path
 _FUSED_NODE = not __import__("os").environ.get("CN_DISABLE_HEAD_FN")      # A/B: the head as three separate autograd nodes
 PRIOR_LOGIT = -2.19          # sigmoid^-1(0.1): bias of every `heatmap*` head's last conv (heads.py:45-50)
 
@@ -50,6 +51,12 @@ class HeadConv(nn.Module):
             y = ops.HeadFn.apply(x, hidden.weight, hidden.bias, out.weight, out.bias)
             y._cn_head_dtype = x.dtype          # SigmoidFocalFn leaves a second-layout gradient only for a bf16 HeadFn (ops.DualLayout)
             return y
+        if (_FUSED_NODE and not _NO_HEAD2 and self.out_channels == 2 and x.is_cuda and x.dtype == torch.bfloat16 and hidden.k == 3
+                and hidden.stride == 1 and hidden.padding == 1 and hidden.bias is not None and out.bias is not None
+                and not (torch.is_grad_enabled() and (x.requires_grad or hidden.weight.requires_grad or out.weight.requires_grad))):
+            y = ops.head2_infer(x, hidden, out)                # no-grad 2-channel head: ONE launch, the hidden activation is never stored
+            if y is not None:
+                return y
         h = hidden(x, relu=True, defer_relu_bwd=True)          # ReLU in the epilogue; its backward is owed to ...
         if not (torch.is_grad_enabled() and (h.requires_grad or out.weight.requires_grad)) and _FUSED_NODE:
             return out.infer_nchw(h)                           # no-grad: the last conv writes the public NCHW fp32 map itself

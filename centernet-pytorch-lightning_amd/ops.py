@@ -1350,6 +1350,23 @@ def conv1x1_to_nchw(h, wp, bias, C):
     return out
 
 
+def head2_infer(x, hidden, out):
+    """No-grad 2-channel head in ONE launch (cn_head2_fwd): -> fp32 NCHW [N, 2, H, W], or None when the kernel declines the shape.
+    The hidden conv's packed weights come from its own no-grad cache (nn.Conv2d.infer_key)."""
+    N, H, W, Cx = x.shape
+    Ch = hidden.weight.shape[0]
+    if Cx != 64 or hidden.weight.shape[1] != 64 or Ch % 64 or out.weight.shape[0] != 2:
+        return None
+    c = hidden.infer_key(x)
+    y = zeros((N, 2, H, W), torch.float32, x.device)
+    w2 = out.weight.detach().reshape(2, Ch)
+    if not w2.is_contiguous():
+        w2 = w2.contiguous()
+    if _hip.try_call("cn_head2_fwd", x, c["wp"], c["b"], w2, out.bias.detach(), y, N, H, W, 64, Cx, Ch, dtype_code(x.dtype)):
+        return y
+    return None
+
+
 class SparseRows:
     """Side channel next to autograd for gradients that are dense tensors by contract but zero outside a few known pixels: the
     backward of a gather-type loss `note`s (its dense gradient map, the gathered indices); a consumer that can work on rows

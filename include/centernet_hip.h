@@ -219,6 +219,12 @@ size_t cn_dwdeconv_wgrad_ws_bytes(int N, int OH, int C);
 int cn_dwdeconv_bwd_weight_rows(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
                                 int stride, int pad, int OH, int OW, int dtype, void* stream);
 
+/* A 2-channel task head (heads.py:9-15: conv3x3 + bias -> ReLU -> conv1x1 + bias; width_height / regression) in ONE launch, no-grad
+ * path: out fp32 NCHW [N, 2, H, W] — ALL-ZERO at launch, the kernel adds — = conv1x1(relu(conv3x3(x) + b1)) + b2; x NHWC bf16, Ci = 64,
+ * wp1 = cn_pack_weight(hidden weight, mode 1), w2 fp32 [2][Ch] (the 1x1 weight as stored), Ch a multiple of 64.  The hidden activation
+ * (537 MB at bs 64, 128x128) is never written or re-read.  CN_EUNSUPPORTED when the weight-stationary kernel declines the shape. */
+int cn_head2_fwd(const void* x, const void* wp1, const float* b1, const float* w2, const float* b2, float* out, int N, int H, int W,
+                 int Ci, int x_ld, int Ch, int dtype, void* stream);
 /* A head's last layer (heads.py:15-17: nn.Conv2d(head_conv, out_channels, 1) on the hidden activation) straight into the public
  * layout: y fp32 NCHW [N,Co,H,W] = conv1x1(x) + bias, x [N,H,W,x_ld] in `dtype`, wp = cn_pack_weight(mode 1).  Replaces
  * cn_conv2d_fwd (NHWC bf16 out) + cn_nhwc_to_nchw.  bf16, Ci == 256, Co <= 128, H*W % 32 == 0, N*H*W >= 65536; anything else

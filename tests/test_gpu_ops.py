@@ -230,6 +230,40 @@ def test_conv1x1_streaming_relu_mask():
     close(dx.float().cpu().reshape(-1, Ci), ref, dt, "1x1 stream relu mask")
 
 
+@pytest.mark.parametrize("cfg", [(4, 32, 64), (2, 48, 32), (9, 16, 16)])
+def test_two_channel_head_in_one_launch(cfg, monkeypatch):
+    """No-grad `HeadConv` with two output channels (width_height / regression; heads.py:9-15) through cn_head2_fwd — the weight-
+    stationary 3x3 kernel with the ReLU and the 1x1 conv in its epilogue, 8 partial sums per pixel met by fp32 atomics, no hidden
+    tensor — against the two-launch path (CN_DISABLE_HEAD2) and against torch fp32 on bf16-rounded operands.  The fused path does NOT
+    round the hidden activation to bf16, so it is the closer of the two to torch; three runs agree to the summation order."""
+    from centernet_amd.models.heads import HeadConv
+    import centernet_amd.models.heads as heads_mod
+    N, H, W = cfg
+    dt = torch.bfloat16
+    head = HeadConv(2, 64, 256).to(DEV)
+    with torch.no_grad():
+        head.fc[0].weight.copy_(rnd(rng.t_normal(21, f"w1{cfg}", (256, 64, 3, 3), 0, (2.0 / 576) ** 0.5), dt))
+        head.fc[0].bias.copy_(rng.t_normal(21, "b1", (256,), 0, 0.1))
+        head.fc[2].weight.copy_(rng.t_normal(21, f"w2{cfg}", (2, 256, 1, 1), 0, 0.05))
+        head.fc[2].bias.copy_(rng.t_normal(21, "b2", (2,), 0, 0.5))
+    x = rng.t_normal(21, f"x{cfg}", (N, 64, H, W))
+    xr = rnd(x, dt)
+    ref = F.conv2d(F.relu(F.conv2d(xr, head.fc[0].weight.float().cpu(), head.fc[0].bias.cpu(), 1, 1)), head.fc[2].weight.cpu(), head.fc[2].bias.cpu())
+    xg = ops().mark_nhwc(to_nhwc(x, dt), 64)
+    monkeypatch.setenv("CN_CONV_WS_FORCE", "8")
+    with torch.no_grad():
+        fused = [head(xg).float().cpu() for _ in range(3)]
+        monkeypatch.setattr(heads_mod, "_NO_HEAD2", True)
+        two = head(xg).float().cpu()
+    assert fused[0].shape == (N, 2, H, W) and two.shape == (N, 2, H, W)
+    sc = float(ref.abs().max())
+    assert float((fused[0] - ref).abs().max()) <= 4e-3 * sc, "fused head vs torch"
+    assert float((two - ref).abs().max()) <= 1.5e-2 * sc, "two-launch head vs torch (hidden rounded to bf16)"
+    assert float((fused[0] - ref).abs().max()) <= float((two - ref).abs().max()) + 1e-6
+    for f2 in fused[1:]:
+        assert float((f2 - fused[0]).abs().max()) <= 1e-5 * sc, "runs differ only by the order of the eight fp32 partial sums"
+
+
 KP_CONVS = [  # N,H,W,Ci,Co,bias,relu,force: >= 128 input channels on 16-aligned maps -> the K-pipelined persistent kernel (conv3x3_kp.hip)
     (4, 32, 32, 128, 128, False, False, 8),    # two channel slices, two tiles per workgroup at 8 workgroups: deferred epilogue + cross-tile prefetch
     (3, 16, 48, 256, 128, True, True, 8),      # four slices, bias + ReLU, nine tiles over eight workgroups (one gets two)
