@@ -29,7 +29,10 @@ __global__ __launch_bounds__(256) void head_sparse_gather_kernel(const T* __rest
                                                                  const int64_t* __restrict__ ind, const float* __restrict__ dout,
                                                                  const float* __restrict__ w2, T* __restrict__ hg, T* __restrict__ dhc,
                                                                  T* __restrict__ xg, T* __restrict__ gq, int M, int C, int H, int W,
-                                                                 int Ch, int h_ld, int Ci, int x_ld, int Cq) {
+                                                                 int Ch, int h_ld, int Ci, int x_ld, int Cq, int mode) {
+    // mode 0: h is the dense hidden activation [B, H, W, h_ld]; everything is written.  mode 1: no hidden activation exists (the head's
+    // forward was the one-launch cn_head2_fwd): only the input patches xg and the output-gradient rows gq.  mode 2: h holds the hidden ROWS
+    // [R, h_ld] recomputed from xg; only the masked hidden gradient dhc is written.
     __shared__ float gs[HS_MAXC];
     __shared__ int dup;
     const int r = blockIdx.x, tid = threadIdx.x;
@@ -48,15 +51,19 @@ __global__ __launch_bounds__(256) void head_sparse_gather_kernel(const T* __rest
     const bool active = dup == 0;
     if (tid < C) gs[tid] = active ? dout[((int64_t)b * C + tid) * HW + pos] : 0.f;
     __syncthreads();
-    for (int c = tid; c < Cq; c += 256) gq[(int64_t)r * Cq + c] = from_f<T>(c < C ? gs[c] : 0.f);
-    const T* hrow = h + ((int64_t)b * HW + pos) * h_ld;
-    for (int t = tid; t < Ch; t += 256) {
-        const T hv = hrow[t];
-        float s = 0.f;
-        for (int c = 0; c < C; ++c) s = fmaf(gs[c], w2[(int64_t)c * Ch + t], s);
-        hg[(int64_t)r * Ch + t] = hv;
-        dhc[(int64_t)r * Ch + t] = from_f<T>(to_f<T>(hv) > 0.f ? s : 0.f);
+    if (mode != 2)
+        for (int c = tid; c < Cq; c += 256) gq[(int64_t)r * Cq + c] = from_f<T>(c < C ? gs[c] : 0.f);
+    if (mode != 1) {
+        const T* hrow = mode == 2 ? h + (int64_t)r * h_ld : h + ((int64_t)b * HW + pos) * h_ld;
+        for (int t = tid; t < Ch; t += 256) {
+            const T hv = hrow[t];
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) s = fmaf(gs[c], w2[(int64_t)c * Ch + t], s);
+            if (mode == 0) hg[(int64_t)r * Ch + t] = hv;
+            dhc[(int64_t)r * Ch + t] = from_f<T>(to_f<T>(hv) > 0.f ? s : 0.f);
+        }
     }
+    if (mode == 2) return;
     const int py = (int)(pos / W), px = (int)(pos - (int64_t)py * W);
     const int K = 9 * Ci;
     for (int k = tid; k < K; k += 256) {
@@ -105,17 +112,31 @@ __global__ __launch_bounds__(256) void scatter3x3_add_kernel(const float* __rest
     }
 }
 
-extern "C" int cn_head_sparse_gather(const void* h, const void* x, const int64_t* ind, const float* dout, const float* w2, void* hg,
-                                     void* dhc, void* xg, void* gq, int B, int M, int C, int H, int W, int Ch, int h_ld, int Ci,
-                                     int x_ld, int Cq, int dtype, void* stream) {
-    CN_CHECK_ARG(h && x && ind && dout && w2 && hg && dhc && xg && gq && B > 0 && M > 0 && C > 0 && H > 0 && W > 0 && Ch > 0 && Ci > 0 &&
-                     h_ld >= Ch && x_ld >= Ci && Cq >= C, "cn_head_sparse_gather: bad args");
+static int head_sparse_gather(const void* h, const void* x, const int64_t* ind, const float* dout, const float* w2, void* hg, void* dhc,
+                              void* xg, void* gq, int B, int M, int C, int H, int W, int Ch, int h_ld, int Ci, int x_ld, int Cq, int mode,
+                              int dtype, void* stream) {
+    CN_CHECK_ARG(x && ind && dout && w2 && B > 0 && M > 0 && C > 0 && H > 0 && W > 0 && Ch > 0 && Ci > 0 && h_ld >= Ch && x_ld >= Ci &&
+                     Cq >= C && (unsigned)mode <= 2u, "cn_head_sparse_gather: bad args");
+    CN_CHECK_ARG((mode == 1 || (h && dhc)) && (mode == 2 || (xg && gq)) && (mode != 0 || hg), "cn_head_sparse_gather: null operand for mode %d", mode);
     if (C > HS_MAXC) CN_UNSUPPORTED("cn_head_sparse_gather: C <= %d (got %d)", HS_MAXC, C);
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(head_sparse_gather_kernel<T>, dim3(B * M), dim3(256), 0, (hipStream_t)stream,
                                                   (const T*)h, (const T*)x, ind, dout, w2, (T*)hg, (T*)dhc, (T*)xg, (T*)gq, M, C, H, W, Ch,
-                                                  h_ld, Ci, x_ld, Cq));
+                                                  h_ld, Ci, x_ld, Cq, mode));
     CN_LAUNCH_CHECK("cn_head_sparse_gather");
     return CN_OK;
+}
+extern "C" int cn_head_sparse_gather(const void* h, const void* x, const int64_t* ind, const float* dout, const float* w2, void* hg,
+                                     void* dhc, void* xg, void* gq, int B, int M, int C, int H, int W, int Ch, int h_ld, int Ci,
+                                     int x_ld, int Cq, int dtype, void* stream) {
+    return head_sparse_gather(h, x, ind, dout, w2, hg, dhc, xg, gq, B, M, C, H, W, Ch, h_ld, Ci, x_ld, Cq, 0, dtype, stream);
+}
+// the two halves of the same gather for a head whose forward never stored its hidden activation (cn_head2_fwd): mode 1 = input patches
+// xg + output-gradient rows gq (h, hg, dhc unused); mode 2 = h holds the hidden ROWS [B*M, h_ld] recomputed from xg, dhc is written
+extern "C" int cn_head_sparse_gather_rows(const void* h, const void* x, const int64_t* ind, const float* dout, const float* w2, void* dhc,
+                                          void* xg, void* gq, int B, int M, int C, int H, int W, int Ch, int h_ld, int Ci, int x_ld, int Cq,
+                                          int mode, int dtype, void* stream) {
+    CN_CHECK_ARG(mode == 1 || mode == 2, "cn_head_sparse_gather_rows: mode 1 or 2");
+    return head_sparse_gather(h, x, ind, dout, w2, nullptr, dhc, xg, gq, B, M, C, H, W, Ch, h_ld, Ci, x_ld, Cq, mode, dtype, stream);
 }
 
 extern "C" int cn_scatter3x3_add(const float* dxc, const int64_t* ind, void* dx, int B, int M, int H, int W, int Ci, int dx_ld,

@@ -1430,6 +1430,7 @@ class HeadFn(Function):
     nodes ran).  The sums are the reference's (heads.py under autograd), taken in a different order."""
 
     sparse_runs = 0       # backward passes that took the row path (tests / profiling)
+    fused2 = not _os.environ.get("CN_DISABLE_HEAD2")      # A/B: 2-channel heads through the one-launch forward (cn_head2_fwd)
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -1437,9 +1438,22 @@ class HeadFn(Function):
         C = w2.shape[0]
         N, H, W, Cx = x.shape
         assert (KH, KW) == (3, 3) and tuple(w2.shape[1:]) == (Ch, 1, 1) and Cx == rup(Ci, 16)
-        h = _igemm(x, pack_weight(w1, 1, x.dtype), b1, None, Ch, 3, 3, 1, 1, False, True, H, W)
-        out = conv1x1_to_nchw(h, pack_weight(w2, 1, x.dtype), b2, C)
-        ctx.save_for_backward(x, h, w1, w2)
+        wp1 = pack_weight(w1, 1, x.dtype)
+        h = out = None
+        if (HeadFn.fused2 and C == 2 and x.dtype == torch.bfloat16 and Ci == 64 and Cx == 64 and Ch % 64 == 0 and b1 is not None
+                and b2 is not None):
+            # a 2-channel head (width_height / regression) in ONE launch: ReLU + 1x1 in the 3x3 kernel's epilogue, the hidden
+            # activation (537 MB at C3) is never stored; its backward recomputes the few hidden rows it needs from the input patches
+            w2c = w2.detach().reshape(2, Ch)
+            out = zeros((N, 2, H, W), torch.float32, x.device)
+            if not _hip.try_call("cn_head2_fwd", x, wp1, b1.detach(), w2c if w2c.is_contiguous() else w2c.contiguous(), b2.detach(), out,
+                                 N, H, W, 64, Cx, Ch, dtype_code(x.dtype)):
+                out = None
+        if out is None:
+            h = _igemm(x, wp1, b1, None, Ch, 3, 3, 1, 1, False, True, H, W)
+            out = conv1x1_to_nchw(h, pack_weight(w2, 1, x.dtype), b2, C)
+        ctx.has_h = h is not None
+        ctx.save_for_backward(x, h if h is not None else x.new_empty(0), w1, w2)
         ctx.refs = (b1, b2)
         ctx.ld2 = rup(C, 16)
         ctx.orders = (SideGrads.next_order(), SideGrads.next_order())
@@ -1456,8 +1470,10 @@ class HeadFn(Function):
         C = w2.shape[0]
         ind = SparseRows.take(g)
         if (ind is not None and g.dtype == torch.float32 and g.is_contiguous() and ind.shape[0] == N and C <= 64 and Cx == Ci
-                and h.shape[-1] == Ch and 4 * ind.shape[1] <= H * W):
+                and (not ctx.has_h or h.shape[-1] == Ch) and 4 * ind.shape[1] <= H * W):
             return HeadFn._backward_rows(ctx, g, ind.contiguous())
+        if not ctx.has_h:      # dense gradient behind a one-launch forward (not a gather-type loss): the hidden activation is recomputed
+            h = _igemm(x, pack_weight(w1, 1, x.dtype), b1.detach(), None, Ch, 3, 3, 1, 1, False, True, H, W)
         dyn = DualLayout.take(g)          # the loss's backward may have left the map in this layout already (SigmoidFocalFn)
         if dyn is None or dyn.dtype != x.dtype or tuple(dyn.shape) != (N, H, W, ctx.ld2):
             dyn = torch.empty((N, H, W, ctx.ld2), dtype=x.dtype, device=x.device)
@@ -1478,12 +1494,19 @@ class HeadFn(Function):
         C, M = w2.shape[0], ind.shape[1]
         R, K, Cq, dt = N * M, 9 * Ci, rup(C, 16), x.dtype
         HeadFn.sparse_runs += 1
-        hg = torch.empty((1, 1, R, Ch), dtype=dt, device=x.device)
         dhc = torch.empty((1, 1, R, Ch), dtype=dt, device=x.device)
         xg = torch.empty((1, 1, R, K), dtype=dt, device=x.device)
         gq = torch.empty((1, 1, R, Cq), dtype=dt, device=x.device)
-        call("cn_head_sparse_gather", h, x, ind, g, w2.detach().contiguous(), hg, dhc, xg, gq, N, M, C, H, W, Ch, h.shape[-1], Ci, Cx,
-             Cq, dtype_code(dt))
+        w2c = w2.detach().contiguous()
+        if ctx.has_h:
+            hg = torch.empty((1, 1, R, Ch), dtype=dt, device=x.device)
+            call("cn_head_sparse_gather", h, x, ind, g, w2c, hg, dhc, xg, gq, N, M, C, H, W, Ch, h.shape[-1], Ci, Cx, Cq, dtype_code(dt))
+        else:
+            # no hidden activation was stored: patches first, the R hidden rows relu(patch W1^T + b1) as a 1x1 convolution over R
+            # "pixels" (w1 read as [Ch, Ci*9], the patches' own column order), then the masked hidden gradient
+            call("cn_head_sparse_gather_rows", None, x, ind, g, w2c, None, xg, gq, N, M, C, H, W, Ch, Ch, Ci, Cx, Cq, 1, dtype_code(dt))
+            hg = _igemm(xg, pack_weight(w1.detach().view(Ch, K, 1, 1), 1, dt), b1.detach(), None, Ch, 1, 1, 1, 0, False, True, 1, R)
+            call("cn_head_sparse_gather_rows", hg, x, ind, g, w2c, dhc, None, None, N, M, C, H, W, Ch, hg.shape[-1], Ci, Cx, Cq, 2, dtype_code(dt))
         dw1 = db1 = dw2 = db2 = dx = None
         if need[1] or need[3]:
             if SideGrads.usable(w1, b1, w2, b2):

@@ -345,6 +345,12 @@ int cn_weighted_sum_bwd(const float* g, float w0, float w1, float w2, float w3, 
 int cn_head_sparse_gather(const void* h, const void* x, const int64_t* ind, const float* dout, const float* w2, void* hg, void* dhc,
                           void* xg, void* gq, int B, int M, int C, int H, int W, int Ch, int h_ld, int Ci, int x_ld, int Cq, int dtype,
                           void* stream);
+/* the same gather in two halves for a head whose forward was the one-launch cn_head2_fwd (no hidden activation stored): mode 1 writes
+ * the 3x3 input patches xg and the output-gradient rows gq (h and dhc unused, may be NULL); the caller recomputes the hidden rows
+ * relu(xg W1^T + b1) with the 1x1 entry points; mode 2 takes those rows as h [B*M, h_ld] and writes the masked hidden gradient dhc. */
+int cn_head_sparse_gather_rows(const void* h, const void* x, const int64_t* ind, const float* dout, const float* w2, void* dhc, void* xg,
+                               void* gq, int B, int M, int C, int H, int W, int Ch, int h_ld, int Ci, int x_ld, int Cq, int mode,
+                               int dtype, void* stream);
 /* dx[b, p + (kh-1, kw-1), ci] += dxc[r, ci*9 + kh*3 + kw] for p = ind[r] (r = b*M + m), taps outside the image dropped; dx
  * [B,H,W,dx_ld] in `dtype` (fp32: atomic add; bf16: compare-and-swap on the containing word), dxc fp32 [R, 9*Ci]. */
 int cn_scatter3x3_add(const float* dxc, const int64_t* ind, void* dx, int B, int M, int H, int W, int Ci, int dx_ld, int dtype,

@@ -976,6 +976,46 @@ def test_head_backward_on_gathered_rows(dt, C, M, hw):
         assert err < tol, (name, err)
 
 
+@pytest.mark.parametrize("dense", [False, True])
+def test_two_channel_head_one_launch_forward_trains(dense, monkeypatch):
+    """A 2-channel bf16 head whose FORWARD is the one-launch cn_head2_fwd (no hidden activation stored): under a gather-type loss the
+    backward recomputes the R hidden rows from the gathered input patches (cn_head_sparse_gather_rows modes 1 / 2 + a 1x1 GEMM); under
+    a dense gradient it recomputes the hidden activation — both against torch's dense autograd of the same head."""
+    from centernet_amd import ops
+    from centernet_amd.utils.losses import RegL1Loss
+    B, Ci, Ch, C, M, hw = 4, 64, 256, 2, 24, 32
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(B, Ci, hw, hw, generator=g)).bfloat16().float()
+    w1 = (torch.randn(Ch, Ci, 3, 3, generator=g) * 0.05).bfloat16().float()
+    b1 = torch.randn(Ch, generator=g) * 0.1
+    w2 = (torch.randn(C, Ch, 1, 1, generator=g) * 0.1).bfloat16().float()
+    b2 = torch.randn(C, generator=g) * 0.1
+    ind = torch.randint(0, hw * hw, (B, M), generator=g)
+    ind[:, 0], ind[:, 1], ind[:, 3] = 0, hw * hw - 1, ind[:, 2]
+    mask = torch.rand(B, M, generator=g) > 0.3
+    target = torch.randn(B, M, C, generator=g)
+    xr, w1r, b1r, w2r, b2r = (t.clone().requires_grad_() for t in (x, w1, b1, w2, b2))
+    outr = F.conv2d(F.relu(F.conv2d(xr, w1r, b1r, 1, 1)), w2r, b2r)
+    lr = _head_reference(xr, w1r, b1r, w2r, b2r, ind, mask, target) + ((0.05 * (outr * outr).sum()) if dense else 0.0)
+    lr.backward()
+    monkeypatch.setenv("CN_CONV_WS_FORCE", "8")          # the weight-stationary kernel takes this small problem
+    xd = x.to(DEV).requires_grad_()
+    params = [t.to(DEV).requires_grad_() for t in (w1, b1, w2, b2)]
+    xn = ops.FromNCHWFn.apply(xd, torch.bfloat16)
+    before = ops.HeadFn.sparse_runs
+    out = ops.HeadFn.apply(xn, *params)
+    assert out.grad_fn is not None and len(out.grad_fn.saved_tensors[1].shape) == 1, "the forward stored a hidden activation"
+    close(out, outr, torch.bfloat16, "one-launch head forward")
+    loss = RegL1Loss()(out, mask.to(DEV), ind.to(DEV), target.to(DEV)) + ((0.05 * (out * out).sum()) if dense else 0.0)
+    loss.backward()
+    assert ops.HeadFn.sparse_runs == before + (0 if dense else 1)
+    assert float(loss) == pytest.approx(float(lr), rel=2e-2)
+    for name, got, ref in [("x", xd.grad, xr.grad), ("w1", params[0].grad, w1r.grad), ("b1", params[1].grad, b1r.grad),
+                           ("w2", params[2].grad, w2r.grad), ("b2", params[3].grad, b2r.grad)]:
+        err = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 5e-2, (name, err)
+
+
 def test_head_backward_dense_fallback_matches_rows():
     """A gradient HeadFn cannot tie to a gather (here: the same map plus a dense term) takes the dense path; both paths agree."""
     from centernet_amd import ops
