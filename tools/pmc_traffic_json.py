@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = "centernet-pytorch-lightning_amd/csrc/"
 # rocprofv3 kernel name pattern -> (bench.py kernel name, source file, note)
 KERNELS = {
-    "conv3x3s1_kernel<unsigned short, 128, 64, 8>": ("conv3x3s1_kernel<bf16,128,64,8>", CSRC + "conv3x3.hip",
+    "conv3x3s1_kernel<unsigned short, 128, 64, 8, 1>": ("conv3x3s1_kernel<bf16,128,64,8>", CSRC + "conv3x3.hip",
                                                       "halo-tile 3x3 kernel, launch mix of the >= 128-input-channel layers and the head data gradients"),
-    "conv3x3_ws_kernel<64, false, 0, true>": ("conv3x3_ws_kernel<64>", CSRC + "conv3x3_ws.hip",
+    "conv3x3_ws_kernel<64, false, 0, true, 0>": ("conv3x3_ws_kernel<64>", CSRC + "conv3x3_ws.hip",
                                               "weight-stationary kernel, ReLU variant = the three 64->256 head convs: 134 MB in (x 1.27 halo, x 4 channel blocks through L2) + 537 MB out"),
     "dcn_bwd_dom_kernel<64>": ("dcn_bwd_dom_kernel<64>", CSRC + "dcn_fused.hip", "offset/mask gradient of the 64-output-channel DCN layers"),
     "dcn_dom_bm_kernel<64>": ("dcn_dom_bm_kernel<64>", CSRC + "dcn_dom_bm.hip", "offset/mask gradient of the DCN layers with 64 output channels (matrix-core corner dots)"),

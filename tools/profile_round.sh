@@ -17,7 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python - <<PY >> $out/pmc_traffic_raw.txt
 import sqlite3, glob
 c = sqlite3.connect(glob.glob('$out/pmc/*.db')[0])
-for pat in ('conv3x3s1_kernel<unsigned short, 128, 64, 8>', 'conv3x3_ws_kernel<64, false, 0, true>', 'dcn_dom_bm_kernel<64>', 'dcn_dx_bm_kernel<2>', 'dcn_fwd_bm_kernel<2>', 'dcn_wgrad_bm_kernel', 'topk_map128_kernel', 'bn_bwd_apply_kernel<unsigned short'):
+for pat in ('conv3x3s1_kernel<unsigned short, 128, 64, 8, 1>', 'conv3x3_ws_kernel<64, false, 0, true, 0>', 'dcn_dom_bm_kernel<64>', 'dcn_dx_bm_kernel<2>', 'dcn_fwd_bm_kernel<2>', 'dcn_wgrad_bm_kernel', 'topk_map128_kernel', 'bn_bwd_apply_kernel<unsigned short'):
     rows = c.execute("select dispatch_id, sum(value) from counters_collection where kernel_name like ? and counter_name='$c' group by dispatch_id", ('%' + pat + '%',)).fetchall()
     print('$c', pat, 'launches', len(rows), 'avg_kib', sum(r[1] for r in rows) / max(1, len(rows)))
 PY
@@ -27,6 +27,7 @@ python tools/pmc_traffic_json.py $out/pmc_traffic_raw.txt > $out/pmc_traffic.jso
 # the bench line comes AFTER the counter passes: `roofline.traffic` is read from profiles/<tag>_pmc_traffic.json (stamped with the
 # kernel source's blob hash), so the line of this run carries the traffic measured on this very tree
 cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
+[ -s $out/bench_kernel_stats.txt ] && cp $out/bench_kernel_stats.txt profiles/${tag}_bench_kernel_stats.txt    # roofline.rocprof of the line below reads it
 python bench.py --steps 20 --warmup 5 --probe-detail $out/ops_by_shape.txt > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/bench_line.json
 python tools/opbench.py decode bn conv > $out/opbench.txt 2>&1
