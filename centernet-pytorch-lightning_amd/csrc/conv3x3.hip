@@ -397,6 +397,7 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     if (g.N > 65535) return false;
     static const bool no_tile = getenv("CN_DISABLE_EPI_TILE") != nullptr, no_c16 = getenv("CN_DISABLE_CONV_C16") != nullptr;
     const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !no_tile) ? 1 : 0;
+    if (g.Ci == 16 && conv_c16r_launch(g, dtype, 1, st)) return true;     // row-walking 16-channel kernel (conv_c16.hip)
     if (dtype == CN_BF16 && g.Ci == 16 && g.Co <= 16 && g.co_pad >= 16 && !g.res && !g.res32 && !g.y_f32 &&
         (g.y_ld & 3) == 0 && g.y_ld <= 16 && (g.x_ld & 7) == 0 && !no_c16) {
         const int64_t strips = (int64_t)g.N * g.H * ((g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS));

@@ -49,7 +49,7 @@ __device__ static inline uint4 c16_fix(uint4 v, const c16_f32x2 (&sc)[4], const 
 }
 
 template <int S, int NCB, int AFF>
-__global__ __launch_bounds__(256, (AFF != 0 || NCB == 2) ? 3 : 4) void conv3x3_c16r_kernel(const ConvGeom g, int R, int sblocks, int rblocks) {
+__global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const ConvGeom g, int R, int sblocks, int rblocks) {
     CN_MAIN_PRIO_SET();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, kc = lane >> 4;
@@ -120,8 +120,13 @@ __global__ __launch_bounds__(256, (AFF != 0 || NCB == 2) ? 3 : 4) void conv3x3_c
         const int64_t rbase = img + (int64_t)ih * rowpitch;
 #pragma unroll
         for (int gq = 0; gq < CR_G; ++gq) {
-            s.a[gq] = ldg16_masked(X, rbase + colA[gq], rv0 && okA[gq]);
-            if (with_b) s.b[gq] = ldg16_masked(X, rbase + colB[gq], rvb && okB[gq]);
+            if constexpr (AFF == 0) {
+                s.a[gq] = ldg16_masked(X, rbase + colA[gq], rv0 && okA[gq]);
+                if (with_b) s.b[gq] = ldg16_masked(X, rbase + colB[gq], rvb && okB[gq]);
+            } else {                                       // masked by fix_row, after the affine map
+                s.a[gq] = ldg16(reinterpret_cast<const char*>(X) + ((rv0 && okA[gq]) ? rbase + colA[gq] : (int64_t)0));
+                if (with_b) s.b[gq] = ldg16(reinterpret_cast<const char*>(X) + ((rvb && okB[gq]) ? rbase + colB[gq] : (int64_t)0));
+            }
         }
     };
     // the affine map of a slot whose loads were issued a step ago (no-op without AFF)

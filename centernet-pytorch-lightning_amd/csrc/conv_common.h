@@ -52,6 +52,10 @@ struct ConvGeom {
     const float* head_w;
     const float* head_b;
     int head_nc;
+    // pre-affine of the INPUT (cn_conv_pre_affine_arm; conv_c16.hip): x is the raw output of the previous conv, the kernel applies
+    // x' = bf16(fma(x, pre_ss[c], pre_ss[Ci + c])) (pre_relu: max(., 0)) — that layer's training-mode BatchNorm — on the way in
+    const float* pre_ss;
+    int pre_relu;
 };
 
 template <typename T> struct Mma;
@@ -358,6 +362,7 @@ bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, con
 
 // 3x3 / stride 1 / pad 1 halo-tile kernel (conv3x3.hip); returns false when the shape is not handled there
 bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st);
+bool conv_c16r_launch(const ConvGeom& g, int dtype, int S, hipStream_t st);
 bool conv3x3s2_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3.hip: the same halo-tile skeleton for the stride-2 forward convs
 bool conv3x3_ws_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3_ws.hip: 64 input channels, weights in registers
 bool conv3x3_kp_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3_kp.hip: >= 128 input channels, both operands by LDS-DMA, phase-staggered waves

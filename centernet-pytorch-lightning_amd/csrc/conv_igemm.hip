@@ -450,11 +450,32 @@ static int dispatch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
     return 0;
 }
 
+// ---- pre-affine of the input: the consumer applies the previous layer's training-mode BatchNorm (+ ReLU) ----
+// cn_conv_pre_affine_arm(ss, C, relu) arms the next cn_conv2d_fwd / cn_conv2d_wgrad of this host thread: x is then the RAW output of
+// the previous convolution and the kernel applies x' = bf16(fma(x, ss[c], ss[C + c])) (relu: max(., 0)) — exactly what
+// cn_bn_train_fwd_sink would have stored — on the way in, so the normalised activation is never materialised (zero padding applies to
+// x').  ss = the layer's saved scale | shift (fp32 [2][C], device memory, written by cn_bn_finalize_sink earlier on the stream).
+// Only the 16-input-channel kernels have the hook (conv_c16.hip, wgrad_c16.hip): any other shape fails with CN_EUNSUPPORTED — there
+// is no fallback that would silently convolve the raw tensor.
+struct PreAffine { const float* ss; int C; int relu; };
+static thread_local PreAffine pre_affine_armed = {nullptr, 0, 0};
+PreAffine pre_affine_take() {
+    const PreAffine p = pre_affine_armed;
+    pre_affine_armed = PreAffine{nullptr, 0, 0};
+    return p;
+}
+extern "C" int cn_conv_pre_affine_arm(const float* ss, int C, int relu) {
+    CN_CHECK_ARG(ss && C > 0 && (relu == 0 || relu == 1) && ((uintptr_t)ss & 3) == 0, "cn_conv_pre_affine_arm: bad args");
+    pre_affine_armed = PreAffine{ss, C, relu};
+    return CN_OK;
+}
+
 extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                              int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
                              int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype,
                              void* stream) {
     const BnSink sink = bn_sink_take();   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm): disarmed before ANY early return
+    const PreAffine pre = pre_affine_take();
     CN_CHECK_ARG(x && wp && y, "cn_conv2d_fwd: null pointer");
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0, "cn_conv2d_fwd: bad dims");
     if (Ci % 16 != 0 || Ci <= 0) CN_UNSUPPORTED("cn_conv2d_fwd: Ci=%d must be a positive multiple of 16", Ci);
@@ -477,6 +498,19 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     // the sink is honoured by the kernels that have the hook
     if (sink.part && dtype == CN_BF16 && out_dtype == dtype && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
     if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);
+    if (pre.ss) {                         // input pre-affine: only the 16-input-channel row-walking kernel has the hook
+        CN_CHECK_ARG(pre.C == Ci, "cn_conv2d_fwd: pre-affine armed for %d channels, conv has %d", pre.C, Ci);
+        g.pre_ss = pre.ss; g.pre_relu = pre.relu;
+        if (transposed || KH != 3 || KW != 3 || pad != 1 || !conv_c16r_launch(g, dtype, stride, (hipStream_t)stream))
+            CN_UNSUPPORTED("cn_conv2d_fwd: an input pre-affine is armed but this shape has no kernel with the hook (bf16, 3x3 / pad 1, 16 input channels)");
+        CN_LAUNCH_CHECK("cn_conv2d_fwd(16 ch, pre-affine)");
+        return CN_OK;
+    }
+    if (!transposed && dtype == CN_BF16 && KH == 3 && KW == 3 && stride == 2 && pad == 1 && Ci == 16 && OH == (H - 1) / 2 + 1 && OW == (W - 1) / 2 + 1 &&
+        conv_c16r_launch(g, dtype, 2, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_conv2d_fwd(16 ch, stride 2)");
+        return CN_OK;
+    }
     if (transposed && dtype == CN_BF16 && out_dtype == dtype && KH == 3 && KW == 3 && stride == 2 && pad == 1 && ((Ci == 32 && Co == 16) || (Ci == 64 && Co == 32)) &&
         OH == 2 * H && OW == 2 * W && !bias && !residual && !relu && dgrad_s2_c32to16_launch(g, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_conv2d_fwd(dgrad s2 32->16)");

@@ -492,11 +492,15 @@ def conv_out(h, k, s, p):
 _SMALLK_WIDTHS = (64, 128, 256, 512, 1024, 2048)
 
 
-def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None, bn_stats=False):
+def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None, bn_stats=False, pre=None):
+    """pre = (ss fp32 [2][Ci], relu): x is the raw output of the previous conv; the kernel applies that layer's BN (+ ReLU) on load"""
     N, H, W, Ci = x.shape
     cp = rup(Co, 16)
     out_dtype = out_dtype or x.dtype
     y = torch.empty((N, OH, OW, cp), dtype=out_dtype, device=x.device)    # the kernels write the channel padding as zeros
+    if pre is not None:
+        if _hip.query("cn_conv_pre_affine_arm", pre[0].data_ptr(), Ci, int(pre[1])) != 0:      # taken by the launch below (unsupported shape: it raises)
+            raise RuntimeError("cn_conv_pre_affine_arm refused: " + _hip.lib().cn_last_error().decode())
     BnStats.launch(bn_stats, y, "cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
                    residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
                    dtype_code(x.dtype), dtype_code(out_dtype))

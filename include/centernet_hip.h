@@ -136,6 +136,13 @@ size_t cn_bn_workspace_bytes(int64_t npix, int C);
  * caller falls back to cn_bn_train_fwd, which reads x itself).  `part` must be all-zero when armed (slots <= 1024, use
  * cn_bn_stats_slots()); cn_bn_train_fwd_stats = cn_bn_train_fwd without the statistics pass over x: finalize from `part`
  * (handed back all-zero) + the apply pass. */
+/* Input pre-affine (training-mode BN + ReLU of the PREVIOUS layer applied by the consumer, so the normalised activation is never
+ * written: pose_dla_dcn.py:283-296 base_layer -> level0 -> level1 are conv -> BN -> ReLU chains).  cn_conv_pre_affine_arm(ss, C, relu)
+ * arms the NEXT cn_conv2d_fwd / cn_conv2d_wgrad of the calling host thread: x is then the raw output of the previous convolution and
+ * the kernel uses x' = bf16(fma(x, ss[c], ss[C + c])) (relu: max(., 0)) — bit-identical to the tensor cn_bn_train_fwd_sink would have
+ * stored — with zero padding applied to x'.  ss = fp32 [2][C] scale | shift in device memory (cn_bn_finalize_sink writes it).  Only
+ * the 16-input-channel bf16 3x3 kernels have the hook; any other shape returns CN_EUNSUPPORTED (no silent fallback on the raw tensor). */
+int cn_conv_pre_affine_arm(const float* ss, int C, int relu);
 int cn_bn_stats_slots(void);
 int cn_bn_stats_arm(float* part, int slots, int C);
 int cn_bn_stats_taken(void);

@@ -46,6 +46,8 @@ CONVS = [  # N,H,W,Ci,Co,k,s,p,bias,relu
     (2, 16, 16, 16, 16, 3, 1, 1, False, False),
     (2, 9, 70, 16, 16, 3, 1, 1, True, True),       # direct 16-channel kernel, ragged row strips
     (1, 33, 129, 16, 16, 3, 1, 1, False, False),
+    (1, 70, 45, 16, 16, 3, 1, 1, True, False),      # row-walking 16-channel kernel: several ring rounds per wave, ragged last round
+    (1, 75, 45, 16, 32, 3, 2, 1, True, True),       # ... stride 2 (level1 forward), odd sizes
     (2, 17, 19, 32, 48, 3, 1, 1, True, True),
     (1, 16, 16, 64, 128, 3, 2, 1, False, False),
     (2, 38, 70, 16, 32, 3, 2, 1, False, False),     # level1 shape: its data gradient runs on dgrad_s2_c32to16_kernel<1,1>
@@ -791,7 +793,8 @@ BN_STAT_PRODUCERS = [  # kind, N, H, W, Ci, Co, k, stride  (which kernel: see th
     ("cat", 2, 8, 8, (128, 128), 128, 1, 1),  # DLA Root: conv1x1 over a concatenation
     ("dcn", 2, 12, 20, 64, 64, 3, 1),         # blend-matrix DCNv2 forward
     ("dcn", 1, 9, 7, 64, 32, 3, 1),
-    ("conv", 2, 9, 70, 16, 16, 3, 1),         # direct 16-channel kernel (DLA level0)
+    ("conv", 2, 9, 70, 16, 16, 3, 1),         # row-walking 16-channel kernel (DLA level0)
+    ("conv", 2, 38, 70, 16, 32, 3, 2),        # ... stride 2, two output-channel blocks (DLA level1)
     ("stem", 2, 37, 41, 3, 16, 7, 1),         # 7x7 stem on the NCHW fp32 image (DLA base_layer)
 ]
 
@@ -853,6 +856,35 @@ def test_bn_statistics_from_the_producer_epilogue(cfg, fused, monkeypatch):
     close(ga[0], gb[0], dt, "BN backward dx", scale=float(gb[0].float().abs().max()))
     for u, v, nm in ((ga[1], gb[1], "dgamma"), (ga[2], gb[2], "dbeta")):
         assert float((u - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, nm
+
+
+@pytest.mark.parametrize("cfg", [(2, 40, 70, 16, 1, True), (1, 75, 45, 32, 2, True), (2, 9, 33, 16, 1, False)])
+def test_conv_applies_previous_bn_on_load(cfg):
+    """cn_conv_pre_affine_arm: the 16-input-channel kernels take the RAW output of the previous conv and apply that layer's BN
+    (+ ReLU) on the way into the matrix cores; the result must be BIT-identical to convolving the tensor cn_scale_shift_act stores
+    (same fma, same rounding, zero padding after the affine map).  Shapes without the hook must fail loudly."""
+    o = ops()
+    N, H, W, Co, stride, relu = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, 16, generator=g).to(dt).to(DEV)
+    ss = torch.cat([torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.5]).to(DEV).contiguous()
+    w = (torch.randn(Co, 16, 3, 3, generator=g) * 0.1).to(DEV)
+    wp = o.pack_weight(w, 1, dt)
+    OH, OW = o.conv_out(H, 3, stride, 1), o.conv_out(W, 3, stride, 1)
+    act = torch.empty_like(x)
+    o.call("cn_scale_shift_act", x, None, act, ss[:16].contiguous(), ss[16:].contiguous(), N * H * W, 16, int(relu), o.dtype_code(dt))
+    ref = o._igemm(act, wp, None, None, Co, 3, 3, stride, 1, False, False, OH, OW)
+    got = o._igemm(x, wp, None, None, Co, 3, 3, stride, 1, False, False, OH, OW, pre=(ss, relu))
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    x64 = torch.randn(1, 8, 8, 64, generator=g).to(dt).to(DEV)
+    w64 = o.pack_weight(torch.randn(64, 64, 3, 3, generator=g).to(DEV), 1, dt)
+    ss64 = torch.ones(128, device=DEV)
+    with pytest.raises(RuntimeError, match="pre-affine"):
+        o._igemm(x64, w64, None, None, 64, 3, 3, 1, 1, False, False, 8, 8, pre=(ss64, True))
+    y = o._igemm(x64, w64, None, None, 64, 3, 3, 1, 1, False, False, 8, 8)      # the failed launch disarmed it
+    assert torch.isfinite(y.float()).all()
 
 
 def test_bn_statistics_hook_can_be_declined(monkeypatch):
