@@ -564,6 +564,20 @@ extern "C" int cn_bn_train_fwd_stats(const void* x, const void* residual, void* 
     return CN_OK;
 }
 
+// The statistics half of cn_bn_train_fwd_stats on its own: finalize from `part` (batch mean / invstd, running-stat update, scale | shift
+// into save_scale_shift[2][C]) with NO apply pass — the consumer of x applies the affine map itself (cn_conv_pre_affine_arm).
+// `part` is handed back all-zero.
+extern "C" int cn_bn_finalize_sink(float* part, int slots, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   float* save_mean, float* save_invstd, float* save_scale_shift, int64_t npix, int C, float momentum,
+                                   float eps, void* stream) {
+    CN_CHECK_ARG(part && gamma && beta && save_mean && save_invstd && save_scale_shift && npix > 0 && C > 0 && slots > 0 && slots <= BN_MAX_BLOCKS,
+                 "cn_bn_finalize_sink: bad args");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, part, slots, C, npix, gamma, beta,
+                       running_mean, running_var, save_mean, save_invstd, save_scale_shift, (float*)nullptr, momentum, eps, part);
+    CN_LAUNCH_CHECK("cn_bn_finalize_sink");
+    return CN_OK;
+}
+
 // cn_bn_train_fwd_stats as ONE launch: the apply kernel reduces `part` itself (see bn_sink_totals).  `part` is left as it is (the
 // caller retires it); `clear` (nullable, clear_n floats, 16-byte aligned, NOT `part`) is a retired sink this launch zeroes.
 extern "C" int cn_bn_train_fwd_sink(const void* x, const void* residual, void* y, const float* gamma, const float* beta,

@@ -77,6 +77,9 @@ __device__ static inline uint32_t pk_bf16(float a, float b) {
 struct BnSink { float* part; int slots; int C; };
 BnSink bn_sink_take();            // the sink armed for this host thread's next forward launch (disarms; {nullptr} when none)
 void bn_sink_mark_taken();        // called by a launch function whose kernel accumulates into the sink
+// input pre-affine armed for this host thread's next cn_conv2d_fwd / cn_conv2d_wgrad (cn_conv_pre_affine_arm, conv_igemm.hip)
+struct PreAffine { const float* ss; int C; int relu; };
+PreAffine pre_affine_take();      // disarms; {nullptr} when none
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {

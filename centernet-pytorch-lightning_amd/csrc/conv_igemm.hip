@@ -457,7 +457,6 @@ static int dispatch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
 // x').  ss = the layer's saved scale | shift (fp32 [2][C], device memory, written by cn_bn_finalize_sink earlier on the stream).
 // Only the 16-input-channel kernels have the hook (conv_c16.hip, wgrad_c16.hip): any other shape fails with CN_EUNSUPPORTED — there
 // is no fallback that would silently convolve the raw tensor.
-struct PreAffine { const float* ss; int C; int relu; };
 static thread_local PreAffine pre_affine_armed = {nullptr, 0, 0};
 PreAffine pre_affine_take() {
     const PreAffine p = pre_affine_armed;

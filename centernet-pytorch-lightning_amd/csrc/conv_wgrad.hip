@@ -31,7 +31,7 @@ __device__ static inline bf16x8_t tr_frag(const bf16_t* tile, int pitch, int r0,
 }
 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
-                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st);   // stem.hip
+                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st, const float* pre_ss, int pre_relu);   // stem.hip
 
 bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
                        hipStream_t st);                                                                 // conv_wgrad3x3.hip
@@ -361,6 +361,7 @@ extern "C" int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, 
 extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
                                int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                                int KH, int KW, int stride, int pad, int dtype, void* stream) {
+    const PreAffine pre = pre_affine_take();     // input pre-affine armed for this launch (cn_conv_pre_affine_arm): disarmed before any early return
     CN_CHECK_ARG(x && dy && dwp, "cn_conv2d_wgrad: null pointer");
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0 && Ci > 0, "cn_conv2d_wgrad: bad dims");
     int V = dtype == CN_F32 ? 4 : 8;
@@ -377,10 +378,13 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float*
     g.P = (int64_t)N * OH * OW;
     hipStream_t st = (hipStream_t)stream;
     bool done_small = false;
-    if (Ci <= 16 && small_wgrad_packed(x, dy, dwp, N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, st)) {
+    if (pre.ss) CN_CHECK_ARG(pre.C == Ci, "cn_conv2d_wgrad: pre-affine armed for %d channels, conv has %d", pre.C, Ci);
+    if (Ci <= 16 && small_wgrad_packed(x, dy, dwp, N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, st, pre.ss, pre.relu)) {
         CN_LAUNCH_CHECK("cn_conv2d_wgrad(small)");
         done_small = true;
     }
+    if (pre.ss && !done_small)
+        CN_UNSUPPORTED("cn_conv2d_wgrad: an input pre-affine is armed but this shape has no kernel with the hook (bf16, 3x3 / pad 1, 16 input channels)");
     if (!done_small && dtype == CN_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W &&
         wgrad3x3s1_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, st)) {
         CN_LAUNCH_CHECK("cn_conv2d_wgrad(3x3)");

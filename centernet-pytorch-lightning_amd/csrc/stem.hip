@@ -188,18 +188,19 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 
 // used by cn_conv2d_wgrad for Ci <= 16 (packed output layout dwp[co][tap*Ci + ci])
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                           int stride, int OH, int OW, hipStream_t st);
+                           int stride, int OH, int OW, hipStream_t st, const float* pre_ss, int pre_relu);
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
                            int OH, int OW, hipStream_t st);
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
                       int stride, int OH, int OW, float* bn_part, int bn_slots, hipStream_t st);
 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
-                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st) {
+                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st, const float* pre_ss, int pre_relu) {
     if (Ci > 16) return false;
     if (dtype == CN_BF16 && KH == 3 && KW == 3 && pad == 1 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
-        wgrad_c16_nhwc_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, stride, OH, OW, st))
+        wgrad_c16_nhwc_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, stride, OH, OW, st, pre_ss, pre_relu))
         return true;
+    if (pre_ss) return false;                    // only the MFMA kernel above has the pre-affine hook
     if (dtype == CN_F32)
         return launch_small_wgrad<float>(x, false, (const float*)dy, dwp, N, Ci, x_ld, H, W, Co, dy_ld, KH, KW, stride, pad, OH, OW,
                                          KH * KW * Ci, 1, Ci, st);

@@ -29,6 +29,7 @@ struct WgC16Geom {
     int N, H, W, Ci, x_ld, Co, dy_ld, OH, OW;      // dy is [N][OH][OW][dy_ld]; a launch's grid.y walks 16-channel blocks of Co
     int os_co, os_ci, os_tap;          // dw[co*os_co + ci*os_ci + (kh*KW+kw)*os_tap]
     int tiles_h, tiles_w, iters;
+    const float* pre_ss; int pre_relu;   // input pre-affine (cn_conv_pre_affine_arm): x' = bf16(fma(x, ss[c], ss[16 + c])), relu: max(., 0); padding stays 0
 };
 
 // 8 consecutive K (pixel) values of 16 columns out of a pixel-major LDS tile: rows are LDS element offsets row_of(k)
@@ -42,8 +43,9 @@ __device__ static inline bf16x8_t tr_frag_k32(const bf16_t* tile, int lane, RowF
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int XPIX, int KH, int KW, int S = 1>
+template <int XPIX, int KH, int KW, int S = 1, bool AFF = false>
 __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
+    static_assert(!AFF || XPIX == 16, "the pre-affine is for the NHWC bf16 input");
     constexpr int PAD = KH / 2;
     constexpr int HH = (C16_TH - 1) * S + KH;
     constexpr int KWG = XPIX == 16 ? KW : (KW + 3) / 4;                       // MFMA column groups per kernel row
@@ -71,6 +73,17 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     uint4 rdy[DYV];
     uint4 rx16[XPIX == 16 ? XV : 1];
     float rx4[XPIX == 4 ? XV : 1][3];
+    uint32_t okm = 0;                                   // AFF: which of this lane's halo vectors lie inside the image (the others stay zero)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef short s16x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ sc[4], sh[4];                                // this lane's 8 channels: 8 (lane & 1) .. +7
+    if constexpr (AFF) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = f32x2_{g.pre_ss[(lane & 1) * 8 + 2 * i], g.pre_ss[(lane & 1) * 8 + 2 * i + 1]};
+            sh[i] = f32x2_{g.pre_ss[16 + (lane & 1) * 8 + 2 * i], g.pre_ss[16 + (lane & 1) * 8 + 2 * i + 1]};
+        }
+    }
 
     auto gload = [&](int64_t tile) {
         const bool tv = tile < ntiles;
@@ -87,6 +100,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
             rdy[v] = ldg16_masked(g.dy, ((((int64_t)n * g.OH + oh) * g.OW + ow) * g.dy_ld + co0 + hf * 8) * 2, ok);
         }
         if constexpr (XPIX == 16) {
+            okm = 0;
 #pragma unroll
             for (int v = 0; v < XV; ++v) {
                 const int idx = lane + v * 64;
@@ -94,6 +108,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
                 const int ih = th0 * S - PAD + hp / HWD, iw = tw0 * S - PAD + hp % HWD;
                 const bool ok = tv && hp < HP && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
                 rx16[v] = ldg16_masked(g.x, ((((int64_t)n * g.H + ih) * g.W + iw) * g.x_ld + hf * 8) * 2, ok);
+                if (AFF && ok) okm |= 1u << v;
             }
         } else {
             const float* X = reinterpret_cast<const float*>(g.x);
@@ -118,6 +133,20 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
 #pragma unroll
             for (int v = 0; v < XV; ++v) {
                 const int idx = lane + v * 64;
+                if constexpr (AFF) {                    // the previous layer's BN (+ ReLU), as bn_fwd_apply_sink_kernel would have stored it
+                    const bool ok = (okm >> v) & 1u;
+                    const uint32_t w[4] = {rx16[v].x, rx16[v].y, rx16[v].z, rx16[v].w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2_ xv = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+                        const f32x2_ yv = __builtin_elementwise_fma(xv, sc[i], sh[i]);
+                        uint32_t pk = pk_bf16(yv[0], yv[1]);
+                        if (g.pre_relu) pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_, pk), s16x2_{0, 0}));
+                        o[i] = ok ? pk : 0u;
+                    }
+                    rx16[v] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
                 if (idx < HP * 2) *reinterpret_cast<uint4*>(xh + idx * 8) = rx16[v];
             }
         } else {
@@ -171,7 +200,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     }
 }
 
-template <int XPIX, int KH, int KW, int S = 1>
+template <int XPIX, int KH, int KW, int S = 1, bool AFF = false>
 static void launch_c16(WgC16Geom& g, hipStream_t st) {
     g.tiles_h = cdiv(g.OH, C16_TH); g.tiles_w = cdiv(g.OW, C16_TW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
@@ -179,19 +208,21 @@ static void launch_c16(WgC16Geom& g, hipStream_t st) {
     const int cap = cn_wgrad_target_blocks() / 3 < 128 ? 128 : cn_wgrad_target_blocks() / 3;   // default 512
     if (blocks > cap) blocks = cap;
     g.iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
-    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S, AFF>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
 }
 
 // bf16 NHWC x, 3x3 / stride 1|2 / pad 1, Ci == 16, Co in 16-channel blocks -> packed dwp[co][tap*16 + ci]
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                           int stride, int OH, int OW, hipStream_t st) {
+                           int stride, int OH, int OW, hipStream_t st, const float* pre_ss, int pre_relu) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
     if (disabled || Ci != 16 || (x_ld & 7) || (dy_ld & 7) || dy_ld < ((Co + 15) & ~15) || (stride != 1 && stride != 2)) return false;
     WgC16Geom g;
     g.x = x; g.dy = (const bf16_t*)dy; g.dw = dwp; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld;
     g.OH = OH; g.OW = OW;
     g.os_co = 9 * Ci; g.os_ci = 1; g.os_tap = Ci;
-    if (stride == 1) launch_c16<16, 3, 3, 1>(g, st); else launch_c16<16, 3, 3, 2>(g, st);
+    g.pre_ss = pre_ss; g.pre_relu = pre_relu;
+    if (pre_ss) { if (stride == 1) launch_c16<16, 3, 3, 1, true>(g, st); else launch_c16<16, 3, 3, 2, true>(g, st); }
+    else if (stride == 1) launch_c16<16, 3, 3, 1>(g, st); else launch_c16<16, 3, 3, 2>(g, st);
     return true;
 }
 
@@ -204,6 +235,7 @@ bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int
     g.x = x; g.dy = (const bf16_t*)dy; g.dw = dw; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = 0; g.Co = Co; g.dy_ld = dy_ld;
     g.OH = OH; g.OW = OW;
     g.os_co = Ci * 49; g.os_ci = 49; g.os_tap = 1;
+    g.pre_ss = nullptr; g.pre_relu = 0;
     if (stride == 1) launch_c16<4, 7, 7, 1>(g, st); else launch_c16<4, 7, 7, 2>(g, st);
     return true;
 }

@@ -132,17 +132,27 @@ class DLA(nn.Module):
         return nn.Sequential(*mods)
 
     @staticmethod
-    def _run_conv_level(seq, x):
+    def _takes_raw(conv):
+        """a conv whose kernels can apply the previous layer's BN + ReLU on load (16 input channels, 3x3 / pad 1)"""
+        return isinstance(conv, hnn.Conv2d) and conv.k == 3 and conv.padding == 1 and conv.weight.shape[1] == 16 and conv.bias is None
+
+    @classmethod
+    def _run_conv_level(cls, seq, x, next_conv=None):
+        """next_conv: the single consumer of this level's output when it is a conv that takes a raw input (the BN apply pass of the
+        level's last layer is then left to it)"""
         for i in range(0, len(seq), 3):
-            x = hnn.conv_bn_act(seq[i], seq[i + 1], x)
+            nxt = seq[i + 3] if i + 3 < len(seq) else next_conv
+            x = hnn.conv_bn_act(seq[i], seq[i + 1], x, defer=nxt is not None and cls._takes_raw(nxt))
         return x
 
     def forward(self, img):
-        x = hnn.stem_bn_act(self.base_layer[0], self.base_layer[1], img, self.compute_dtype)
+        # base_layer -> level0 -> level1 are plain conv -> BN -> ReLU chains on the two largest tensors of the network (16 channels
+        # at full resolution): in training their normalised activations are never stored — the next conv applies the BN on load
+        x = hnn.stem_bn_act(self.base_layer[0], self.base_layer[1], img, self.compute_dtype, defer=self._takes_raw(self.level0[0]))
         y = []
         for i in range(6):
             level = getattr(self, f"level{i}")
-            x = self._run_conv_level(level, x) if i < 2 else level(x)
+            x = self._run_conv_level(level, x, self.level1[0] if i == 0 else None) if i < 2 else level(x)
             if i >= 2:
                 x = ops.share(x)        # a level's output feeds the next level and the up path
             y.append(x)

@@ -11,7 +11,11 @@ import math
 import torch
 import torch.nn as nn
 
+import os
+
 from . import ops
+
+BN_DEFER = not os.environ.get("CN_DISABLE_BN_DEFER")     # training-mode BN of the 16-channel 512^2 layers applied by the consuming conv
 
 
 class Conv2d(nn.Module):
@@ -33,8 +37,15 @@ class Conv2d(nn.Module):
 
     def forward(self, x, relu=False, mask_dx=False, defer_relu_bwd=False, bn_stats=False):
         """bn_stats: the output goes straight into a training-mode BatchNorm2d (ops.BnStats: statistics from the conv epilogue)"""
+        pre = getattr(x, "_cn_pre", None)           # x is a raw conv output whose BN (+ ReLU) is applied by this conv's kernels (ops.BnDeferFn)
         if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
-            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu, mask_dx, defer_relu_bwd, bn_stats=bn_stats)
+            return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu, mask_dx, defer_relu_bwd, bn_stats=bn_stats, pre=pre)
+        if pre is not None:
+            c = self.infer_key(x)
+            Co, _, KH, KW = self.weight.shape
+            OH, OW = ops.conv_out(x.shape[1], KH, self.stride, self.padding), ops.conv_out(x.shape[2], KW, self.stride, self.padding)
+            y = ops._igemm(x, c["wp"], c["b"], None, Co, KH, KW, self.stride, self.padding, False, relu, OH, OW, bn_stats=bn_stats, pre=pre)
+            return ops.BnStats.pop(y) if bn_stats else y
         return self.infer(x, None, None, None, relu)
 
     def with_skip(self, x, bn_stats=False):
@@ -97,10 +108,15 @@ class BatchNorm2d(nn.BatchNorm2d):
             self._fold = (key, scale.contiguous(), shift.contiguous())
         return self._fold[1], self._fold[2]
 
-    def forward(self, x, residual=None, relu=True):
+    def forward(self, x, residual=None, relu=True, defer=False):
+        """defer: the caller guarantees that the ONLY consumer of the result is a 3x3 Conv2d with 16 input channels (DLA base_layer ->
+        level0 -> level1): the apply pass is then left to that conv's kernels (ops.BnDeferFn) when x carries its producer's statistics"""
         if self.training:
             self._pending += 1
             ops.WeightsEpoch.bump()              # running_mean / running_var are about to change through raw pointers
+            if (defer and BN_DEFER and residual is None and x.dtype == torch.bfloat16 and x.shape[-1] == 16
+                    and getattr(x, "_bn_part", None) is not None and getattr(x, "_cn_pre", None) is None):
+                return ops.batch_norm_defer(x, self, relu)
             return ops.batch_norm_act(x, self, residual, relu)
         s, b = self.folded()
         return ops.scale_shift_act(x, s, b, residual, relu)
@@ -132,10 +148,10 @@ def cat_conv_bn_act(conv, bn, xs, residual=None, relu=True):
                                conv.weight.shape[0], relu)
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True):
-    """conv -> BN -> (+residual) -> ReLU.  One fused kernel in eval/no-grad mode."""
+def conv_bn_act(conv, bn, x, residual=None, relu=True, defer=False):
+    """conv -> BN -> (+residual) -> ReLU.  One fused kernel in eval/no-grad mode.  defer: see BatchNorm2d.forward."""
     if bn.training:
-        return bn(conv(x, bn_stats=True), residual, relu)      # statistics from the conv kernel's epilogue where it has the hook
+        return bn(conv(x, bn_stats=True), residual, relu, defer)      # statistics from the conv kernel's epilogue where it has the hook
     if torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad):
         return bn(conv(x), residual, relu)          # eval-mode BN but gradients wanted: unfused affine pass
     s, b = bn.folded()
@@ -160,10 +176,10 @@ class StemConv(nn.Module):
         return ops.stem_conv_infer(img, self.weight, scale, shift, self.stride, self.padding, relu, dtype)
 
 
-def stem_bn_act(stem, bn, img, dtype, relu=True):
-    """stem conv -> BN -> ReLU; one fused kernel in eval / no-grad mode"""
+def stem_bn_act(stem, bn, img, dtype, relu=True, defer=False):
+    """stem conv -> BN -> ReLU; one fused kernel in eval / no-grad mode.  defer: see BatchNorm2d.forward."""
     if bn.training or (torch.is_grad_enabled() and stem.weight.requires_grad):
-        return bn(stem(img, dtype, bn_stats=bn.training), None, relu)
+        return bn(stem(img, dtype, bn_stats=bn.training), None, relu, defer)
     s, b = bn.folded()
     return stem.infer(img, dtype, s, b, relu)
 

@@ -499,33 +499,40 @@ def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH,
     out_dtype = out_dtype or x.dtype
     y = torch.empty((N, OH, OW, cp), dtype=out_dtype, device=x.device)    # the kernels write the channel padding as zeros
     if pre is not None:
-        if _hip.query("cn_conv_pre_affine_arm", pre[0].data_ptr(), Ci, int(pre[1])) != 0:      # taken by the launch below (unsupported shape: it raises)
-            raise RuntimeError("cn_conv_pre_affine_arm refused: " + _hip.lib().cn_last_error().decode())
+        _arm_pre(pre, Ci)                                                 # taken by the launch below (unsupported shape: it raises)
     BnStats.launch(bn_stats, y, "cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
                    residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
                    dtype_code(x.dtype), dtype_code(out_dtype))
     return y
 
 
-def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=None):
+def _arm_pre(pre, Ci):
+    """arm the input pre-affine for the NEXT cn_conv2d_fwd / cn_conv2d_wgrad of this thread (a shape without the hook then raises)"""
+    if _hip.query("cn_conv_pre_affine_arm", pre[0].data_ptr(), Ci, int(pre[1])) != 0:
+        raise RuntimeError("cn_conv_pre_affine_arm refused: " + _hip.lib().cn_last_error().decode())
+
+
+def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=None, pre=None):
     """-> (dwp fp32 [rup32(Co)][KH*KW*Ci], db fp32[Co] | None); x [N,H,W,Ci], dy [N,OH,OW,>=Co].
     `db_into`: fp32[Co] buffer the bias gradient is ACCUMULATED into (e.g. bias.grad)."""
     N, H, W, Ci = x.shape
     _, OH, OW, ld = dy.shape
     dwp = zeros((rup(Co, 32), KH * KW * Ci), torch.float32, x.device)
     db = db_into if db_into is not None else (zeros((Co,), torch.float32, x.device) if want_bias else None)
+    if pre is not None:
+        _arm_pre(pre, Ci)
     call("cn_conv2d_wgrad", x, dy, dwp, db, N, H, W, Ci, Ci, OH, OW, Co, ld, KH, KW, stride, pad, dtype_code(x.dtype))
     return dwp, db
 
 
-def _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=None, want_bias=False, db_into=None):
+def _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=None, want_bias=False, db_into=None, pre=None):
     """Weight (+ bias) gradient in PARAMETER layout: -> (dw fp32 [Co,Ci,KH,KW] — `into` when given, accumulated in place —, db).
     Shapes whose kernel has the slab form (cn_conv2d_wgrad_direct: bf16 3x3 / stride 1) need neither a pre-zeroed packed gradient
     nor an unpack launch; everything else goes through cn_conv2d_wgrad + cn_unpack_wgrad."""
     N, H, W, Cx = x.shape
     _, OH, OW, ld = dy.shape
     dt = dtype_code(x.dtype)
-    if Cx == Ci and x.dtype == torch.bfloat16:
+    if Cx == Ci and x.dtype == torch.bfloat16 and pre is None:
         n = int(_hip.query("cn_conv2d_wgrad_direct_bytes", N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW, stride, pad, dt))
         if n:
             ws = _hip.workspace(n, x.device, "wgrad_slabs")
@@ -534,7 +541,7 @@ def _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=None, want_bias=False,
             call("cn_conv2d_wgrad_direct", x, dy, dw, db, int(into is not None), ws, n, N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW,
                  stride, pad, dt)
             return dw, db
-    dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=db_into)
+    dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=db_into, pre=pre)
     if into is not None:
         return unpack_wgrad(dwp, Co, Ci, KH, KW, into=into), db
     dw = unpack_wgrad(dwp, Co, Cx, KH, KW)[:, :Ci].contiguous() if Cx != Ci else unpack_wgrad(dwp, Co, Ci, KH, KW)
@@ -546,8 +553,10 @@ class Conv2dFn(Function):
     """nn.Conv2d (+bias, +ReLU) on NHWC.  weight fp32 [Co,Ci,KH,KW]; x channels = rup(Ci,16) (zero padded)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, mask_dx=False, defer_relu_bwd=False, passthrough=False, bn_stats=False):
-        """mask_dx: x is the output of a fused-ReLU producer that was built with defer_relu_bwd=True; this layer's data
+    def forward(ctx, x, weight, bias, stride, pad, relu, mask_dx=False, defer_relu_bwd=False, passthrough=False, bn_stats=False, pre=None):
+        """pre = (ss, relu): x is the RAW output of the previous conv whose training-mode BN (+ ReLU) was deferred (BnDeferFn): the
+        forward and the weight-gradient kernels apply it on load; the data gradient is w.r.t. the normalised activation.
+        mask_dx: x is the output of a fused-ReLU producer that was built with defer_relu_bwd=True; this layer's data
         gradient is then masked by (x > 0) in its own epilogue (relu mode 2) and the producer skips its cn_relu_bwd pass.
         passthrough: also return x itself (for a residual connection around this conv): the gradient of that second use
         then arrives in THIS backward and is added in the data-gradient kernel's epilogue instead of by a separate
@@ -557,8 +566,9 @@ class Conv2dFn(Function):
         assert Cx == rup(Ci, 16), f"conv input has {Cx} channels, weight expects {Ci}"
         wp = pack_weight(weight, 1, x.dtype)
         OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
-        y = _igemm(x, wp, bias, None, Co, KH, KW, stride, pad, False, relu, OH, OW, bn_stats=bn_stats)
+        y = _igemm(x, wp, bias, None, Co, KH, KW, stride, pad, False, relu, OH, OW, bn_stats=bn_stats, pre=pre)
         ctx.save_for_backward(x, weight, y if (relu and not defer_relu_bwd) else None)
+        ctx.pre = pre
         ctx.cfg = (stride, pad, relu and not defer_relu_bwd, bias is not None)
         ctx.mask_dx = mask_dx
         ctx.bias_ref = bias
@@ -576,7 +586,7 @@ class Conv2dFn(Function):
         if dy is None:                            # only the skip path carried a gradient
             if ctx.cell is not None:
                 dskip = ctx.cell.give(dskip)
-            return dskip, None, None, None, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None, None, None, None
         stride, pad, relu, has_bias = ctx.cfg
         dy = dy.contiguous()
         if relu:
@@ -584,11 +594,11 @@ class Conv2dFn(Function):
             call("cn_relu_bwd", dy, y, g, dy.numel(), dtype_code(dy.dtype))
             dy = g
         dx, dw, db = _conv2d_bwd(x, weight, ctx.bias_ref, dy, stride, pad, has_bias, ctx.mask_dx, ctx.cell, ctx.order,
-                                 ctx.needs_input_grad[:3], dskip)
-        return dx, dw, db, None, None, None, None, None, None, None
+                                 ctx.needs_input_grad[:3], dskip, pre=ctx.pre)
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def _conv2d_bwd(x, weight, bias_ref, dy, stride, pad, has_bias, mask_dx, cell, order, needs, dskip=None):
+def _conv2d_bwd(x, weight, bias_ref, dy, stride, pad, has_bias, mask_dx, cell, order, needs, dskip=None, pre=None):
     """Backward of one NHWC convolution for the output gradient dy (ReLU already undone): -> (dx, dw, db).  Weight / bias gradients
     go to the side stream and straight into `.grad` inside a TrainStep (then dw = db = None); dx goes to x's GradCell when it has one
     (then dx = None).  needs = (dx?, dw?, db?).  Shared by Conv2dFn and HeadFn."""
@@ -597,12 +607,14 @@ def _conv2d_bwd(x, weight, bias_ref, dy, stride, pad, has_bias, mask_dx, cell, o
     dx = dw = db = None
     if needs[1] and Cx == Ci and SideGrads.usable(weight, bias_ref):
         def side_work(x=x, dy=dy, bias=bias_ref):
-            _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=weight.grad, db_into=bias.grad if has_bias else None)
+            _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=weight.grad, db_into=bias.grad if has_bias else None, pre=pre)
             GradReady.note(weight, bias)
         SideGrads.submit(SideGrads.wide_if_tail(side_work, order), x, dy, claims=(weight, bias_ref))
     elif needs[1]:
-        dw, db = _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, want_bias=has_bias and needs[2])
+        dw, db = _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, want_bias=has_bias and needs[2], pre=pre)
     if needs[0]:
+        if pre is not None and mask_dx:
+            raise RuntimeError("mask_dx on a conv whose input BN is deferred: the masks would be applied twice")
         wpd = pack_weight(weight, 0, x.dtype)          # rows = Ci, k = tap*rup(Co,16) + co
         if Cx != Ci:
             raise RuntimeError("data gradient through a channel-padded conv input is not supported")
@@ -870,6 +882,42 @@ class BatchNormActFn(Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
         run(dgamma, dbeta, 0)
         return dx, dgamma, dbeta, None, None, (cell.give(dres) if cell is not None else dres), None, None
+
+
+class BnDeferFn(Function):
+    """Training-mode BatchNorm2d (+ ReLU) whose apply pass is left to the CONSUMER: forward only finalizes the batch statistics the
+    producing kernel accumulated (`part`) and hands the raw tensor on; the consumer (a 16-input-channel 3x3 conv: its forward and its
+    weight gradient, `pre=`) computes bf16(relu(fma(x, scale, shift))) on load — bit-identical to what the apply pass would have
+    stored — so the normalised activation is never written or read.  Backward is BatchNormActFn's (ReLU mask recomputed from x and
+    the saved affine) on the gradient w.r.t. that virtual activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, part, relu):
+        C = x.shape[-1]
+        npix = x.numel() // C
+        stats = torch.empty((4, C), dtype=torch.float32, device=x.device)     # mean, invstd, scale, shift
+        call("cn_bn_finalize_sink", part, part.shape[0], gamma.detach(), beta.detach(), running_mean, running_var, stats[0], stats[1],
+             stats[2:], npix, C, BN_MOMENTUM, BN_EPS)
+        BnStats.release(part)                     # handed back all-zero
+        ctx.save_for_backward(x, None, gamma, stats)
+        ctx.beta_ref = beta
+        ctx.cfg = (relu, False)
+        ctx.res_cell = None
+        ctx.mark_non_differentiable(stats)
+        return x.view_as(x), stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats=None):
+        r = BatchNormActFn.backward(ctx, dy)
+        return r[0], r[1], r[2], None, None, None, None
+
+
+def batch_norm_defer(x, bn, relu=True):
+    """-> x itself (raw) tagged with `_cn_pre = (scale | shift, relu)` for the conv that consumes it; x must carry the statistics sink
+    of its producer (`_bn_part`)"""
+    y, stats = BnDeferFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, x._bn_part, relu)
+    y._cn_pre = (stats[2:], bool(relu))
+    return y
 
 
 class ScaleShiftActFn(Function):
@@ -1619,9 +1667,10 @@ def weighted_sum(terms, weights):
 
 
 # ------------------------------------------------------------------------------------------------ functional aliases
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, defer_relu_bwd=False, passthrough=False, bn_stats=False):
-    """bn_stats: the output feeds a training-mode BatchNorm — ask the kernel for the batch statistics (BnStats)"""
-    out = Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd, passthrough, bn_stats)
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, mask_dx=False, defer_relu_bwd=False, passthrough=False, bn_stats=False, pre=None):
+    """bn_stats: the output feeds a training-mode BatchNorm — ask the kernel for the batch statistics (BnStats);
+    pre: x is a raw conv output whose BN (+ ReLU) the kernels apply on load (batch_norm_defer)"""
+    out = Conv2dFn.apply(x, weight, bias, stride, pad, relu, mask_dx, defer_relu_bwd, passthrough, bn_stats, pre)
     if bn_stats:
         BnStats.pop(out[0] if passthrough else out)
     if passthrough and cell_of(x) is not None:

@@ -146,6 +146,11 @@ int cn_conv_pre_affine_arm(const float* ss, int C, int relu);
 int cn_bn_stats_slots(void);
 int cn_bn_stats_arm(float* part, int slots, int C);
 int cn_bn_stats_taken(void);
+/* cn_bn_finalize_sink: the statistics half of cn_bn_train_fwd_stats alone (mean / invstd / running stats / scale | shift from `part`,
+ * handed back all-zero) — no apply pass: the consumer applies the affine map on load (cn_conv_pre_affine_arm). */
+int cn_bn_finalize_sink(float* part, int slots, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                        float* save_mean, float* save_invstd, float* save_scale_shift, int64_t npix, int C, float momentum,
+                        float eps, void* stream);
 int cn_bn_train_fwd_stats(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float* save_mean, float* save_invstd,
                           float* save_scale_shift, float* part, int slots, int64_t npix, int C, float momentum, float eps,

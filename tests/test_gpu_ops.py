@@ -887,6 +887,52 @@ def test_conv_applies_previous_bn_on_load(cfg):
     assert torch.isfinite(y.float()).all()
 
 
+@pytest.mark.parametrize("grad", [True, False])
+def test_dla_base_chain_leaves_bn_apply_to_the_next_conv(grad, monkeypatch):
+    """pose_dla_dcn.py:283-296: base_layer -> level0 -> level1 = conv -> BN -> ReLU x 3 on 16-channel full-resolution tensors.  In
+    training mode the two 16-channel BN apply passes are left to the consuming conv (ops.BnDeferFn + cn_conv_pre_affine_arm): forward
+    values, running statistics and every gradient must match the unfused chain (same arithmetic; the batch statistics are reduced by
+    a different kernel, so last-bit differences of scale / shift may flip individual bf16 roundings)."""
+    from centernet_amd import nn as hnn
+    from centernet_amd.models.backbones.pose_dla_dcn import DLA
+    o = ops()
+    dt = torch.bfloat16
+    torch.manual_seed(5)
+    net = DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], compute_dtype=dt).to(DEV).train()
+    img = torch.randn(2, 3, 72, 104, device=DEV)
+
+    def run(defer):
+        monkeypatch.setattr(hnn, "BN_DEFER", defer)
+        for m in net.modules():
+            if isinstance(m, hnn.BatchNorm2d):
+                m.reset_running_stats()
+        net.zero_grad(set_to_none=True)
+        calls = []
+        real = o.batch_norm_defer
+        monkeypatch.setattr(o, "batch_norm_defer", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        with torch.set_grad_enabled(grad):
+            x = hnn.stem_bn_act(net.base_layer[0], net.base_layer[1], img, dt, defer=True)
+            x = net._run_conv_level(net.level0, x, net.level1[0])
+            x = net._run_conv_level(net.level1, x)
+        monkeypatch.setattr(o, "batch_norm_defer", real)
+        assert getattr(x, "_cn_pre", None) is None, "level1's output is a stored activation"
+        assert len(calls) == (2 if defer else 0)
+        out = {"y": x.detach().float().clone(), "rm0": net.base_layer[1].running_mean.clone(), "rv1": net.level0[1].running_var.clone()}
+        if grad:
+            g = torch.randn(x.shape, generator=torch.Generator().manual_seed(1)).to(DEV).to(dt)
+            x.backward(g)
+            for name in ("base_layer.0.weight", "base_layer.1.weight", "base_layer.1.bias", "level0.0.weight", "level0.1.weight",
+                         "level0.1.bias", "level1.0.weight", "level1.1.weight"):
+                out[name] = net.get_parameter(name).grad.detach().float().clone()
+        return out
+
+    a, b = run(True), run(False)
+    for k in b:
+        scale = float(b[k].abs().max())
+        err = float((a[k] - b[k]).abs().max()) / max(scale, 1e-6)
+        assert err < (1e-5 if k.startswith("r") else 2e-2), f"{k}: {err:.3e}"
+
+
 def test_bn_statistics_hook_can_be_declined(monkeypatch):
     """kernels without the hook (weight-stationary 3x3, fp32 compute) report `not taken`: BN then reads x itself"""
     from centernet_amd import nn as hnn
