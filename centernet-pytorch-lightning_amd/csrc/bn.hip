@@ -643,6 +643,65 @@ extern "C" int cn_bn_train_bwd_acc(const void* dy, const void* x, const void* y,
     return CN_OK;
 }
 
+// ---- BN backward for consumers that apply it on load (cn_stem_conv_wgrad_bn) ----
+// one wave per channel: totals of the sink -> dgamma / dbeta and the coefficients ca | cp | cq | sc | sh (fp32 [5][C]) of
+//   g = relu ? (fma(x, sc, sh) > 0 ? dy : 0) : dy,   dx = fma(ca, g, fma(cp, x, cq))          (bn_bwd_apply_kernel's arithmetic)
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restrict__ part, int slots, int C, int64_t npix,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ ss,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                          float* __restrict__ coef, float* __restrict__ clear, int clear_n) {
+    if (clear) {
+        const int nthr = gridDim.x * 256;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < clear_n; i += nthr) clear[i] = 0.f;
+    }
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < slots; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
+    s = wave_sum_d(s); q = wave_sum_d(q);
+    if (lane != 0) return;
+    dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+    const float is = invstd[c], mu = mean[c];
+    const float a = gamma[c] * is, b = (float)(s / (double)npix), cc = (float)(q / (double)npix);
+    const float cp = -a * cc * is;
+    coef[c] = a;
+    coef[C + c] = cp;
+    coef[2 * C + c] = -a * b - cp * mu;
+    coef[3 * C + c] = ss ? ss[c] : 0.f;
+    coef[4 * C + c] = ss ? ss[C + c] : 0.f;
+}
+
+// the statistics pass of cn_bn_train_bwd_sink alone: (sum dy', sum dy' * xhat) per channel added to `sink` (fp32 [slots][2][C], all-zero on entry)
+extern "C" int cn_bn_bwd_stats(const void* dy, const void* x, const void* y, const float* save_mean, const float* save_invstd,
+                               const float* scale_shift, float* sink, int slots, int64_t npix, int C, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(dy && x && save_mean && save_invstd && sink && npix > 0 && C > 0 && slots > 0 && slots <= BN_MAX_BLOCKS, "cn_bn_bwd_stats: bad args");
+    CN_CHECK_ARG(!relu || y || scale_shift, "cn_bn_bwd_stats: relu needs the forward output or the saved scale/shift");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0 && C % 4 == 0, "cn_bn_bwd_stats: C=%d must be a multiple of %d", C, V);
+    BnLayout L = bn_layout(npix, C, V);
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_partial_kernel<T, 1>), dim3(L.nblk, L.ycols), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)x, (const T*)dy, (const T*)y, save_mean, save_invstd, scale_shift, sink,
+                                                   npix, C, L, relu, slots));
+    CN_LAUNCH_CHECK("cn_bn_bwd_stats");
+    return CN_OK;
+}
+
+// sink -> dgamma / dbeta (accumulate != 0: added) + coef fp32 [5][C] for a consumer that applies the BN backward on load; `sink` is left
+// as it is (the caller retires it), `clear` (another, retired sink) is zeroed on the way
+extern "C" int cn_bn_bwd_coef_sink(const float* sink, int slots, const float* gamma, const float* save_mean, const float* save_invstd,
+                                   const float* scale_shift, float* dgamma, float* dbeta, int accumulate, float* coef, float* clear,
+                                   int64_t clear_n, int64_t npix, int C, void* stream) {
+    CN_CHECK_ARG(sink && gamma && save_mean && save_invstd && dgamma && dbeta && coef && npix > 0 && C > 0 && slots > 0 && slots <= BN_MAX_BLOCKS,
+                 "cn_bn_bwd_coef_sink: bad args");
+    CN_CHECK_ARG(clear != sink && clear_n >= 0 && clear_n < (1 << 30), "cn_bn_bwd_coef_sink: a launch cannot clear the sink it reads");
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, sink, slots, C, npix, gamma, save_mean,
+                       save_invstd, scale_shift, dgamma, dbeta, accumulate, coef, clear, (int)clear_n);
+    CN_LAUNCH_CHECK("cn_bn_bwd_coef_sink");
+    return CN_OK;
+}
+
 // cn_bn_train_bwd_acc as TWO launches: the statistics pass adds its per-workgroup sums to `sink` (fp32 [slots][2][C], all-zero on
 // entry, fp32 atomics: the summation order of the batch sums then varies from run to run like the forward sinks') and the apply
 // pass reduces it itself (no finalize launch).  `sink` is left as it is (the caller retires it); `clear` as in cn_bn_train_fwd_sink.
@@ -669,6 +728,28 @@ extern "C" int cn_bn_train_bwd_sink(const void* dy, const void* x, const void* y
                                                    scale_shift, (T*)dx, (T*)dres, (const T*)dres_acc, npix, C, E, relu,
                                                    (const float*)sink, slots, gamma, dgamma, dbeta, accumulate, clear, (int)clear_n));
     CN_LAUNCH_CHECK("cn_bn_train_bwd_sink(apply)");
+    return CN_OK;
+}
+
+// the apply half of cn_bn_train_bwd_sink alone: `sink` already holds the statistics (cn_bn_bwd_stats, or the epilogue of the kernel that
+// produced dy: cn_bn_bwd_stats_arm)
+extern "C" int cn_bn_train_bwd_apply(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                                     const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
+                                     float* dgamma, float* dbeta, int accumulate, const float* sink, int slots, float* clear, int64_t clear_n,
+                                     int64_t npix, int C, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(!dres_acc || dres, "cn_bn_train_bwd_apply: dres_acc without dres");
+    CN_CHECK_ARG(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && sink && npix > 0 && C > 0 && slots > 0 &&
+                     slots <= BN_MAX_BLOCKS, "cn_bn_train_bwd_apply: bad args");
+    CN_CHECK_ARG(!relu || y || scale_shift, "cn_bn_train_bwd_apply: relu needs the forward output or the saved scale/shift");
+    CN_CHECK_ARG(clear != sink && clear_n >= 0 && clear_n < (1 << 30), "cn_bn_train_bwd_apply: a launch cannot clear the sink it reads");
+    int V = dtype == CN_F32 ? 4 : 8;
+    CN_CHECK_ARG(C % V == 0 && C % 4 == 0, "cn_bn_train_bwd_apply: C=%d must be a multiple of %d", C, V);
+    BnLayout E = ew_layout(npix, C, V, sink_wg_cap());
+    CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(E.nblk, E.ycols), dim3(256), 0, (hipStream_t)stream,
+                                                   (const T*)dy, (const T*)x, (const T*)y, save_mean, save_invstd, (const float*)nullptr,
+                                                   scale_shift, (T*)dx, (T*)dres, (const T*)dres_acc, npix, C, E, relu,
+                                                   sink, slots, gamma, dgamma, dbeta, accumulate, clear, (int)clear_n));
+    CN_LAUNCH_CHECK("cn_bn_train_bwd_apply");
     return CN_OK;
 }
 

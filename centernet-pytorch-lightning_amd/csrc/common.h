@@ -77,6 +77,10 @@ __device__ static inline uint32_t pk_bf16(float a, float b) {
 struct BnSink { float* part; int slots; int C; };
 BnSink bn_sink_take();            // the sink armed for this host thread's next forward launch (disarms; {nullptr} when none)
 void bn_sink_mark_taken();        // called by a launch function whose kernel accumulates into the sink
+// BN backward statistics sink armed for this host thread's next cn_conv2d_fwd (cn_bn_bwd_stats_arm, conv_igemm.hip)
+struct BnbArm { float* part; int slots; int C; const void* x; const float* stats; int relu; };
+BnbArm bnb_take();                // disarms; {nullptr} when none
+void bnb_mark_taken();
 // input pre-affine armed for this host thread's next cn_conv2d_fwd / cn_conv2d_wgrad (cn_conv_pre_affine_arm, conv_igemm.hip)
 struct PreAffine { const float* ss; int C; int relu; };
 PreAffine pre_affine_take();      // disarms; {nullptr} when none

@@ -296,6 +296,11 @@ __global__ __launch_bounds__(256) void dgrad_s2_c32to16_kernel(const ConvGeom g)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
                 wa[nb][k][t] = __builtin_bit_cast(bf16x8_t, ldg16(Wp + (int64_t)(16 * nb + px) * g.ktot + t * CO + 32 * k + 8 * kc));
+    // BatchNorm backward statistics of the stored gradient (cn_bn_bwd_stats_arm; 16 output channels only)
+    const bool bnb = NB == 1 && g.bnb_part != nullptr;
+    BnbLane bl;
+    bnb_lane_init(bl, bnb ? g.bnb_stats : nullptr, g.y_ld, 4 * kc);
+    float bs0[4] = {0.f, 0.f, 0.f, 0.f}, bs1[4] = {0.f, 0.f, 0.f, 0.f};
     const int segs = (g.W + 15) / 16;                      // 16 dy columns -> 32 dx columns
     const int64_t strips = (int64_t)g.N * g.H * segs;      // one strip = one dy row r of one image -> dx rows 2r, 2r+1
 #pragma unroll 1
@@ -333,10 +338,22 @@ __global__ __launch_bounds__(256) void dgrad_s2_c32to16_kernel(const ConvGeom g)
             }
             auto put = [&](const f32x4_t& v, int ph, int pw) {
                 const int oh = 2 * r + ph, ow = 2 * c0 + pw;
-                if (oh < g.OH && ow < g.OW)
-                    *reinterpret_cast<uint2*>(DX + ((n * g.OH + oh) * g.OW + ow) * g.y_ld + 16 * nb + 4 * kc) = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+                if (oh < g.OH && ow < g.OW) {
+                    const uint2 o = make_uint2(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]));
+                    const int64_t at = ((n * g.OH + oh) * g.OW + ow) * g.y_ld + 16 * nb + 4 * kc;
+                    *reinterpret_cast<uint2*>(DX + at) = o;
+                    if constexpr (NB == 1) {
+                        if (bnb) bnb_lane_add(bl, o, *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.bnb_x) + at), g.bnb_relu, bs0, bs1);
+                    }
+                }
             };
             put(ee, 0, 0); put(eo, 0, 1); put(oe, 1, 0); put(oo, 1, 1);
+        }
+    }
+    if constexpr (NB == 1) {
+        if (bnb) {                                         // uniform over the workgroup
+            __shared__ float red[4 * 32];
+            bn_stats_flush_c16<256>(bs0, bs1, red, g.bnb_part, g.bnb_slots, g.y_ld, g.Co, blockIdx.x, threadIdx.x);
         }
     }
 }
@@ -348,6 +365,9 @@ bool dgrad_s2_c32to16_launch(const ConvGeom& g, hipStream_t st) {
     const int64_t strips = (int64_t)g.N * g.H * ((g.W + 15) / 16);
     int64_t blocks = (strips + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    if (g.bnb_part) {
+        if (g.Ci == 32 && g.Co == 16 && g.bnb_slots > 0) bnb_mark_taken(); else const_cast<ConvGeom&>(g).bnb_part = nullptr;
+    }
     if (g.Ci == 32 && g.Co == 16) hipLaunchKernelGGL((dgrad_s2_c32to16_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else if (g.Ci == 64 && g.Co == 32) hipLaunchKernelGGL((dgrad_s2_c32to16_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else return false;

@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
     };
 
     // BatchNorm statistics of the stored values (sink protocol of bn.hip): this lane's four channels per block over every pixel it stores
-    const bool stats = g.bn_part != nullptr;
+    const bool bnb = NCB == 1 && g.bnb_part != nullptr;   // y is a gradient w.r.t. a BN output: the BN's backward statistics instead (ConvGeom)
+    const bool stats = g.bn_part != nullptr || bnb;
+    BnbLane bl;
+    bnb_lane_init(bl, bnb ? g.bnb_stats : nullptr, g.y_ld, 4 * kc);
     float s0[NCB][4], s1[NCB][4];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -176,7 +179,10 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
                     uint2 o;
                     o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
                     *reinterpret_cast<uint2*>(Y + (yrow + ow) * g.y_ld + ch) = o;
-                    if (stats) {
+                    if (bnb) {
+                        const uint2 xq = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.bnb_x) + (yrow + ow) * g.y_ld + ch);
+                        bnb_lane_add(bl, o, xq, g.bnb_relu, s0[0], s1[0]);
+                    } else if (stats) {
                         const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
                         const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
                         s0[cb][0] += a0; s0[cb][1] += a1; s0[cb][2] += a2; s0[cb][3] += a3;
@@ -229,7 +235,8 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
         __shared__ float red[4 * 32];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
-            bn_stats_flush_c16<256>(s0[cb], s1[cb], red, g.bn_part + cb * 16, g.bn_slots, g.y_ld, g.Co - cb * 16, blockIdx.x, threadIdx.x);
+            bn_stats_flush_c16<256>(s0[cb], s1[cb], red, (bnb ? g.bnb_part : g.bn_part) + cb * 16, bnb ? g.bnb_slots : g.bn_slots, g.y_ld,
+                                    g.Co - cb * 16, blockIdx.x, threadIdx.x);
     }
 }
 
@@ -251,6 +258,9 @@ bool conv_c16r_launch(const ConvGeom& g, int dtype, int S, hipStream_t st) {
     if (blocks > 0x7fffffff) return false;
     if (g.bn_part) {
         if (g.bn_slots > 0) bn_sink_mark_taken(); else const_cast<ConvGeom&>(g).bn_part = nullptr;
+    }
+    if (g.bnb_part) {
+        if (S == 1 && g.bnb_slots > 0 && !g.bn_part) bnb_mark_taken(); else const_cast<ConvGeom&>(g).bnb_part = nullptr;
     }
     const int aff = g.pre_ss ? 1 + g.pre_relu : 0;
 #define CR_GO(S_, NCB_, AFF_) hipLaunchKernelGGL((conv3x3_c16r_kernel<S_, NCB_, AFF_>), dim3((unsigned)blocks), dim3(256), 0, st, g, R, sblocks, rblocks)

@@ -56,7 +56,38 @@ struct ConvGeom {
     // x' = bf16(fma(x, pre_ss[c], pre_ss[Ci + c])) (pre_relu: max(., 0)) — that layer's training-mode BatchNorm — on the way in
     const float* pre_ss;
     int pre_relu;
+    // BatchNorm BACKWARD statistics sink (cn_bn_bwd_stats_arm; the 16-channel data-gradient kernels have the hook): y is the gradient
+    // w.r.t. the output of a training-mode BN (+ ReLU) whose input was bnb_x (pitch y_ld); every workgroup adds, over the values it
+    // STORES, sum g and sum g * xhat (g = relu ? (fma(x, sc, sh) > 0 ? y : 0) : y, xhat = (x - mean) * invstd) to bnb_part[slots][2][y_ld]
+    float* bnb_part;
+    int bnb_slots;
+    const void* bnb_x;
+    const float* bnb_stats;   // fp32 [4][y_ld]: mean | invstd | scale | shift
+    int bnb_relu;
 };
+
+// the hook for kernels whose lanes hold 4 consecutive channels of one pixel (conv3x3_c16r_kernel, dgrad_s2_c32to16_kernel)
+struct BnbLane { float mu[4], is[4], sc[4], sh[4]; };
+__device__ static inline void bnb_lane_init(BnbLane& b, const float* __restrict__ stats, int C, int ch) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool in = stats != nullptr && ch + r < C;
+        b.mu[r] = in ? stats[ch + r] : 0.f; b.is[r] = in ? stats[C + ch + r] : 0.f;
+        b.sc[r] = in ? stats[2 * C + ch + r] : 0.f; b.sh[r] = in ? stats[3 * C + ch + r] : 0.f;
+    }
+}
+// dy, x: the 4 bf16 this lane stores / the BN input at the same position (packed pairs); bn_partial_kernel<T, 1>'s arithmetic
+__device__ static inline void bnb_lane_add(const BnbLane& b, uint2 dy, uint2 x, int relu, float (&s0)[4], float (&s1)[4]) {
+    const float gv[4] = {__uint_as_float(dy.x << 16), __uint_as_float(dy.x & 0xffff0000u), __uint_as_float(dy.y << 16), __uint_as_float(dy.y & 0xffff0000u)};
+    const float xv[4] = {__uint_as_float(x.x << 16), __uint_as_float(x.x & 0xffff0000u), __uint_as_float(x.y << 16), __uint_as_float(x.y & 0xffff0000u)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float gg = (!relu || fmaf(xv[r], b.sc[r], b.sh[r]) > 0.f) ? gv[r] : 0.f;
+        s0[r] += gg;
+        s1[r] = fmaf(gg, (xv[r] - b.mu[r]) * b.is[r], s1[r]);
+    }
+}
+
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {

@@ -463,6 +463,31 @@ PreAffine pre_affine_take() {
     pre_affine_armed = PreAffine{nullptr, 0, 0};
     return p;
 }
+// ---- BatchNorm backward statistics from the kernel that PRODUCES the gradient ----
+// cn_bn_bwd_stats_arm(sink, slots, C, x, stats, relu) arms the next cn_conv2d_fwd of this host thread (a data gradient: transposed != 0):
+// its output y is the gradient w.r.t. the output of a training-mode BN (+ ReLU) with input x (NHWC, pitch C == y_ld) and saved
+// statistics stats = fp32 [4][C] mean | invstd | scale | shift.  When the kernel it dispatches to has the hook (the 16-channel bf16
+// data-gradient kernels), it adds per channel sum g and sum g * xhat of the values it stores to sink[slots][2][C] (all-zero when armed)
+// — what cn_bn_bwd_stats would compute in a pass of its own over (y, x) — and cn_bn_bwd_stats_taken() returns 1; otherwise the sink
+// is untouched and it returns 0.
+static thread_local BnbArm bnb_armed = {nullptr, 0, 0, nullptr, nullptr, 0};
+static thread_local int bnb_taken_flag = 0;
+BnbArm bnb_take() {
+    const BnbArm b = bnb_armed;
+    bnb_armed = BnbArm{nullptr, 0, 0, nullptr, nullptr, 0};
+    bnb_taken_flag = 0;
+    return b;
+}
+void bnb_mark_taken() { bnb_taken_flag = 1; }
+extern "C" int cn_bn_bwd_stats_arm(float* sink, int slots, int C, const void* x, const float* stats, int relu) {
+    CN_CHECK_ARG(sink && slots > 0 && slots <= 1024 && C > 0 && x && stats && (relu == 0 || relu == 1) && ((uintptr_t)x & 15) == 0,
+                 "cn_bn_bwd_stats_arm: bad args");
+    bnb_armed = BnbArm{sink, slots, C, x, stats, relu};
+    bnb_taken_flag = 0;
+    return CN_OK;
+}
+extern "C" int cn_bn_bwd_stats_taken(void) { return bnb_taken_flag; }
+
 extern "C" int cn_conv_pre_affine_arm(const float* ss, int C, int relu) {
     CN_CHECK_ARG(ss && C > 0 && (relu == 0 || relu == 1) && ((uintptr_t)ss & 3) == 0, "cn_conv_pre_affine_arm: bad args");
     pre_affine_armed = PreAffine{ss, C, relu};
@@ -475,6 +500,7 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
                              void* stream) {
     const BnSink sink = bn_sink_take();   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm): disarmed before ANY early return
     const PreAffine pre = pre_affine_take();
+    const BnbArm bnb = bnb_take();
     CN_CHECK_ARG(x && wp && y, "cn_conv2d_fwd: null pointer");
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0, "cn_conv2d_fwd: bad dims");
     if (Ci % 16 != 0 || Ci <= 0) CN_UNSUPPORTED("cn_conv2d_fwd: Ci=%d must be a positive multiple of 16", Ci);
@@ -497,6 +523,9 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     // the sink is honoured by the kernels that have the hook
     if (sink.part && dtype == CN_BF16 && out_dtype == dtype && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
     if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);
+    if (bnb.part && transposed && dtype == CN_BF16 && out_dtype == dtype && bnb.C == y_ld && !sink.part) {   // honoured by the kernels that have the hook
+        g.bnb_part = bnb.part; g.bnb_slots = bnb.slots; g.bnb_x = bnb.x; g.bnb_stats = bnb.stats; g.bnb_relu = bnb.relu;
+    }
     if (pre.ss) {                         // input pre-affine: only the 16-input-channel row-walking kernel has the hook
         CN_CHECK_ARG(pre.C == Ci, "cn_conv2d_fwd: pre-affine armed for %d channels, conv has %d", pre.C, Ci);
         g.pre_ss = pre.ss; g.pre_relu = pre.relu;

@@ -190,7 +190,7 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
                            int stride, int OH, int OW, hipStream_t st, const float* pre_ss, int pre_relu);
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
-                           int OH, int OW, hipStream_t st);
+                           int OH, int OW, hipStream_t st, const void* bn_x, const float* bn_coef, int bn_relu);
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
                       int stride, int OH, int OW, float* bn_part, int bn_slots, hipStream_t st);
 
@@ -246,7 +246,7 @@ extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int
     if (rc) return rc;
     bool ok;
     if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
-        wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream))
+        wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream, nullptr, nullptr, 0))
         ok = true;
     else if (dtype == CN_F32)
         ok = launch_small_wgrad<float>(x, true, (const float*)dy, dw, N, Ci, 0, H, W, Co, Co, KH, KW, stride, pad, OH, OW,
@@ -258,5 +258,23 @@ extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int
         CN_CHECK_ARG(false, "cn_stem_conv_wgrad: bad dtype %d", dtype);
     if (!ok) CN_UNSUPPORTED("cn_stem_conv_wgrad: shape does not fit the small-channel kernel");
     CN_LAUNCH_CHECK("cn_stem_conv_wgrad");
+    return CN_OK;
+}
+
+// cn_stem_conv_wgrad THROUGH the training-mode BatchNorm (+ ReLU) that follows the stem (pose_dla_dcn.py:283-287 base_layer): dy is
+// the gradient w.r.t. the BN OUTPUT, y_raw the stem's own (raw) output, coef = fp32 [5][Co] from cn_bn_bwd_coef_sink.  The kernel
+// forms the BN input gradient on load — g = relu ? (fma(y_raw, sc, sh) > 0 ? dy : 0) : dy, dx = fma(ca, g, fma(cp, y_raw, cq)), rounded
+// to bf16 like the tensor cn_bn_train_bwd_sink would have stored — so that tensor is never written or read.  bf16, 7x7 / pad 3, Ci <= 3,
+// Co a multiple of 16 only (CN_EUNSUPPORTED otherwise: the caller runs cn_bn_train_bwd_sink + cn_stem_conv_wgrad).
+extern "C" int cn_stem_conv_wgrad_bn(const float* x, const void* dy, const void* y_raw, const float* coef, float* dw, int N, int Ci, int H,
+                                     int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream) {
+    CN_CHECK_ARG(x && dy && y_raw && coef && dw && N > 0 && Co > 0, "cn_stem_conv_wgrad_bn: bad args");
+    CN_CHECK_ARG((((uintptr_t)dy | (uintptr_t)y_raw) & 15) == 0, "cn_stem_conv_wgrad_bn: dy / y_raw must be 16-byte aligned");
+    int rc = stem_check(Ci, KH, KW, stride);
+    if (rc) return rc;
+    if (!(dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
+          wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream, y_raw, coef, relu)))
+        CN_UNSUPPORTED("cn_stem_conv_wgrad_bn: bf16, 7x7 / pad 3, Ci <= 3, Co a multiple of 16");
+    CN_LAUNCH_CHECK("cn_stem_conv_wgrad_bn");
     return CN_OK;
 }

@@ -29,6 +29,10 @@ struct WgC16Geom {
     int N, H, W, Ci, x_ld, Co, dy_ld, OH, OW;      // dy is [N][OH][OW][dy_ld]; a launch's grid.y walks 16-channel blocks of Co
     int os_co, os_ci, os_tap;          // dw[co*os_co + ci*os_ci + (kh*KW+kw)*os_tap]
     int tiles_h, tiles_w, iters;
+    // BNB: dy is the gradient w.r.t. the OUTPUT of the training-mode BatchNorm (+ ReLU) that follows this conv, bn_x the conv's own raw
+    // output; the kernel forms the BN input gradient on load: g = relu ? (fma(x, sc, sh) > 0 ? dy : 0) : dy, dx = fma(ca, g, fma(cp, x, cq))
+    // (bn_bwd_apply_kernel's arithmetic), bn_coef = fp32 [5][bn_C]: ca | cp | cq | sc | sh (cn_bn_bwd_coef_sink)
+    const bf16_t* bn_x; const float* bn_coef; int bn_C, bn_relu;
     const float* pre_ss; int pre_relu;   // input pre-affine (cn_conv_pre_affine_arm): x' = bf16(fma(x, ss[c], ss[16 + c])), relu: max(., 0); padding stays 0
 };
 
@@ -43,7 +47,7 @@ __device__ static inline bf16x8_t tr_frag_k32(const bf16_t* tile, int lane, RowF
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int XPIX, int KH, int KW, int S = 1, bool AFF = false>
+template <int XPIX, int KH, int KW, int S = 1, bool AFF = false, bool BNB = false>
 __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     static_assert(!AFF || XPIX == 16, "the pre-affine is for the NHWC bf16 input");
     constexpr int PAD = KH / 2;
@@ -73,6 +77,18 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     uint4 rdy[DYV];
     uint4 rx16[XPIX == 16 ? XV : 1];
     float rx4[XPIX == 4 ? XV : 1][3];
+    uint4 rbx[BNB ? DYV : 1];                           // BNB: the conv's raw output at the dy positions
+    uint32_t dym = 0;                                   // BNB: which of this lane's dy vectors are real (the others stay zero)
+    float bca[BNB ? 8 : 1], bcp[BNB ? 8 : 1], bcq[BNB ? 8 : 1], bsc[BNB ? 8 : 1], bsh[BNB ? 8 : 1];   // this lane's 8 channels: co0 + 8 (lane & 1) .. +7
+    if constexpr (BNB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = co0 + (lane & 1) * 8 + j;
+            const bool in = c < g.bn_C;
+            bca[j] = in ? g.bn_coef[c] : 0.f; bcp[j] = in ? g.bn_coef[g.bn_C + c] : 0.f; bcq[j] = in ? g.bn_coef[2 * g.bn_C + c] : 0.f;
+            bsc[j] = in ? g.bn_coef[3 * g.bn_C + c] : 0.f; bsh[j] = in ? g.bn_coef[4 * g.bn_C + c] : 0.f;
+        }
+    }
     uint32_t okm = 0;                                   // AFF: which of this lane's halo vectors lie inside the image (the others stay zero)
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     typedef short s16x2_ __attribute__((ext_vector_type(2)));
@@ -98,6 +114,11 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
             const int oh = th0 + px / C16_TW, ow = tw0 + px % C16_TW;
             const bool ok = tv && oh < g.OH && ow < g.OW && co0 + hf * 8 < g.dy_ld;
             rdy[v] = ldg16_masked(g.dy, ((((int64_t)n * g.OH + oh) * g.OW + ow) * g.dy_ld + co0 + hf * 8) * 2, ok);
+            if constexpr (BNB) {
+                if (v == 0) dym = 0;
+                rbx[v] = ldg16_masked(g.bn_x, ((((int64_t)n * g.OH + oh) * g.OW + ow) * g.dy_ld + co0 + hf * 8) * 2, ok);
+                if (ok) dym |= 1u << v;
+            }
         }
         if constexpr (XPIX == 16) {
             okm = 0;
@@ -128,7 +149,27 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int v = 0; v < DYV; ++v) *reinterpret_cast<uint4*>(dyt + (lane + v * 64) * 8) = rdy[v];
+        for (int v = 0; v < DYV; ++v) {
+            if constexpr (BNB) {                        // BN input gradient from (dy, x): what bn_bwd_apply_kernel would have stored
+                float gv[8], xv[8];
+                Vec16<bf16_t>::unpack(rdy[v], gv);
+                Vec16<bf16_t>::unpack(rbx[v], xv);
+                const bool ok = (dym >> v) & 1u;
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    float d[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float gg = (!g.bn_relu || fmaf(xv[j + e], bsc[j + e], bsh[j + e]) > 0.f) ? gv[j + e] : 0.f;
+                        d[e] = fmaf(bca[j + e], gg, fmaf(bcp[j + e], xv[j + e], bcq[j + e]));
+                    }
+                    o[j >> 1] = ok ? pk_bf16(d[0], d[1]) : 0u;
+                }
+                rdy[v] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+            *reinterpret_cast<uint4*>(dyt + (lane + v * 64) * 8) = rdy[v];
+        }
         if constexpr (XPIX == 16) {
 #pragma unroll
             for (int v = 0; v < XV; ++v) {
@@ -200,7 +241,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     }
 }
 
-template <int XPIX, int KH, int KW, int S = 1, bool AFF = false>
+template <int XPIX, int KH, int KW, int S = 1, bool AFF = false, bool BNB = false>
 static void launch_c16(WgC16Geom& g, hipStream_t st) {
     g.tiles_h = cdiv(g.OH, C16_TH); g.tiles_w = cdiv(g.OW, C16_TW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
@@ -208,7 +249,7 @@ static void launch_c16(WgC16Geom& g, hipStream_t st) {
     const int cap = cn_wgrad_target_blocks() / 3 < 128 ? 128 : cn_wgrad_target_blocks() / 3;   // default 512
     if (blocks > cap) blocks = cap;
     g.iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
-    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S, AFF>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S, AFF, BNB>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
 }
 
 // bf16 NHWC x, 3x3 / stride 1|2 / pad 1, Ci == 16, Co in 16-channel blocks -> packed dwp[co][tap*16 + ci]
@@ -221,14 +262,16 @@ bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int
     g.OH = OH; g.OW = OW;
     g.os_co = 9 * Ci; g.os_ci = 1; g.os_tap = Ci;
     g.pre_ss = pre_ss; g.pre_relu = pre_relu;
+    g.bn_x = nullptr; g.bn_coef = nullptr; g.bn_C = 0; g.bn_relu = 0;
     if (pre_ss) { if (stride == 1) launch_c16<16, 3, 3, 1, true>(g, st); else launch_c16<16, 3, 3, 2, true>(g, st); }
     else if (stride == 1) launch_c16<16, 3, 3, 1>(g, st); else launch_c16<16, 3, 3, 2>(g, st);
     return true;
 }
 
 // fp32 NCHW x (the image), 7x7 / stride 1|2 / pad 3, Ci <= 3, Co % 16 == 0 -> dw[co][ci][kh][kw]
+// bn_x != nullptr: dy is the gradient w.r.t. the output of the BatchNorm (+ ReLU) behind the stem, see WgC16Geom
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
-                           int OH, int OW, hipStream_t st) {
+                           int OH, int OW, hipStream_t st, const void* bn_x, const float* bn_coef, int bn_relu) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
     if (disabled || Ci > 3 || (Co & 15) || (dy_ld & 7) || dy_ld < Co || (stride != 1 && stride != 2)) return false;
     WgC16Geom g;
@@ -236,6 +279,12 @@ bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int
     g.OH = OH; g.OW = OW;
     g.os_co = Ci * 49; g.os_ci = 49; g.os_tap = 1;
     g.pre_ss = nullptr; g.pre_relu = 0;
+    g.bn_x = (const bf16_t*)bn_x; g.bn_coef = bn_coef; g.bn_C = Co; g.bn_relu = bn_relu;
+    if (bn_x) {
+        if (dy_ld != Co) return false;               // bn_x is read with dy's pitch
+        if (stride == 1) launch_c16<4, 7, 7, 1, false, true>(g, st); else launch_c16<4, 7, 7, 2, false, true>(g, st);
+        return true;
+    }
     if (stride == 1) launch_c16<4, 7, 7, 1>(g, st); else launch_c16<4, 7, 7, 2>(g, st);
     return true;
 }

@@ -15,6 +15,7 @@ import os
 
 from . import ops
 
+STEM_BN_FUSED = not (os.environ.get("CN_DISABLE_STEM_BN_FUSED") or os.environ.get("CN_DISABLE_WGRAD_C16"))   # stem conv + BN as one autograd node
 BN_DEFER = not os.environ.get("CN_DISABLE_BN_DEFER")     # training-mode BN of the 16-channel 512^2 layers applied by the consuming conv
 
 
@@ -178,6 +179,12 @@ class StemConv(nn.Module):
 
 def stem_bn_act(stem, bn, img, dtype, relu=True, defer=False):
     """stem conv -> BN -> ReLU; one fused kernel in eval / no-grad mode.  defer: see BatchNorm2d.forward."""
+    if (defer and BN_DEFER and STEM_BN_FUSED and bn.training and dtype == torch.bfloat16 and stem.weight.shape[0] == 16
+            and stem.weight.shape[2] == 7 and stem.padding == 3 and stem.weight.shape[1] <= 3 and ops.BnStats.enabled):
+        # the BN behind the stem lives entirely in the neighbouring kernels (ops.StemBnDeferFn)
+        bn._pending += 1
+        ops.WeightsEpoch.bump()
+        return ops.stem_bn_defer(img, stem.weight, bn, stem.stride, stem.padding, dtype, relu)
     if bn.training or (torch.is_grad_enabled() and stem.weight.requires_grad):
         return bn(stem(img, dtype, bn_stats=bn.training), None, relu, defer)
     s, b = bn.folded()

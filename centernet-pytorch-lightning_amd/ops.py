@@ -182,6 +182,29 @@ class BnStats:
                 buf.zero_()
         cls._state.clear()
         cls.last = None
+        BnBwdSinks._by_ptr.clear()             # (their buffers are in the rings above)
+
+
+class BnBwdSinks:
+    """Backward-statistics sinks filled by the kernel that PRODUCED a gradient tensor (cn_bn_bwd_stats_arm), keyed by that tensor's
+    address until the BN backward that consumes the gradient picks it up (a side channel next to autograd, like SparseRows)."""
+    enabled = not _os.environ.get("CN_DISABLE_BN_BWD_EPILOGUE_STATS")
+    _by_ptr = {}
+
+    @classmethod
+    def note(cls, t, sink):
+        cls._by_ptr[(t.data_ptr(), str(t.device))] = sink
+
+    @classmethod
+    def take(cls, t):
+        return cls._by_ptr.pop((t.data_ptr(), str(t.device)), None)
+
+    @classmethod
+    def reset(cls):
+        for sink in cls._by_ptr.values():
+            sink.zero_()
+            BnStats.release(sink)
+        cls._by_ptr.clear()
 
 
 class GradReady:
@@ -636,7 +659,25 @@ def _conv2d_bwd(x, weight, bias_ref, dy, stride, pad, has_bias, mask_dx, cell, o
                 # x is shared: what its other consumers sent rides in the epilogue's residual slot (the two stride-2 shapes
                 # with a dedicated data-gradient kernel keep it: that kernel has no residual input)
                 skip = cell.take(like=x)
-            dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
+            sink = None
+            if (pre is not None and len(pre) > 2 and skip is None and BnBwdSinks.enabled and BnStats.fused and x.dtype == torch.bfloat16
+                    and Cx == pre[2].shape[1]):
+                # x is a raw conv output behind a deferred BN: ask the data-gradient kernel for that BN's backward statistics
+                sink = BnStats.acquire("b", Cx, x.device)
+                if _hip.query("cn_bn_bwd_stats_arm", sink.data_ptr(), sink.shape[0], Cx, x.data_ptr(), pre[2].data_ptr(), int(pre[1])) != 0:
+                    BnStats.release(sink)
+                    sink = None
+            try:
+                dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
+            except BaseException:
+                if sink is not None:
+                    BnStats.release(sink)
+                raise
+            if sink is not None:
+                if _hip.query("cn_bn_bwd_stats_taken"):
+                    BnBwdSinks.note(dx, sink)
+                else:
+                    BnStats.release(sink)
         if dskip is not None:
             dx = _add_tensors(dx, dskip)
     elif dskip is not None:
@@ -861,13 +902,24 @@ class BatchNormActFn(Function):
         cell = ctx.res_cell if has_res else None
         racc = cell.take(like=x) if cell is not None else None       # shared residual input: its other consumers' sum joins in the store
         sink = clear = None
-        if BnStats.fused and x.dtype == torch.bfloat16 and C % 8 == 0:
+        filled = BnBwdSinks.take(dy)               # the kernel that produced dy already summed the statistics in its epilogue
+        if filled is not None and (has_res or y is not None):
+            filled.zero_()
+            BnStats.release(filled)
+            filled = None
+        if filled is not None:
+            sink = filled
+            clear = BnStats.retire(sink)
+        elif BnStats.fused and x.dtype == torch.bfloat16 and C % 8 == 0:
             # two launches instead of three: the statistics pass adds into a sink that the apply pass reduces itself
             sink = BnStats.acquire("b", C, x.device)
             clear = BnStats.retire(sink)
 
         def run(dgamma, dbeta, accumulate):
-            if sink is not None:
+            if filled is not None:
+                call("cn_bn_train_bwd_apply", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, dgamma, dbeta, accumulate,
+                     sink, sink.shape[0], clear, clear.numel() if clear is not None else 0, npix, C, int(relu), dtype_code(x.dtype))
+            elif sink is not None:
                 call("cn_bn_train_bwd_sink", dy, x, y, gamma.detach(), mean, invstd, ss, dx, dres, racc, dgamma, dbeta, accumulate,
                      sink, sink.shape[0], clear, clear.numel() if clear is not None else 0, npix, C, int(relu), dtype_code(x.dtype))
             else:
@@ -912,11 +964,92 @@ class BnDeferFn(Function):
         return r[0], r[1], r[2], None, None, None, None
 
 
+class StemBnDeferFn(Function):
+    """7x7 stem conv -> training-mode BatchNorm2d (+ ReLU) as ONE autograd node whose BN passes live in the neighbouring kernels
+    (pose_dla_dcn.py:283-287 base_layer): forward = the stem kernel (batch statistics from its epilogue) + a finalize launch, the raw
+    conv output is handed on for the next conv to normalise on load (BnDeferFn's protocol); backward = statistics pass + a
+    coefficient launch, then the stem's weight-gradient kernel forms the BN input gradient on load (cn_stem_conv_wgrad_bn) — neither
+    the normalised activation nor the BN input gradient ever exists in memory."""
+
+    @staticmethod
+    def forward(ctx, img, weight, gamma, beta, running_mean, running_var, stride, pad, dtype, relu):
+        Co, Ci, KH, KW = weight.shape
+        N, _, H, W = img.shape
+        OH, OW = conv_out(H, KH, stride, pad), conv_out(W, KW, stride, pad)
+        img = img.contiguous()
+        y = torch.empty((N, OH, OW, Co), dtype=dtype, device=img.device)
+        BnStats.launch(True, y, "cn_stem_conv_fwd", img, weight.detach().contiguous(), None, None, y, N, Ci, H, W, Co, KH, KW, stride,
+                       pad, OH, OW, 0, dtype_code(dtype))
+        part, BnStats.last = BnStats.last, None
+        if part is None:
+            raise RuntimeError("StemBnDeferFn: the stem kernel for this shape has no statistics hook (use stem conv + BatchNormActFn)")
+        npix = N * OH * OW
+        stats = torch.empty((4, Co), dtype=torch.float32, device=img.device)  # mean, invstd, scale, shift
+        call("cn_bn_finalize_sink", part, part.shape[0], gamma.detach(), beta.detach(), running_mean, running_var, stats[0], stats[1],
+             stats[2:], npix, Co, BN_MOMENTUM, BN_EPS)
+        BnStats.release(part)
+        ctx.save_for_backward(img, weight, gamma, y, stats)
+        ctx.beta_ref = beta
+        ctx.cfg = (stride, pad, relu)
+        ctx.order = SideGrads.next_order()
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats=None):
+        img, weight, gamma, y, stats = ctx.saved_tensors
+        beta = ctx.beta_ref
+        stride, pad, relu = ctx.cfg
+        Co, Ci, KH, KW = weight.shape
+        N, _, H, W = img.shape
+        OH, OW = y.shape[1], y.shape[2]
+        npix = N * OH * OW
+        dt = dtype_code(y.dtype)
+        dy = dy.contiguous()
+        mean, invstd, ss = stats[0], stats[1], stats[2:]
+        sink = BnBwdSinks.take(dy)                 # filled by the epilogue of the kernel that produced dy, where it has the hook
+        filled = sink is not None
+        if not filled:
+            sink = BnStats.acquire("b", Co, y.device)
+        clear = BnStats.retire(sink)
+        if not filled:
+            call("cn_bn_bwd_stats", dy, y, None, mean, invstd, ss, sink, sink.shape[0], npix, Co, int(relu), dt)
+        coef = torch.empty((5, Co), dtype=torch.float32, device=y.device)
+        direct = SideGrads.usable(gamma, beta)
+        dgamma = gamma.grad if direct else torch.empty(Co, dtype=torch.float32, device=y.device)
+        dbeta = beta.grad if direct else torch.empty(Co, dtype=torch.float32, device=y.device)
+        call("cn_bn_bwd_coef_sink", sink, sink.shape[0], gamma.detach(), mean, invstd, ss, dgamma, dbeta, int(direct), coef, clear,
+             clear.numel() if clear is not None else 0, npix, Co)
+        if direct:
+            GradReady.note(gamma, beta)
+
+        def wgrad(dw):
+            call("cn_stem_conv_wgrad_bn", img, dy, y, coef, dw, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, int(relu), dt)
+
+        if SideGrads.usable(weight):
+            def side_work():
+                wgrad(weight.grad)
+                GradReady.note(weight)
+            SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy, y, coef, claims=(weight,))
+            dw = None
+        else:
+            dw = zeros_like(weight, torch.float32)
+            wgrad(dw)
+        return None, dw, (None if direct else dgamma), (None if direct else dbeta), None, None, None, None, None, None
+
+
+def stem_bn_defer(img, weight, bn, stride, pad, dtype, relu=True):
+    """-> the stem's RAW output tagged `_cn_pre` (see batch_norm_defer)"""
+    y, stats = StemBnDeferFn.apply(img, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, stride, pad, dtype, relu)
+    y._cn_pre = (stats[2:], bool(relu), stats)
+    return y
+
+
 def batch_norm_defer(x, bn, relu=True):
     """-> x itself (raw) tagged with `_cn_pre = (scale | shift, relu)` for the conv that consumes it; x must carry the statistics sink
     of its producer (`_bn_part`)"""
     y, stats = BnDeferFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, x._bn_part, relu)
-    y._cn_pre = (stats[2:], bool(relu))
+    y._cn_pre = (stats[2:], bool(relu), stats)
     return y
 
 

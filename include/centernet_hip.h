@@ -123,6 +123,10 @@ int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype
  * and relu fold an eval-mode BN + ReLU into the epilogue: y = act(fma(conv, scale, bias)). */
 int cn_stem_conv_fwd(const float* x_nchw, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H, int W, int Co,
                      int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream);
+/* cn_stem_conv_wgrad through the training-mode BN (+ ReLU) behind the stem: dy = gradient w.r.t. the BN output, y_raw = the stem's raw
+ * output, coef from cn_bn_bwd_coef_sink; the BN input gradient is formed on load and never stored (bf16, 7x7 / pad 3, Co % 16 == 0). */
+int cn_stem_conv_wgrad_bn(const float* x_nchw, const void* dy, const void* y_raw, const float* coef, float* dw, int N, int Ci, int H,
+                          int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream);
 int cn_stem_conv_wgrad(const float* x_nchw, const void* dy, float* dw, int N, int Ci, int H, int W, int Co,
                        int KH, int KW, int stride, int pad, int OH, int OW, int dtype, void* stream);
 
@@ -143,6 +147,26 @@ size_t cn_bn_workspace_bytes(int64_t npix, int C);
  * stored — with zero padding applied to x'.  ss = fp32 [2][C] scale | shift in device memory (cn_bn_finalize_sink writes it).  Only
  * the 16-input-channel bf16 3x3 kernels have the hook; any other shape returns CN_EUNSUPPORTED (no silent fallback on the raw tensor). */
 int cn_conv_pre_affine_arm(const float* ss, int C, int relu);
+/* BN backward for a consumer that applies it on load (the stem's weight gradient, cn_stem_conv_wgrad_bn): cn_bn_bwd_stats = the
+ * statistics pass of cn_bn_train_bwd_sink alone; cn_bn_bwd_coef_sink = totals of the sink -> dgamma / dbeta and coef fp32 [5][C]
+ * (ca | cp | cq | sc | sh: g = relu ? (fma(x, sc, sh) > 0 ? dy : 0) : dy, dx = fma(ca, g, fma(cp, x, cq))). */
+/* BN backward statistics from the kernel that PRODUCES dy: cn_bn_bwd_stats_arm(sink, slots, C, x, stats, relu) arms the next
+ * cn_conv2d_fwd (transposed != 0) of the calling host thread; its output is the gradient w.r.t. the output of a training-mode BN (+ ReLU)
+ * with input x (NHWC, pitch C == y_ld) and stats = fp32 [4][C] mean | invstd | scale | shift.  When the dispatched kernel has the hook
+ * (the 16-channel bf16 data-gradient kernels) it fills sink[slots][2][C] (all-zero when armed) with what cn_bn_bwd_stats would compute
+ * and cn_bn_bwd_stats_taken() returns 1; otherwise 0 and the sink is untouched.  cn_bn_train_bwd_apply = the apply half of
+ * cn_bn_train_bwd_sink alone, on a sink that is already filled. */
+int cn_bn_bwd_stats_arm(float* sink, int slots, int C, const void* x, const float* stats, int relu);
+int cn_bn_bwd_stats_taken(void);
+int cn_bn_train_bwd_apply(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
+                          const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
+                          float* dgamma, float* dbeta, int accumulate, const float* sink, int slots, float* clear, int64_t clear_n,
+                          int64_t npix, int C, int relu, int dtype, void* stream);
+int cn_bn_bwd_stats(const void* dy, const void* x, const void* y, const float* save_mean, const float* save_invstd,
+                    const float* scale_shift, float* sink, int slots, int64_t npix, int C, int relu, int dtype, void* stream);
+int cn_bn_bwd_coef_sink(const float* sink, int slots, const float* gamma, const float* save_mean, const float* save_invstd,
+                        const float* scale_shift, float* dgamma, float* dbeta, int accumulate, float* coef, float* clear,
+                        int64_t clear_n, int64_t npix, int C, void* stream);
 int cn_bn_stats_slots(void);
 int cn_bn_stats_arm(float* part, int slots, int C);
 int cn_bn_stats_taken(void);

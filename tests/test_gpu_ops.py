@@ -901,8 +901,13 @@ def test_dla_base_chain_leaves_bn_apply_to_the_next_conv(grad, monkeypatch):
     net = DLA([1, 1, 1, 2, 2, 1], [16, 32, 64, 128, 256, 512], compute_dtype=dt).to(DEV).train()
     img = torch.randn(2, 3, 72, 104, device=DEV)
 
-    def run(defer):
+    def run(defer, stem_fused=False, bwd_hook=False):
         monkeypatch.setattr(hnn, "BN_DEFER", defer)
+        monkeypatch.setattr(hnn, "STEM_BN_FUSED", stem_fused)
+        monkeypatch.setattr(o.BnBwdSinks, "enabled", bwd_hook)
+        taken = []
+        real_note = o.BnBwdSinks.note.__func__
+        monkeypatch.setattr(o.BnBwdSinks, "note", classmethod(lambda cls, t, sink: (taken.append(1), real_note(cls, t, sink))[1]))
         for m in net.modules():
             if isinstance(m, hnn.BatchNorm2d):
                 m.reset_running_stats()
@@ -916,21 +921,26 @@ def test_dla_base_chain_leaves_bn_apply_to_the_next_conv(grad, monkeypatch):
             x = net._run_conv_level(net.level1, x)
         monkeypatch.setattr(o, "batch_norm_defer", real)
         assert getattr(x, "_cn_pre", None) is None, "level1's output is a stored activation"
-        assert len(calls) == (2 if defer else 0)
+        assert len(calls) == ((1 if stem_fused else 2) if defer else 0)
         out = {"y": x.detach().float().clone(), "rm0": net.base_layer[1].running_mean.clone(), "rv1": net.level0[1].running_var.clone()}
         if grad:
             g = torch.randn(x.shape, generator=torch.Generator().manual_seed(1)).to(DEV).to(dt)
             x.backward(g)
+            assert len(taken) == (2 if (bwd_hook and defer) else 0), "both 16-channel data-gradient kernels have the BN-backward statistics hook"
+            assert not o.BnBwdSinks._by_ptr
             for name in ("base_layer.0.weight", "base_layer.1.weight", "base_layer.1.bias", "level0.0.weight", "level0.1.weight",
                          "level0.1.bias", "level1.0.weight", "level1.1.weight"):
                 out[name] = net.get_parameter(name).grad.detach().float().clone()
         return out
 
-    a, b = run(True), run(False)
-    for k in b:
-        scale = float(b[k].abs().max())
-        err = float((a[k] - b[k]).abs().max()) / max(scale, 1e-6)
-        assert err < (1e-5 if k.startswith("r") else 2e-2), f"{k}: {err:.3e}"
+    b = run(False)
+    # second: the stem's BN entirely inside its neighbours (ops.StemBnDeferFn + cn_stem_conv_wgrad_bn); third / fourth: the BN backward
+    # statistics of both 16-channel BNs from the epilogue of the kernel that produces their gradient (cn_bn_bwd_stats_arm)
+    for a in (run(True), run(True, True), run(True, False, True), run(True, True, True)):
+        for k in b:
+            scale = float(b[k].abs().max())
+            err = float((a[k] - b[k]).abs().max()) / max(scale, 1e-6)
+            assert err < (1e-5 if k.startswith("r") else 2e-2), f"{k}: {err:.3e}"
 
 
 def test_bn_statistics_hook_can_be_declined(monkeypatch):

@@ -63,5 +63,44 @@ def main():
         print("conv3x3 16->32 s2 fwd      + BN/ReLU on load", mb(x.numel() * 2 + N * 256 * 256 * 32 * 2, us))
 
 
+def tail():
+    """the last kernels of a step: BN backward of the stem's BN + the stem's weight gradient, unfused vs fused (cn_stem_conv_wgrad_bn)"""
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    dt = torch.bfloat16
+    code = _hip.dtype_code(dt)
+    img = torch.randn(N, 3, 512, 512, device=DEV)
+    y = torch.randn(N, 512, 512, 16, device=DEV).to(dt)
+    dy = torch.randn(N, 512, 512, 16, device=DEV).to(dt)
+    dx = torch.empty_like(dy)
+    gamma = torch.rand(16, device=DEV) + 0.5
+    stats = torch.stack([torch.zeros(16, device=DEV), torch.ones(16, device=DEV), gamma, torch.zeros(16, device=DEV)]).contiguous()
+    dw = torch.zeros(16, 3, 7, 7, device=DEV)
+    dg, db = torch.zeros(16, device=DEV), torch.zeros(16, device=DEV)
+    sink = torch.zeros(_hip.query("cn_bn_stats_slots"), 2, 16, device=DEV)
+    coef = torch.zeros(5, 16, device=DEV)
+    npix = N * 512 * 512
+    for blocks in (160, 1536):
+        _hip.call("cn_set_wgrad_parallelism", blocks) if False else _hip.query("cn_set_wgrad_parallelism", blocks)
+        us = timeit(lambda: _hip.call("cn_stem_conv_wgrad", img, dy, dw, N, 3, 512, 512, 16, 7, 7, 1, 3, 512, 512, code))
+        print(f"stem wgrad              [wgrad blocks {blocks:4d}] {us:8.1f} us")
+        us = timeit(lambda: _hip.call("cn_stem_conv_wgrad_bn", img, dy, y, coef, dw, N, 3, 512, 512, 16, 7, 7, 1, 3, 512, 512, 1, code))
+        print(f"stem wgrad through BN   [wgrad blocks {blocks:4d}] {us:8.1f} us")
+    def bwd():
+        sink.zero_()
+        _hip.call("cn_bn_train_bwd_sink", dy, y, None, gamma, stats[0], stats[1], stats[2:], dx, None, None, dg, db, 1, sink, sink.shape[0], None, 0,
+                  npix, 16, 1, code)
+    us = timeit(bwd)
+    print(f"cn_bn_train_bwd_sink 16 ch (+ zero of the sink) {us:8.1f} us")
+    def st():
+        sink.zero_()
+        _hip.call("cn_bn_bwd_stats", dy, y, None, stats[0], stats[1], stats[2:], sink, sink.shape[0], npix, 16, 1, code)
+        _hip.call("cn_bn_bwd_coef_sink", sink, sink.shape[0], gamma, stats[0], stats[1], stats[2:], dg, db, 1, coef, None, 0, npix, 16)
+    us = timeit(st)
+    print(f"cn_bn_bwd_stats + cn_bn_bwd_coef_sink (+ zero)  {us:8.1f} us")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "tail":
+        tail()
+        sys.exit(0)
     main()
