@@ -833,29 +833,32 @@ extern "C" int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, in
     return CN_OK;
 }
 
-// One launch packs every weight operand of a step (table: w, wp, A, B, taps, mode, rows_pad, inner_pad, first_block per entry).
-// A thread owns one (row, inner) PAIR and walks its taps: the fp32 source w[a][b][0..taps-1] is one contiguous run per pair and
-// the lanes of a wave write consecutive bf16 elements for every tap.  (The first version was output-element driven: every
-// lane read with a stride of `taps` floats, 9x over-fetch from L2, and divided 64-bit indices twice per element: 266 us.)
-// Items per entry: modes 0/1 rows_pad * inner_pad; mode 2 (rows = tap*B + b) B * inner_pad pairs + the zero rows of the padding.
-__device__ static inline int64_t pack_items(int A, int B, int taps, int mode, int rows_pad, int inner_pad) {
-    return (mode == 2 ? (int64_t)(B + rows_pad - taps * B) : (int64_t)rows_pad) * (inner_pad / 8);
-}
+// One launch packs every weight operand of a step.  Table record (10 int64): w, wp, A, B, taps, mode, rows_pad, inner_pad, first_block,
+// AA | BB << 8 | tiles_b << 16.  A workgroup owns a tile of AA x BB (a, b) pairs with all their taps: the fp32 source
+// w[a][b0 .. b0+BB-1][0 .. taps-1] is one contiguous run per a (coalesced loads into LDS), the packed rows leave as 16-byte vectors of 8
+// consecutive INNER elements (mode 1: b, tiles 4 x 64; modes 0 / 2: a, tiles 64 x 4, 64 x 16 for 1x1 weights) read back from LDS with the
+// (a, b, t) -> (row, tap, inner) permutation.  The tiles cover the padded ranges, so every element of wp (padding = 0) is written by
+// every launch; mode 2's padding rows behind tap*B + b have one extra workgroup per record.  (History: output-element driven with a
+// stride of `taps` floats per lane, 9x over-fetch: 266 us; a thread per (row, 8 inner) pair walking its taps, 64 cache lines per
+// wave load: 207 us for DLA-34's 2 x 20 M elements — the first kernel of every step.)
+#define PACK_LDS_FLOATS 4096
 template <typename T>
-__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const int64_t* __restrict__ tab, int n) {
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const int64_t* __restrict__ tab, int n, const int* __restrict__ block_record) {
+    __shared__ float L[PACK_LDS_FLOATS];
     int lo = 0, hi = n - 1;                                 // last record whose first_block <= blockIdx.x
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (tab[mid * 10 + 8] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
+    if (block_record) lo = block_record[blockIdx.x];        // (eight dependent L2 round trips per workgroup otherwise: 3 of its ~4 us)
+    else
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid * 10 + 8] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
     const int64_t* e = tab + lo * 10;
     const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
     T* __restrict__ wp = reinterpret_cast<T*>(e[1]);
     const int A = (int)e[2], B = (int)e[3], taps = (int)e[4], mode = (int)e[5], rows_pad = (int)e[6], ip = (int)e[7];
-    const int ipv = ip / 8;                                 // inner_pad is a multiple of 16: a thread packs 8 inner elements
-    const int i = (int)((int64_t)blockIdx.x - e[8]) * 256 + threadIdx.x;
-    if ((int64_t)i >= pack_items(A, B, taps, mode, rows_pad, ip)) return;
-    const int r = (int)((unsigned)i / (unsigned)ipv), c0 = (i - r * ipv) * 8;
+    const int AA = (int)(e[9] & 255), BB = (int)((e[9] >> 8) & 255), tiles_b = (int)(e[9] >> 16);
+    const int tile = (int)((int64_t)blockIdx.x - e[8]);
+    const int tid = threadIdx.x;
     auto put8 = [&](T* dst, const float (&v)[8]) {
         if constexpr (sizeof(T) == 2) st16(dst, make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])));
         else {
@@ -863,32 +866,79 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const int64_t* _
             for (int j = 0; j < 8; ++j) dst[j] = v[j];
         }
     };
-    if (mode == 2 && r >= B) {                              // padding rows of the (tap, b)-major matrix
+    const int a_range = mode == 1 ? rows_pad : ip, b_range = mode == 1 ? ip : (mode == 0 ? rows_pad : B);
+    const int tiles_a = (a_range + AA - 1) / AA;
+    if (tile >= tiles_a * tiles_b) {                        // mode 2: the zero rows behind (tap, b)
         const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        put8(wp + (int64_t)taps * B * ip + (int64_t)(r - B) * ip + c0, z);
+        const int ipv = ip / 8, nv = (rows_pad - taps * B) * ipv;
+        for (int i = tid; i < nv; i += 256) put8(wp + (int64_t)taps * B * ip + (int64_t)i * 8, z);
         return;
     }
-    // source element of inner index c0 + j: modes 0 / 2: a = c0 + j, b = r; mode 1: a = r, b = c0 + j
-    int64_t src[8];
-    bool ok[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int a = mode == 1 ? r : c0 + j, bb = mode == 1 ? c0 + j : r;
-        ok[j] = a < A && bb < B;
-        src[j] = ok[j] ? ((int64_t)a * B + bb) * taps : 0;
-    }
-    for (int t = 0; t < taps; ++t) {
+    const int ta = tile / tiles_b, tb = tile - ta * tiles_b;
+    const int a0 = ta * AA, b0 = tb * BB;
+    const int run = BB * taps;                              // LDS pitch of one a
+    const int bval = B - b0 < BB ? (B - b0 > 0 ? B - b0 : 0) : BB;
+    // exact quotients by the two small run-time divisors without integer division: q = umulhi(e, ceil(2^32 / d)) for e < 2^12, d <= 2^12
+    const unsigned m_run = (unsigned)((0x100000000ull + (unsigned)run - 1) / (unsigned)run);
+    const unsigned m_taps = taps > 1 ? (unsigned)((0x100000000ull + (unsigned)taps - 1) / (unsigned)taps) : 0u;
+    auto div_taps = [&](int x) { return taps > 1 ? (int)__umulhi((unsigned)x, m_taps) : x; };
+    const int64_t src0 = ((int64_t)a0 * B + (bval > 0 ? b0 : 0)) * taps;
+    const int lim = bval * taps;
+    const int total = AA * run;
+#pragma unroll 1
+    for (int base = tid; base < total; base += 256 * 8) {   // eight branch-free loads in flight per thread, then the LDS stores
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float x = w[src[j] + t]; v[j] = ok[j] ? x : 0.f; }
-        put8(mode == 2 ? wp + ((int64_t)t * B + r) * ip + c0 : wp + (int64_t)r * taps * ip + (int64_t)t * ip + c0, v);
+        for (int u = 0; u < 8; ++u) {
+            const int el = base + u * 256;
+            const int al = (int)__umulhi((unsigned)el, m_run), off = el - al * run;
+            const bool ok = el < total && a0 + al < A && off < lim;
+            const float x = w[ok ? src0 + (int64_t)al * B * taps + off : 0];
+            v[u] = ok ? x : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (base + u * 256 < total) L[base + u * 256] = v[u];
+    }
+    __syncthreads();
+    if (mode == 1) {                                        // wp[a][t * ip + b]: vectors of 8 b
+        const int bv = BB / 8, nvec = AA * taps * bv;
+        for (int i = tid; i < nvec; i += 256) {
+            const int v = i % bv, at = i / bv, al = div_taps(at), t = at - al * taps;      // bv is a power of two
+            const int a = a0 + al, b = b0 + 8 * v;
+            if (a >= rows_pad || b >= ip) continue;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = L[al * run + (8 * v + j) * taps + t];
+            put8(wp + (int64_t)a * taps * ip + (int64_t)t * ip + b, o);
+        }
+    } else {                                                // mode 0: wp[b][t * ip + a]; mode 2: wp[t * B + b][a]: vectors of 8 a
+        const int av = AA / 8, nvec = BB * taps * av;
+        for (int i = tid; i < nvec; i += 256) {
+            const int v = i % av, bt = i / av, bl = div_taps(bt), t = bt - bl * taps;      // av = 8
+            const int a = a0 + 8 * v, b = b0 + bl;
+            if (a >= ip || b >= b_range) continue;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = L[(8 * v + j) * run + bl * taps + t];
+            put8(mode == 0 ? wp + (int64_t)b * taps * ip + (int64_t)t * ip + a : wp + ((int64_t)t * B + b) * ip + a, o);
+        }
     }
 }
 
-extern "C" int cn_pack_weight_batch(const void* table, int n_entries, int n_blocks, int dtype, void* stream) {
+// tile shape of a record (the caller builds the table with it): -> AA | BB << 8, 0 when the record does not fit (taps > 64)
+extern "C" int cn_pack_weight_tile(int taps, int mode) {
+    if (taps < 1 || taps > PACK_LDS_FLOATS / 64 || mode < 0 || mode > 2) return 0;
+    int AA, BB;
+    if (mode == 1) { BB = 64; AA = PACK_LDS_FLOATS / (64 * taps); AA = AA > 4 ? 4 : AA; }
+    else { AA = 64; BB = PACK_LDS_FLOATS / (64 * taps); const int cap = taps == 1 ? 16 : 4; BB = BB > cap ? cap : BB; }
+    return AA | (BB << 8);
+}
+
+extern "C" int cn_pack_weight_batch(const void* table, int n_entries, int n_blocks, const int* block_record, int dtype, void* stream) {
     CN_CHECK_ARG(table && n_entries > 0 && n_blocks > 0, "cn_pack_weight_batch: bad args");
     CN_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL(pack_weight_batch_kernel<T>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream,
-                                                   (const int64_t*)table, n_entries));
+                                                   (const int64_t*)table, n_entries, block_record));
     CN_LAUNCH_CHECK("cn_pack_weight_batch");
     return CN_OK;
 }

@@ -340,7 +340,7 @@ class PackArena:
 
     def __init__(self):
         self.recording = False
-        self.requests, self.slots, self.table, self.n_blocks, self.dtype = {}, {}, None, 0, None
+        self.requests, self.slots, self.table, self.n_blocks, self.dtype, self.block_record = {}, {}, None, 0, None, None
 
     @staticmethod
     def key(w, mode, dtype):
@@ -360,18 +360,28 @@ class PackArena:
         for k, w in reqs:
             mode = k[2]
             A, B, KH, KW = w.shape
+            taps = KH * KW
+            tile = int(_hip.query("cn_pack_weight_tile", taps, mode))         # AA | BB << 8 (see pack_weight_batch_kernel)
+            if not tile:
+                continue                          # (too many taps for a tile: that weight keeps its own cn_pack_weight launch)
+            AA, BB = tile & 255, tile >> 8
             rows_pad, inner_pad, cols = _pack_dims(w.shape, mode)
             wp = torch.empty((rows_pad, cols), dtype=self.dtype, device=w.device)
             self.slots[k] = wp
-            rows.append([w.data_ptr(), wp.data_ptr(), A, B, KH * KW, mode, rows_pad, inner_pad, blk, 0])
-            items = ((B + rows_pad - KH * KW * B) if mode == 2 else rows_pad) * (inner_pad // 8)   # see pack_weight_batch_kernel
-            blk += (items + 255) // 256
+            a_range, b_range = (rows_pad, inner_pad) if mode == 1 else ((inner_pad, rows_pad) if mode == 0 else (inner_pad, B))
+            tiles_b = -(-b_range // BB)
+            rows.append([w.data_ptr(), wp.data_ptr(), A, B, taps, mode, rows_pad, inner_pad, blk, tile | (tiles_b << 16)])
+            blk += -(-a_range // AA) * tiles_b + (1 if (mode == 2 and rows_pad > taps * B) else 0)
+        if not rows:
+            return
+        first = torch.tensor([r[8] for r in rows] + [blk], dtype=torch.int64)
+        self.block_record = torch.repeat_interleave(torch.arange(len(rows), dtype=torch.int32), first[1:] - first[:-1]).to(reqs[0][1].device)
         self.table = torch.tensor(rows, dtype=torch.int64).to(reqs[0][1].device)
         self.n_blocks = blk
 
     def repack(self):
         if self.table is not None:
-            call("cn_pack_weight_batch", self.table, self.table.shape[0], self.n_blocks, dtype_code(self.dtype))
+            call("cn_pack_weight_batch", self.table, self.table.shape[0], self.n_blocks, self.block_record, dtype_code(self.dtype))
 
 
 def pack_weight(w, mode, dtype, row_scale=None):

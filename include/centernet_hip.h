@@ -64,9 +64,14 @@ int cn_pack_weight(const float* w, void* wp, int A, int B, int KH, int KW, int m
                    const float* row_scale, int dtype, void* stream);
 /* All weight packings of a training step in ONE launch (the per-layer calls were ~160 tiny launches per step).
  * table: device array of n_entries records of 10 int64:
- *   { w (fp32 device pointer), wp (device pointer), A, B, KH*KW, mode, rows_pad, inner_pad, first_block, 0 }
- * with first_block the running sum of ceil(rows_pad*row_len / 2048) over the preceding records and n_blocks its total. */
-int cn_pack_weight_batch(const void* table, int n_entries, int n_blocks, int dtype, void* stream);
+ *   { w (fp32 device pointer), wp (device pointer), A, B, KH*KW, mode, rows_pad, inner_pad, first_block, AA | BB << 8 | tiles_b << 16 }
+ * A record is packed by tiles of AA x BB (a, b) pairs, AA | BB << 8 = cn_pack_weight_tile(taps, mode) (0: taps > 64, pack that weight
+ * with cn_pack_weight): tiles_a = ceil(a_range / AA), tiles_b = ceil(b_range / BB) over the PADDED ranges (mode 1: a < rows_pad,
+ * b < inner_pad; mode 0: a < inner_pad, b < rows_pad; mode 2: a < inner_pad, b < B), blocks = tiles_a * tiles_b (+ 1 for mode 2 when
+ * rows_pad > KH*KW*B); first_block = the running sum of blocks over the preceding records, n_blocks its total.  block_record
+ * (nullable, int32[n_blocks] on the device): the record index of every workgroup (otherwise each workgroup searches the table). */
+int cn_pack_weight_tile(int taps, int mode);
+int cn_pack_weight_batch(const void* table, int n_entries, int n_blocks, const int* block_record, int dtype, void* stream);
 /* inverse of mode 1 for gradients: dw[a][b][t] (+)= dwp[a][t*inner_pad + b] (fp32 -> fp32); accumulate != 0 adds into dw
  * (used to deposit gradients straight into the flat gradient buffer from a side stream) */
 int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, int inner_pad, int accumulate, void* stream);
