@@ -413,6 +413,157 @@ __global__ __launch_bounds__(256) void stem7_fwd_kernel(const float* __restrict_
     if (stats) bn_stats_flush_c16<256>(s0, s1, reinterpret_cast<float*>(halo), bn_part, bn_slots, y_ld, Co, blockIdx.x, tid);
 }
 
+// ---- the same contraction, ROW-WALKING (stride 1, <= 16 output channels: DLA base_layer, 512x512 -> 16 channels) ----------------
+// stem7_fwd_kernel moves every 8x16 tile's halo global -> registers -> LDS -> registers behind two barriers, with 4-byte loads from the
+// fp32 planes (the texture path takes a wave-level load instruction every ~16 cycles whatever its width: 18 of them per 128 outputs);
+// at 16 output channels the layer is an HBM stream (0.2 GB in, 0.54 GB out) and ran at 2.5 TB/s.  Here a workgroup owns a region of R
+// output rows x 128 columns: its (R + 6) x 136 input window is fetched ONCE with 16-byte loads (four pixels of one plane), converted
+// and parked in LDS as {c0, c1, c2, 0} bf16 per pixel, zeros outside the image; then every wave walks down a 32-pixel-wide column of
+// output rows.  The B operand of an INPUT row — lane (px, g4): pixels (ow + 2 g4 - 3, + 1) x 4 channel slots = 16 bytes of the LDS row
+// — is the same for all seven kernel rows that use that row, so a wave keeps the last eight input rows' operands in a register ring:
+// one LDS read per lane, 16-pixel group and output row, 7 MFMAs, no VALU on the input side.  Images are dealt to the XCDs as in
+// conv3x3_c16r_kernel.
+#define ST7R_G 2
+#define ST7R_RMAX 32
+#define ST7R_COLS 136                                      // 4 + 128 + 4: the window starts at the (16-byte aligned) column x0 - 4
+__global__ __launch_bounds__(256, 2) void stem7_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, bf16_t* __restrict__ y,
+                                                            int N, int Ci, int H, int W, int Co, int y_ld, int R, int sblocks, int rblocks,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias, int relu,
+                                                            float* __restrict__ bn_part, int bn_slots) {
+    CN_MAIN_PRIO_SET();
+    __shared__ __attribute__((aligned(16))) uint2 win[(ST7R_RMAX + 6) * ST7R_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 15, g4 = lane >> 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int bpi = sblocks * rblocks;
+    const int n = (jb / bpi) * 8 + xcd;
+    if (n >= N) return;                                   // whole workgroup
+    const int within = jb % bpi, rb = within / sblocks, sb = within % sblocks;
+    const int oh0 = rb * R, x0 = sb * 128, ow0 = x0 + wave * 16 * ST7R_G;
+
+    // ---- the window: rows oh0 - 3 .. oh0 + R + 2, columns x0 - 4 .. x0 + 131 (W is a multiple of 4: a 4-pixel vector is in or out) ----
+    const int64_t plane = (int64_t)H * W;
+    const float* const xn = x + (int64_t)n * Ci * plane;
+    const int nrows = R + 6;
+#pragma unroll 1
+    for (int base = tid; base < nrows * (ST7R_COLS / 4); base += 256 * 2) {
+        float4 v[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = base + u * 256;
+            const int row = it / (ST7R_COLS / 4), v4 = it - row * (ST7R_COLS / 4);
+            const int ih = oh0 - 3 + row, iw = x0 - 4 + 4 * v4;
+            const bool ok = it < nrows * (ST7R_COLS / 4) && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bool okc = ok && c < Ci;
+                const float4 q = *reinterpret_cast<const float4*>(xn + (okc ? c * plane + (int64_t)ih * W + iw : 0));
+                v[u][c] = okc ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int it = base + u * 256;
+            if (it < nrows * (ST7R_COLS / 4)) {
+                uint2* d = win + it * 4;                    // (row * COLS + 4 v4) pixels
+                d[0] = make_uint2(pk_bf16(v[u][0].x, v[u][1].x), pk_bf16(v[u][2].x, 0.f));
+                d[1] = make_uint2(pk_bf16(v[u][0].y, v[u][1].y), pk_bf16(v[u][2].y, 0.f));
+                d[2] = make_uint2(pk_bf16(v[u][0].z, v[u][1].z), pk_bf16(v[u][2].z, 0.f));
+                d[3] = make_uint2(pk_bf16(v[u][0].w, v[u][1].w), pk_bf16(v[u][2].w, 0.f));
+            }
+        }
+    }
+
+    // weight fragments of the seven kernel rows: A[co = lane & 15][k = 8 g4 + j] = w[co][ci = j & 3][kh][kw = 2 g4 + (j >> 2)]
+    bf16x8_t wa[7];
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kw = 2 * g4 + (j >> 2), ci = j & 3;
+            const bool ok = px < Co && ci < Ci && kw < 7;
+            const float val = w[ok ? ((int64_t)(px * Ci + ci) * 7 + kh) * 7 + kw : 0];
+            v[j] = ok ? val : 0.f;
+        }
+        wa[kh] = __builtin_bit_cast(bf16x8_t, make_uint4(pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])));
+    }
+    float sc4[4], bi4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool in = 4 * g4 + q < Co;
+        sc4[q] = (scale && in) ? scale[4 * g4 + q] : 1.f;
+        bi4[q] = (bias && in) ? bias[4 * g4 + q] : 0.f;
+    }
+    const bool affine = scale || bias || relu;
+    const bool stats = bn_part != nullptr;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // window column of this lane's first pixel: (ow - 3) - (x0 - 4) = wave * 32 + gq * 16 + px + 2 g4 + 1
+    const uint2* const wl = win + wave * 16 * ST7R_G + px + 2 * g4 + 1;
+    uint4 ring[8][ST7R_G];
+    auto fetch = [&](uint4 (&slot)[ST7R_G], int wrow) {    // window row wrow (clamped: rows past the region are never multiplied into a stored row)
+        const uint2* p = wl + (wrow < nrows ? wrow : nrows - 1) * ST7R_COLS;
+#pragma unroll
+        for (int gq = 0; gq < ST7R_G; ++gq) {
+            const uint2 lo = p[gq * 16], hi = p[gq * 16 + 1];
+            slot[gq] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < 7; ++u) fetch(ring[u], u);
+#pragma unroll 1
+    for (int r = 0; r < R; r += 8) {
+        if (oh0 + r >= H) break;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int oh = oh0 + r + u;
+            uint4 nxt[ST7R_G];
+            fetch(nxt, r + u + 7);                         // input row oh + 4 = window row (oh - oh0) + 7
+            if (oh < H && r + u < R) {
+                bf16_t* const yrow = y + ((int64_t)n * H + oh) * W * y_ld;
+#pragma unroll
+                for (int gq = 0; gq < ST7R_G; ++gq) {
+                    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kh = 0; kh < 7; ++kh)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kh], __builtin_bit_cast(bf16x8_t, ring[(u + kh) & 7][gq]), acc, 0, 0, 0);
+                    if (affine) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float v = fmaf(acc[q], sc4[q], bi4[q]);
+                            acc[q] = relu ? fmaxf(v, 0.f) : v;
+                        }
+                    }
+                    const int ow = ow0 + gq * 16 + px, c0 = 4 * g4;
+                    if (ow < W && c0 < Co) {
+                        bf16_t* dst = yrow + ow * y_ld + c0;
+                        if (c0 + 4 <= Co) {
+                            const uint2 o = make_uint2(pk_bf16(acc[0], acc[1]), pk_bf16(acc[2], acc[3]));
+                            *reinterpret_cast<uint2*>(dst) = o;
+                            if (stats) {
+                                const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
+                                const float a2 = __uint_as_float(o.y << 16), a3 = __uint_as_float(o.y & 0xffff0000u);
+                                s0[0] += a0; s0[1] += a1; s0[2] += a2; s0[3] += a3;
+                                s1[0] = fmaf(a0, a0, s1[0]); s1[1] = fmaf(a1, a1, s1[1]); s1[2] = fmaf(a2, a2, s1[2]); s1[3] = fmaf(a3, a3, s1[3]);
+                            }
+                        } else {
+                            for (int q = 0; q < 4 && c0 + q < Co; ++q) dst[q] = f2bf(acc[q]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int gq = 0; gq < ST7R_G; ++gq) ring[(u + 7) & 7][gq] = nxt[gq];      // row oh + 4 replaces row oh - 4
+        }
+    }
+    if (stats) {
+        __syncthreads();                                   // the window is dead: its head is the reduction scratch
+        bn_stats_flush_c16<256>(s0, s1, reinterpret_cast<float*>(win), bn_part, bn_slots, y_ld, Co, blockIdx.x, tid);
+    }
+}
+
 // bf16 output, 7x7 / stride 1|2 / pad 3, Ci <= 3, Co a multiple of 4; more than 64 output channels (Hourglass: 128) run as
 // 64-channel chunks over the same image (the 3-channel fp32 input is small next to the output).
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
@@ -426,6 +577,17 @@ bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const 
     const int iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
     constexpr int CHUNK = 16 * ST7_MAXCB;
     if (bn_part && Co <= 16 && (Co & 3) == 0) bn_sink_mark_taken(); else bn_part = nullptr;     // statistics hook: one channel block only
+    static const bool no_rows = getenv("CN_DISABLE_STEM_ROWS") != nullptr;
+    if (!no_rows && stride == 1 && Co <= 16 && OH == H && OW == W && (W & 3) == 0 && (((uintptr_t)x) & 15) == 0) {      // row-walking kernel (DLA base_layer)
+        const int R = OH >= 256 ? 32 : 16;
+        const int sblocks = cdiv(OW, 128), rblocks = cdiv(OH, R);
+        const int64_t nb = (int64_t)8 * ((N + 7) / 8) * sblocks * rblocks;
+        if (nb <= 0x7fffffff) {
+            hipLaunchKernelGGL(stem7_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, x, w, (bf16_t*)y, N, Ci, H, W, Co, Co, R, sblocks, rblocks,
+                               scale, bias, relu, bn_part, bn_slots);
+            return true;
+        }
+    }
     for (int c0 = 0; c0 < Co; c0 += CHUNK) {
         const int cc = Co - c0 < CHUNK ? Co - c0 : CHUNK;
         const float* wc = w + (int64_t)c0 * Ci * 49;

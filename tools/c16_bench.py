@@ -54,6 +54,11 @@ def main():
     wp2 = ops.pack_weight(w32, 1, dt)
     us = timeit(lambda: ops._igemm(x, wp2, None, None, 32, 3, 3, 2, 1, False, False, 256, 256))
     print("conv3x3 16->32 s2 @512^2 fwd     ", mb(x.numel() * 2 + N * 256 * 256 * 32 * 2, us))
+    img = torch.randn(N, 3, 512, 512, device=DEV)
+    ws = (torch.randn(16, 3, 7, 7, generator=g) * 0.1).to(DEV)
+    ys = torch.empty(N, 512, 512, 16, device=DEV, dtype=dt)
+    us = timeit(lambda: _hip.call("cn_stem_conv_fwd", img, ws, None, None, ys, N, 3, 512, 512, 16, 7, 7, 1, 3, 512, 512, 0, _hip.dtype_code(dt)))
+    print("stem 7x7 3->16 @512^2 fwd         ", mb(img.numel() * 4 + ys.numel() * 2, us), "   CN_DISABLE_STEM_ROWS =", os.environ.get("CN_DISABLE_STEM_ROWS"))
     if not os.environ.get("CN_DISABLE_CONV_C16R"):
         def aff(wp_, Co, s, OH):
             return ops._igemm(x, wp_, None, None, Co, 3, 3, s, 1, False, False, OH, OH, pre=(ss, True))
