@@ -394,6 +394,7 @@ bool dcn_bwd_dom_tile_launch(const void* dy, const void* wd2, const void* x, con
 // 3x3 / stride 1 / pad 1 halo-tile kernel (conv3x3.hip); returns false when the shape is not handled there
 bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st);
 bool conv_c16r_launch(const ConvGeom& g, int dtype, int S, hipStream_t st);
+bool dgrad3x3s2_launch(const ConvGeom& g, int dtype, hipStream_t st);     // conv_dgrad_s2.hip: data gradient of the stride-2 3x3 convs, all four parity classes per workgroup
 bool conv3x3s2_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3.hip: the same halo-tile skeleton for the stride-2 forward convs
 bool conv3x3_ws_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3_ws.hip: 64 input channels, weights in registers
 bool conv3x3_kp_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3_kp.hip: >= 128 input channels, both operands by LDS-DMA, phase-staggered waves

@@ -539,9 +539,13 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
         CN_LAUNCH_CHECK("cn_conv2d_fwd(16 ch, stride 2)");
         return CN_OK;
     }
-    if (transposed && dtype == CN_BF16 && out_dtype == dtype && KH == 3 && KW == 3 && stride == 2 && pad == 1 && ((Ci == 32 && Co == 16) || (Ci == 64 && Co == 32)) &&
+    if (transposed && dtype == CN_BF16 && out_dtype == dtype && KH == 3 && KW == 3 && stride == 2 && pad == 1 && ((Ci == 32 && Co == 16) || (Ci == 64 && Co == 32 && getenv("CN_DISABLE_DGRAD3X3_S2"))) &&
         OH == 2 * H && OW == 2 * W && !bias && !residual && !relu && dgrad_s2_c32to16_launch(g, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_conv2d_fwd(dgrad s2 32->16)");
+        return CN_OK;
+    }
+    if (transposed && ncls == 4 && KH == 3 && KW == 3 && stride == 2 && pad == 1 && out_dtype == dtype && dgrad3x3s2_launch(g, dtype, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_conv2d_fwd(dgrad 3x3 stride 2)");
         return CN_OK;
     }
     if (use_conv3x3(KH, KW, stride, pad, H, W, OH, OW) && conv3x3s1_launch(g, dtype, (hipStream_t)stream)) {

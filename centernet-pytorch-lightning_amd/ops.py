@@ -12,6 +12,8 @@ from ._hip import call, dtype_code
 
 import os as _os
 
+_NO_DGRAD_S2_TILE = bool(_os.environ.get("CN_DISABLE_DGRAD3X3_S2"))
+
 _DCN_UNFUSED = bool(_os.environ.get("CN_DCN_UNFUSED"))
 BN_MOMENTUM = 0.1  # msra_resnet.py:11, pose_dla_dcn.py:13
 BN_EPS = 1e-5
@@ -665,9 +667,9 @@ def _conv2d_bwd(x, weight, bias_ref, dy, stride, pad, has_bias, mask_dx, cell, o
             skip = dskip.contiguous() if (dskip is not None and dskip.dtype == x.dtype and dskip.shape == x.shape) else None
             if skip is not None:
                 dskip = None                                  # folded into the epilogue
-            elif cell is not None and not (stride == 2 and KH == 3 and (Co, Ci) in ((32, 16), (64, 32))):
-                # x is shared: what its other consumers sent rides in the epilogue's residual slot (the two stride-2 shapes
-                # with a dedicated data-gradient kernel keep it: that kernel has no residual input)
+            elif cell is not None and not (stride == 2 and KH == 3 and ((Co, Ci) == (32, 16) or ((Co, Ci) == (64, 32) and _NO_DGRAD_S2_TILE))):
+                # x is shared: what its other consumers sent rides in the epilogue's residual slot (the stride-2 shapes on the
+                # direct-from-global data-gradient kernel keep it: that kernel has no residual input)
                 skip = cell.take(like=x)
             sink = None
             if (pre is not None and len(pre) > 2 and skip is None and BnBwdSinks.enabled and BnStats.fused and x.dtype == torch.bfloat16
