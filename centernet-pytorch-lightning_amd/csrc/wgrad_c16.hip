@@ -47,13 +47,18 @@ __device__ static inline bf16x8_t tr_frag_k32(const bf16_t* tile, int lane, RowF
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int XPIX, int KH, int KW, int S = 1, bool AFF = false, bool BNB = false>
+// VEC4 (XPIX == 4, S == 1, W % 4 == 0): the image halo is fetched with 16-byte loads — four pixels of one fp32 plane, the window starting at
+// the aligned column tw0 - 4 — instead of one 4-byte load per pixel and plane (18 -> 6 wave-level load instructions per tile: the texture
+// path issues one every ~16 cycles whatever its width)
+template <int XPIX, int KH, int KW, int S = 1, bool AFF = false, bool BNB = false, bool VEC4 = false>
 __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     static_assert(!AFF || XPIX == 16, "the pre-affine is for the NHWC bf16 input");
+    static_assert(!VEC4 || (XPIX == 4 && S == 1 && KW == 7), "VEC4 is the stride-1 7x7 stem");
     constexpr int PAD = KH / 2;
     constexpr int HH = (C16_TH - 1) * S + KH;
     constexpr int KWG = XPIX == 16 ? KW : (KW + 3) / 4;                       // MFMA column groups per kernel row
-    constexpr int HWD = XPIX == 16 ? (C16_TW - 1) * S + KW : (C16_TW - 1) * S + 4 * KWG;   // halo row length (the last 4-pixel window starts at S*tx + 4*(KWG-1))
+    constexpr int HWD = VEC4 ? 24 : (XPIX == 16 ? (C16_TW - 1) * S + KW : (C16_TW - 1) * S + 4 * KWG);   // halo row length (the last 4-pixel window starts at S*tx + 4*(KWG-1)); VEC4: columns tw0 - 4 .. tw0 + 19
+    constexpr int XO = VEC4 ? 1 : 0;                                          // column of the halo's first USED pixel (tw0 - PAD)
     constexpr int HP = HH * HWD;
     constexpr int DY_ELEMS = C16_TH * C16_TW * 16;
     constexpr int X_ELEMS = HP * XPIX;
@@ -73,10 +78,11 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     for (int a = 0; a < NACC; ++a) acc[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     constexpr int DYV = DY_ELEMS / 8 / 64;                                    // 16-byte vectors per lane (4)
-    constexpr int XV = XPIX == 16 ? (HP * 2 + 63) / 64 : (HP + 63) / 64;      // XPIX 16: 16-byte vectors;  XPIX 4: pixels (3 floats each)
+    constexpr int XV = XPIX == 16 ? (HP * 2 + 63) / 64 : (VEC4 ? (HH * 6 + 63) / 64 : (HP + 63) / 64);      // XPIX 16: 16-byte vectors;  XPIX 4: pixels (3 floats each); VEC4: (row, 4-pixel group) items
     uint4 rdy[DYV];
     uint4 rx16[XPIX == 16 ? XV : 1];
-    float rx4[XPIX == 4 ? XV : 1][3];
+    float rx4[(XPIX == 4 && !VEC4) ? XV : 1][3];
+    float4 rv4[VEC4 ? XV : 1][3];
     uint4 rbx[BNB ? DYV : 1];                           // BNB: the conv's raw output at the dy positions
     uint32_t dym = 0;                                   // BNB: which of this lane's dy vectors are real (the others stay zero)
     float bca[BNB ? 8 : 1], bcp[BNB ? 8 : 1], bcq[BNB ? 8 : 1], bsc[BNB ? 8 : 1], bsh[BNB ? 8 : 1];   // this lane's 8 channels: co0 + 8 (lane & 1) .. +7
@@ -130,6 +136,21 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
                 const bool ok = tv && hp < HP && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
                 rx16[v] = ldg16_masked(g.x, ((((int64_t)n * g.H + ih) * g.W + iw) * g.x_ld + hf * 8) * 2, ok);
                 if (AFF && ok) okm |= 1u << v;
+            }
+        } else if constexpr (VEC4) {
+            const float* X = reinterpret_cast<const float*>(g.x);
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                const int it = lane + v * 64;
+                const int row = it / 6, q4 = it - row * 6;
+                const int ih = th0 - PAD + row, iw = tw0 - 4 + 4 * q4;
+                const bool ok = tv && it < HH * 6 && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const bool okc = ok && c < g.Ci;
+                    const float4 q = *reinterpret_cast<const float4*>(X + (okc ? (((int64_t)n * g.Ci + c) * g.H + ih) * g.W + iw : 0));
+                    rv4[v][c] = okc ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         } else {
             const float* X = reinterpret_cast<const float*>(g.x);
@@ -190,6 +211,16 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
                 }
                 if (idx < HP * 2) *reinterpret_cast<uint4*>(xh + idx * 8) = rx16[v];
             }
+        } else if constexpr (VEC4) {
+#pragma unroll
+            for (int v = 0; v < XV; ++v) {
+                const int it = lane + v * 64;
+                if (it < HH * 6) {
+                    uint4* d = reinterpret_cast<uint4*>(xh + it * 16);        // 4 pixels x {c0, c1, c2, 0}
+                    d[0] = make_uint4(pk_bf16(rv4[v][0].x, rv4[v][1].x), pk_bf16(rv4[v][2].x, 0.f), pk_bf16(rv4[v][0].y, rv4[v][1].y), pk_bf16(rv4[v][2].y, 0.f));
+                    d[1] = make_uint4(pk_bf16(rv4[v][0].z, rv4[v][1].z), pk_bf16(rv4[v][2].z, 0.f), pk_bf16(rv4[v][0].w, rv4[v][1].w), pk_bf16(rv4[v][2].w, 0.f));
+                }
+            }
         } else {
 #pragma unroll
             for (int v = 0; v < XV; ++v) {
@@ -216,7 +247,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
 #pragma unroll
                 for (int kwg = 0; kwg < KWG; ++kwg) {
                     const int kwb = XPIX == 16 ? kwg : 4 * kwg;
-                    const bf16x8_t fb = tr_frag_k32(xh, lane, [&](int kk) { return ((S * (2 * c + (kk >> 4)) + kh) * HWD + S * (kk & 15) + kwb) * XPIX; });
+                    const bf16x8_t fb = tr_frag_k32(xh, lane, [&](int kk) { return ((S * (2 * c + (kk >> 4)) + kh) * HWD + S * (kk & 15) + kwb + XO) * XPIX; });
                     acc[kh * KWG + kwg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[kh * KWG + kwg], 0, 0, 0);
                 }
         }
@@ -241,7 +272,7 @@ __global__ __launch_bounds__(256) void wgrad_c16_kernel(const WgC16Geom g) {
     }
 }
 
-template <int XPIX, int KH, int KW, int S = 1, bool AFF = false, bool BNB = false>
+template <int XPIX, int KH, int KW, int S = 1, bool AFF = false, bool BNB = false, bool VEC4 = false>
 static void launch_c16(WgC16Geom& g, hipStream_t st) {
     g.tiles_h = cdiv(g.OH, C16_TH); g.tiles_w = cdiv(g.OW, C16_TW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
@@ -249,7 +280,7 @@ static void launch_c16(WgC16Geom& g, hipStream_t st) {
     const int cap = cn_wgrad_target_blocks() / 3 < 128 ? 128 : cn_wgrad_target_blocks() / 3;   // default 512
     if (blocks > cap) blocks = cap;
     g.iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
-    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S, AFF, BNB>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S, AFF, BNB, VEC4>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
 }
 
 // bf16 NHWC x, 3x3 / stride 1|2 / pad 1, Ci == 16, Co in 16-channel blocks -> packed dwp[co][tap*16 + ci]
@@ -280,11 +311,15 @@ bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int
     g.os_co = Ci * 49; g.os_ci = 49; g.os_tap = 1;
     g.pre_ss = nullptr; g.pre_relu = 0;
     g.bn_x = (const bf16_t*)bn_x; g.bn_coef = bn_coef; g.bn_C = Co; g.bn_relu = bn_relu;
+    static const bool no_vec4 = getenv("CN_DISABLE_STEM_WGRAD_VEC4") != nullptr;
+    const bool vec4 = !no_vec4 && stride == 1 && (W & 3) == 0 && (((uintptr_t)x) & 15) == 0;
     if (bn_x) {
         if (dy_ld != Co) return false;               // bn_x is read with dy's pitch
-        if (stride == 1) launch_c16<4, 7, 7, 1, false, true>(g, st); else launch_c16<4, 7, 7, 2, false, true>(g, st);
+        if (vec4) launch_c16<4, 7, 7, 1, false, true, true>(g, st);
+        else if (stride == 1) launch_c16<4, 7, 7, 1, false, true>(g, st); else launch_c16<4, 7, 7, 2, false, true>(g, st);
         return true;
     }
+    if (vec4) { launch_c16<4, 7, 7, 1, false, false, true>(g, st); return true; }
     if (stride == 1) launch_c16<4, 7, 7, 1>(g, st); else launch_c16<4, 7, 7, 2>(g, st);
     return true;
 }
