@@ -184,29 +184,48 @@ class BnStats:
                 buf.zero_()
         cls._state.clear()
         cls.last = None
-        BnBwdSinks._by_ptr.clear()             # (their buffers are in the rings above)
+        BnBwdSinks.entries = []                # (their buffers are in the rings above)
 
 
 class BnBwdSinks:
-    """Backward-statistics sinks filled by the kernel that PRODUCED a gradient tensor (cn_bn_bwd_stats_arm), keyed by that tensor's
-    address until the BN backward that consumes the gradient picks it up (a side channel next to autograd, like SparseRows)."""
+    """Backward-statistics sinks filled by the kernel that PRODUCED a gradient tensor (cn_bn_bwd_stats_arm), kept next to that very
+    tensor (same Python object, same version: the side-channel rule of SparseRows) until the BN backward that receives it picks the
+    sink up.  What nobody picked up when the backward pass ends is zeroed and handed back."""
     enabled = not _os.environ.get("CN_DISABLE_BN_BWD_EPILOGUE_STATS")
-    _by_ptr = {}
+    entries = []
+    _lock = __import__("threading").Lock()
 
     @classmethod
     def note(cls, t, sink):
-        cls._by_ptr[(t.data_ptr(), str(t.device))] = sink
+        with cls._lock:
+            first = not cls.entries
+            cls.entries.append((t, t._version, sink))
+        if first:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(cls.clear)
+            except RuntimeError:              # not inside a backward pass
+                pass
 
     @classmethod
-    def take(cls, t):
-        return cls._by_ptr.pop((t.data_ptr(), str(t.device)), None)
+    def take(cls, g):
+        with cls._lock:
+            for i, (t, v, sink) in enumerate(cls.entries):
+                if t is g:
+                    cls.entries.pop(i)
+                    if g._version == v:
+                        return sink
+                    sink.zero_()              # the gradient was modified in place after the sums were taken: they are stale
+                    BnStats.release(sink)
+                    return None
+        return None
 
     @classmethod
-    def reset(cls):
-        for sink in cls._by_ptr.values():
+    def clear(cls):
+        with cls._lock:
+            left, cls.entries = cls.entries, []
+        for _, _, sink in left:
             sink.zero_()
             BnStats.release(sink)
-        cls._by_ptr.clear()
 
 
 class GradReady:

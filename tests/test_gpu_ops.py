@@ -927,7 +927,7 @@ def test_dla_base_chain_leaves_bn_apply_to_the_next_conv(grad, monkeypatch):
             g = torch.randn(x.shape, generator=torch.Generator().manual_seed(1)).to(DEV).to(dt)
             x.backward(g)
             assert len(taken) == (2 if (bwd_hook and defer) else 0), "both 16-channel data-gradient kernels have the BN-backward statistics hook"
-            assert not o.BnBwdSinks._by_ptr
+            assert not o.BnBwdSinks.entries
             for name in ("base_layer.0.weight", "base_layer.1.weight", "base_layer.1.bias", "level0.0.weight", "level0.1.weight",
                          "level0.1.bias", "level1.0.weight", "level1.1.weight"):
                 out[name] = net.get_parameter(name).grad.detach().float().clone()
