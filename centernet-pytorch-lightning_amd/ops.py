@@ -987,10 +987,13 @@ class BnDeferFn(Function):
         ctx.cfg = (relu, False)
         ctx.res_cell = None
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)          # (no zero tensor for the statistics output's gradient: an ATen fill per step otherwise)
         return x.view_as(x), stats
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
+        if dy is None:
+            return None, None, None, None, None, None, None
         r = BatchNormActFn.backward(ctx, dy)
         return r[0], r[1], r[2], None, None, None, None
 
@@ -1024,10 +1027,13 @@ class StemBnDeferFn(Function):
         ctx.cfg = (stride, pad, relu)
         ctx.order = SideGrads.next_order()
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return y, stats
 
     @staticmethod
     def backward(ctx, dy, _dstats=None):
+        if dy is None:
+            return None, None, None, None, None, None, None, None, None, None
         img, weight, gamma, y, stats = ctx.saved_tensors
         beta = ctx.beta_ref
         stride, pad, relu = ctx.cfg

@@ -31,3 +31,16 @@ for i, (n, s, e) in enumerate(seg):
 print("---- producers without a BN statistics hook (launches, us in bn_partial<0>, us in the finalize launch behind it)")
 for k, (c_, a, b) in sorted(prod.items(), key=lambda kv: -kv[1][1]):
     print(f"  {c_:3d}  {a:8.1f} us  {b:7.1f} us  {k}")
+# short kernels of the step (every launch-stream kernel boundary costs ~3.7 us of serialisation on top of its run time: +212 one-thread
+# launches = +0.78 ms, measured): launches under 12 us by name
+small = {}
+for n, s, e in seg:
+    d = (e - s) / 1e3
+    if d < 12.0:
+        k = short(n)
+        v = small.setdefault(k, [0, 0.0])
+        v[0] += 1; v[1] += d
+print("---- kernels under 12 us (launches per step, total us)")
+for k, (c_, a) in sorted(small.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {c_:4d}  {a:8.1f} us  {k}")
+print(f"  total {sum(v[0] for v in small.values())} launches, {sum(v[1] for v in small.values()):.1f} us")
