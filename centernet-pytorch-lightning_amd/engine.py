@@ -393,6 +393,7 @@ class TrainStep:
         SideGrads.fwd_order = 0
         if not self.opt.flat_p.is_cuda:
             return
+        ops.FarFlags.begin(self.opt.flat_p.device, id(self))
         PackArena.current = self._packs
         if self._packs.table is not None:
             self._packs.repack()
@@ -403,6 +404,7 @@ class TrainStep:
         if self._packs.recording:
             self._packs.build()
         PackArena.current = None
+        ops.FarFlags.end()
 
     def _eager(self, batch, batch_idx=0):
         # this step's chain of BatchNorm statistics sinks, kept apart from every other chain in the process.  Once a graph has
@@ -426,6 +428,7 @@ class TrainStep:
             # must be all-zero when armed): clear them, or the next training-mode BN of that width normalises with stale sums
             ops.BnStats.reset()
             PackArena.current, self._packs.recording = None, False
+            ops.FarFlags.end()
             raise
         self._fork_post_forward()
         if self.sync is not None and not self._between:
@@ -453,6 +456,7 @@ class TrainStep:
         SideGrads.pending, SideGrads.active = [], False
         GradReady.sink = GradReady.claim_sink = None
         PackArena.current, self._packs.recording = None, False
+        ops.FarFlags.end()
         ops.BnStats.reset()
         if self.sync is not None:
             self.sync.abort()

@@ -74,6 +74,39 @@ def _pack_dims(shape, mode):
 _FAR_BUFFERS = {}
 
 
+class FarFlags:
+    """The per-call `far_flag` words of the DCN backward (set by the offset / mask gradient kernel when a sample left the tile window,
+    read by the data gradient kernel).  Every launch-stream kernel boundary of a replayed step costs ~3.7 us: inside a TrainStep the 16
+    one-word zero fills become ONE fill of a persistent 64-word array at the start of the step, each DCN layer takes the next word."""
+    SLOTS = 64
+    enabled = not _os.environ.get("CN_DISABLE_FAR_FLAG_ARRAY")
+    _buf, _cur, _next, active = {}, None, 0, False
+
+    @classmethod
+    def begin(cls, device, owner=None):
+        """owner: the TrainStep (a captured graph bakes the array's address in: every step object has its own)"""
+        if not cls.enabled:
+            return
+        key = (str(device), owner)
+        buf = cls._buf.get(key)
+        if buf is None:
+            buf = cls._buf[key] = torch.empty(cls.SLOTS, dtype=torch.int32, device=device)
+        call("cn_zero", buf, cls.SLOTS * 4)
+        cls._cur, cls._next, cls.active = buf, 0, True
+
+    @classmethod
+    def end(cls):
+        cls.active, cls._cur = False, None
+
+    @classmethod
+    def take(cls, device):
+        buf = cls._cur
+        if not cls.active or buf is None or buf.device != device or cls._next >= cls.SLOTS:
+            return zeros((1,), torch.int32, device)
+        cls._next += 1
+        return buf[cls._next - 1:cls._next]
+
+
 def _far_buffer(shape, device):
     """persistent all-zero fp32 scratch for DCN far samples (cn_dcn_bwd_dx restores the zeros it consumes)"""
     key = (tuple(shape), str(device))
@@ -1410,7 +1443,7 @@ class DCNv2Fn(Function):
             # dx_far (samples displaced > 3 px: rare) follows the lazy protocol of the header: one persistent all-zero
             # buffer per shape + a per-call flag, instead of clearing and re-reading 4*P*Ci bytes per layer per step
             dx_far = _far_buffer((N, H, W, Ci), x.device)
-            far_flag = zeros((1,), torch.int32, x.device)
+            far_flag = FarFlags.take(x.device)
             slabs = _hip.query("cn_dcn_bwd_dom_slabs", int(Ci), int(dy.shape[-1]), dt)
             direct = (x.dtype == torch.bfloat16 and Ci == 64 and slabs == 1 and dy.shape[-1] in (64, 128)
                       and not _os.environ.get("CN_DISABLE_DOM_TILE"))
