@@ -374,7 +374,7 @@ __device__ static inline void dcn_dom_accumulate(const ConvGeom& g, f32x16_t (&a
 void dcn_bwd_dx_launch(const ConvGeom& g, int dtype, hipStream_t st);
 void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st);
 bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                         int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st);
+                         int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st);
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
                        int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st);   // dcn_bm.hip: blend on the matrix cores
 bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld);

@@ -26,6 +26,7 @@
 struct FwdTileGeom {
     const bf16_t* x; const bf16_t* w; const float* om; const float* bias; bf16_t* y;
     int N, H, W, Ci, Co, x_ld, y_ld, om_ld, ktot, relu;
+    float* bn_part; int bn_slots;     // BatchNorm statistics sink (cn_bn_stats_arm), nullable: sum / sum of squares of the stored values
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -65,6 +66,11 @@ __global__ __launch_bounds__(512) void dcn_fwd_tile_kernel(const FwdTileGeom g) 
     const int tpb = (ntiles + G - 1) / G;
     const int t_begin = lb * tpb, t_end = min(ntiles, t_begin + tpb);
     if (t_begin >= t_end) return;
+    // BatchNorm statistics of the stored values (sink protocol of bn.hip): this thread's channel vector over every pixel it stores
+    const bool stats = g.bn_part != nullptr;
+    float bs0[8], bs1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs0[e] = 0.f; bs1[e] = 0.f; }
 
     constexpr int XV = (FT_HP * 8 + 511) / 512;      // halo vectors per thread
     constexpr int GV = (BM * 9 + 511) / 512;         // (pixel, tap) geometry items per thread
@@ -252,10 +258,20 @@ __global__ __launch_bounds__(512) void dcn_fwd_tile_kernel(const FwdTileGeom g) 
             const int v = tid + i * 512;
             const int pl = v / (BN / 8), col = (v % (BN / 8)) * 8;
             const int h = th0 + pl / FT_TW, w = tw0 + pl % FT_TW;
-            if (h < g.H && w < g.W && n0 + col < g.y_ld)
-                *reinterpret_cast<uint4*>(g.y + (img + (int64_t)h * g.W + w) * g.y_ld + n0 + col) = *reinterpret_cast<const uint4*>(Es + pl * EP + col);
+            if (h < g.H && w < g.W && n0 + col < g.y_ld) {
+                const uint4 o = *reinterpret_cast<const uint4*>(Es + pl * EP + col);
+                *reinterpret_cast<uint4*>(g.y + (img + (int64_t)h * g.W + w) * g.y_ld + n0 + col) = o;
+                if (stats) {                                   // a thread stores the same channel vector in every pass of every tile
+                    const uint32_t wv[4] = {o.x, o.y, o.z, o.w};
+                    bn_stat_add(bs0, bs1, wv);
+                }
+            }
         }
         __syncthreads();                                       // Es (= As) and Geo are rewritten by the next tile
+    }
+    if (stats) {
+        static_assert(512 % (BN / 8) == 0, "thread -> channel-vector map of the statistics");
+        bn_stats_flush<BN / 8, 512>(bs0, bs1, reinterpret_cast<float*>(As), g.bn_part, g.bn_slots, g.y_ld, n0, g.Co, blockIdx.x + blockIdx.y * gridDim.x, tid);
     }
 }
 
@@ -271,11 +287,14 @@ bool dcn_fwd_tile_shape_ok(int Ci, int x_ld, int Co, int y_ld) {
 }
 
 bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                         int Co, int y_ld, int om_ld, int ktot, int relu, hipStream_t st) {
+                         int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st) {
     if (!dcn_fwd_tile_shape_ok(Ci, x_ld, Co, y_ld) || relu > 1) return false;
     FwdTileGeom g;
     g.x = (const bf16_t*)x; g.w = (const bf16_t*)wp; g.om = om; g.bias = bias; g.y = (bf16_t*)y;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.relu = relu;
+    static const bool no_stats = getenv("CN_DISABLE_DCN_TILE_STATS") != nullptr;
+    g.bn_part = (bn_slots > 0 && !no_stats) ? bn_part : nullptr; g.bn_slots = bn_slots;
+    if (g.bn_part) bn_sink_mark_taken();            // the LDS-staged epilogue has the statistics hook
     const int bn = (Co % 128 == 0) ? 128 : 64;
     const int nco = Co / bn;
     const int ntiles = ((H + FT_TH - 1) / FT_TH) * ((W + FT_TW - 1) / FT_TW) * N;
