@@ -761,8 +761,10 @@ extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const 
         return CN_OK;
     }
     if (!(dtype == CN_BF16 && dcn_fwd_tile_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr, sink.slots,
-                                                  (hipStream_t)stream)))
+                                                  (hipStream_t)stream))) {
+        if (sink_ok) { g.bn_part = sink.part; g.bn_slots = sink.slots; }      // honoured where the gather kernel runs its LDS-staged epilogue
         dcn_fwd_launch(g, dtype, (hipStream_t)stream);
+    }
     CN_LAUNCH_CHECK("cn_dcn_fwd");
     return CN_OK;
 }

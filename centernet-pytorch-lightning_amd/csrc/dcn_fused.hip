@@ -406,6 +406,16 @@ __global__ __launch_bounds__(256) void dcn_fwd_kernel(const ConvGeom g) {
         const int oh = th0 + m / DX_TW, ow = tw0 + m % DX_TW;
         pix[i] = (oh < g.H && ow < g.W) ? img + (int64_t)oh * g.W + ow : -1;
     }
+    if constexpr (sizeof(T) == 2 && (size_t)WGM * 32 * (BN + 4) * sizeof(float) <= (size_t)(BM + BN) * PITCH * sizeof(T)) {
+        if (g.epi_tile) {                              // the main loop ended on a barrier: the operand tiles are dead.  LDS-staged epilogue:
+            // 16-byte stores and the BatchNorm statistics hook (sum / sum of squares of the stored values)
+            conv_epilogue_tile<MI, NJ, WGM, WGN>(g, acc, reinterpret_cast<float*>(lds), n0, tid, [&](int m) -> int64_t {
+                const int oh = th0 + m / DX_TW, ow = tw0 + m % DX_TW;
+                return (oh < g.H && ow < g.W) ? img + (int64_t)oh * g.W + ow : -1;
+            });
+            return;
+        }
+    }
     conv_epilogue<T, MI, NJ>(g, acc, pix, n0 + wn, lane);
 }
 
@@ -415,12 +425,21 @@ static void launch_fwd(const ConvGeom& g, hipStream_t st) {
     hipLaunchKernelGGL((dcn_fwd_kernel<T, BN, CK>), grid, dim3(256), 0, st, g);
 }
 
-void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st) {
+void dcn_fwd_launch(const ConvGeom& g_, int dtype, hipStream_t st) {
+    ConvGeom g = g_;
     const int co32 = (g.Co + 31) / 32 * 32;
     int bn = 32, bw = co32;
     for (int c : {64, 128}) {
         int w = (co32 + c - 1) / c * c;
         if (w <= bw) { bn = c; bw = w; }
+    }
+    // LDS-staged epilogue (16-byte stores, BatchNorm statistics hook) where the output rows are vectors and the slab fits the operand
+    // tiles' LDS (64-channel slices: every tile width; 32-channel slices: the 32-wide tile only)
+    static const bool no_tile = getenv("CN_DISABLE_EPI_TILE") != nullptr || getenv("CN_DISABLE_DCN_GATHER_EPI_TILE") != nullptr;
+    const bool fits = g.Ci % 64 == 0 || (g.Ci % 32 == 0 && bn == 32);
+    g.epi_tile = (dtype == CN_BF16 && !no_tile && fits && conv_epi_tile_ok(g, dtype)) ? 1 : 0;
+    if (g.bn_part) {
+        if (g.epi_tile) bn_sink_mark_taken(); else g.bn_part = nullptr;
     }
     if (dtype == CN_BF16) {
         if (g.Ci % 64 == 0) { if (bn == 128) launch_fwd<bf16_t, 128, 64>(g, st); else if (bn == 64) launch_fwd<bf16_t, 64, 64>(g, st); else launch_fwd<bf16_t, 32, 64>(g, st); }

@@ -795,6 +795,7 @@ BN_STAT_PRODUCERS = [  # kind, N, H, W, Ci, Co, k, stride  (which kernel: see th
     ("dcn", 1, 9, 7, 64, 32, 3, 1),
     ("dcn", 2, 12, 20, 128, 128, 3, 1),       # LDS-resident tile DCNv2 forward (>= 128 channels on both sides)
     ("dcn", 1, 9, 7, 256, 128, 3, 1),
+    ("dcn", 2, 12, 20, 128, 64, 3, 1),        # gather DCNv2 forward with the LDS-staged epilogue (128 -> 64: neither matrix-core-blend nor tile kernel)
     ("conv", 2, 9, 70, 16, 16, 3, 1),         # row-walking 16-channel kernel (DLA level0)
     ("conv", 2, 38, 70, 16, 32, 3, 2),        # ... stride 2, two output-channel blocks (DLA level1)
     ("stem", 2, 37, 41, 3, 16, 7, 1),         # 7x7 stem on the NCHW fp32 image (DLA base_layer)
