@@ -11,7 +11,7 @@ import sqlite3, re
 c = sqlite3.connect("$db")
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 # the last replay: from the last stem kernel to the end
-stem = [i for i, r in enumerate(rows) if "stem7_fwd" in r[0]]
+stem = [i for i, r in enumerate(rows) if "stem7_" in r[0]]
 seg = rows[stem[-1]:]
 t0 = seg[0][1]
 print(f"last replayed batch: {len(seg)} kernels, span {(seg[-1][2] - t0) / 1e6:.3f} ms")
