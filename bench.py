@@ -262,7 +262,9 @@ def inference_rate(model, x, steps=20):
     def infer():
         with torch.no_grad():
             out = model(x)[-1]
-            return ctdet_decode(sigmoid_clamped(out["heatmap"]), out["width_height"], reg=out["regression"])
+            # sigmoid + clamp applied by the top-K kernel on load (cn_ctdet_decode_logits): bit-identical detections to
+            # ctdet_decode(sigmoid_clamped(hm), ...), without the separate pass over the 335 MB map
+            return ctdet_decode(out["heatmap"], out["width_height"], reg=out["regression"], logits_clamp=1e-4)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

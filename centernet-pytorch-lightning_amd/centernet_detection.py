@@ -57,8 +57,12 @@ class CenterNetDetection(CenterNet):
         return loss, {"loss": loss, "hm_loss": hm_loss, "wh_loss": wh_loss, "off_loss": off_loss}
 
     @torch.no_grad()
-    def decode(self, output, K=100):
-        """The decode call of test_step_end (centernet_detection.py:183-187): sigmoid in place, then ctdet_decode."""
+    def decode(self, output, K=100, fused=False):
+        """The decode call of test_step_end (centernet_detection.py:183-187): sigmoid in place, then ctdet_decode.
+        fused=True (opt-in, throughput path): the sigmoid is applied by the top-K kernel on load (cn_ctdet_decode_logits, no pass over
+        the map, `output["heatmap"]` keeps the logits); its expf-based sigmoid may differ from ATen's in the last bit of a score."""
+        if fused:
+            return ctdet_decode(output["heatmap"], output["width_height"], reg=output["regression"], K=K, logits_clamp=0.0)
         return ctdet_decode(output["heatmap"].sigmoid_(), output["width_height"], reg=output["regression"], K=K)
 
     @torch.no_grad()

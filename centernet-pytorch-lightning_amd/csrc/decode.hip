@@ -255,9 +255,20 @@ __global__ __launch_bounds__(TK_THREADS) void topk_channel_kernel(const float* _
 // neighbour columns from the adjacent lanes.  Bytes per map: 64 KB read once (+12 % halo rows, L2 hits), 800 B written.
 __device__ static inline float ts_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-template <bool NMS>
+// SIG: `heat` holds LOGITS; the kernel applies y = clamp(1 / (1 + expf(-x)), lo, 1 - lo) — the arithmetic of sigmoid_clamp_fwd_vec_kernel,
+// bit for bit — to every value it loads, so the sigmoid pass over the map (read + 2 writes of 335 MB at C3) disappears from inference
+template <bool NMS, bool SIG = false>
 __global__ __launch_bounds__(TS_THREADS, 3) void topk_map128_kernel(const float* __restrict__ heat, float* __restrict__ scores,
-                                                                    int32_t* __restrict__ inds, int K) {
+                                                                    int32_t* __restrict__ inds, int K, float lo = 0.f) {
+    auto act = [&](float4 v) {
+        if constexpr (SIG) {
+            const float hi = 1.f - lo;
+            float* e = &v.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = fminf(fmaxf(1.f / (1.f + expf(-e[j])), lo), hi);
+        }
+        return v;
+    };
     __shared__ TsShared sh;
     const int tid = threadIdx.x, x4 = tid & 31, row0 = (tid >> 5) * 16;
     const float* src = heat + (int64_t)blockIdx.x * 16384 + x4 * 4;
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(TS_THREADS, 3) void topk_map128_kernel(const float*
         for (int j = 0; j < 18; ++j) {             // branch-free: rows outside the map re-read a border row and are replaced by -inf
             const int r = row0 - 1 + j;
             const int rc = r < 0 ? 0 : (r > 127 ? 127 : r);
-            raw[j] = *reinterpret_cast<const float4*>(src + rc * 128);
+            raw[j] = act(*reinterpret_cast<const float4*>(src + rc * 128));
         }
         const float ninf = -INFINITY;
         if (row0 == 0) raw[0] = make_float4(ninf, ninf, ninf, ninf);
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(TS_THREADS, 3) void topk_map128_kernel(const float*
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float4 c = *reinterpret_cast<const float4*>(src + (row0 + j) * 128);
+            const float4 c = act(*reinterpret_cast<const float4*>(src + (row0 + j) * 128));
             key[4 * j + 0] = ts_f2key(c.x); key[4 * j + 1] = ts_f2key(c.y); key[4 * j + 2] = ts_f2key(c.z); key[4 * j + 3] = ts_f2key(c.w);
         }
     }
@@ -312,9 +323,18 @@ static bool topk_stream_enabled() {
     return on;
 }
 
+// sig_lo >= 0: heat holds logits, sigmoid + clamp(sig_lo, 1 - sig_lo) on load (streaming kernel only: CN_EUNSUPPORTED otherwise)
 static int launch_topk_channel(const float* heat, float* scores, int32_t* inds, int BC, int H, int W, int K, int apply_nms,
-                               hipStream_t st) {
+                               hipStream_t st, float sig_lo = -1.f) {
     const int HW = H * W;
+    if (sig_lo >= 0.f) {
+        if (!(H == 128 && W == 128 && K >= 1 && K <= TS_CAND && topk_stream_enabled() && (((uintptr_t)heat) & 15) == 0 && apply_nms)) {
+            cn_set_error("top-K on logits: 128x128 maps with the pseudo-NMS only");
+            return CN_EUNSUPPORTED;
+        }
+        hipLaunchKernelGGL((topk_map128_kernel<true, true>), dim3(BC), dim3(TS_THREADS), 0, st, heat, scores, inds, K, sig_lo);
+        return CN_OK;
+    }
     if (H == 128 && W == 128 && K >= 1 && K <= TS_CAND && topk_stream_enabled() && (((uintptr_t)heat) & 15) == 0) {
         if (apply_nms) hipLaunchKernelGGL(topk_map128_kernel<true>, dim3(BC), dim3(TS_THREADS), 0, st, heat, scores, inds, K);
         else hipLaunchKernelGGL(topk_map128_kernel<false>, dim3(BC), dim3(TS_THREADS), 0, st, heat, scores, inds, K);
@@ -529,15 +549,29 @@ __global__ __launch_bounds__(TS_THREADS) void ctdet_stage2_stream_kernel(const f
 
 extern "C" size_t cn_ctdet_decode_workspace_bytes(int B, int C, int K) { return (size_t)B * C * K * 8; }
 
+static int ctdet_decode_impl(const float* heat, const float* wh, const float* reg, float* det, int64_t* inds, int32_t* clses,
+                            int B, int C, int H, int W, int K, void* ws, size_t ws_bytes, void* stream, float sig_lo);
 extern "C" int cn_ctdet_decode(const float* heat, const float* wh, const float* reg, float* det, int64_t* inds, int32_t* clses,
                                int B, int C, int H, int W, int K, void* ws, size_t ws_bytes, void* stream) {
+    return ctdet_decode_impl(heat, wh, reg, det, inds, clses, B, C, H, W, K, ws, ws_bytes, stream, -1.f);
+}
+// cn_ctdet_decode on the LOGITS of the class heat map: scores = clamp(sigmoid(logit), lo, 1 - lo) computed by the top-K kernel on load
+// (same arithmetic as cn_sigmoid_clamp_fwd: the detections are bit-identical to cn_sigmoid_clamp_fwd + cn_ctdet_decode), the map itself
+// is left untouched.  128x128 maps only (CN_EUNSUPPORTED otherwise: run the two calls).
+extern "C" int cn_ctdet_decode_logits(const float* heat_logits, const float* wh, const float* reg, float* det, int64_t* inds, int32_t* clses,
+                                      int B, int C, int H, int W, int K, float lo, void* ws, size_t ws_bytes, void* stream) {
+    CN_CHECK_ARG(lo >= 0.f && lo < 0.5f, "cn_ctdet_decode_logits: clamp %f", (double)lo);
+    return ctdet_decode_impl(heat_logits, wh, reg, det, inds, clses, B, C, H, W, K, ws, ws_bytes, stream, lo);
+}
+static int ctdet_decode_impl(const float* heat, const float* wh, const float* reg, float* det, int64_t* inds, int32_t* clses,
+                            int B, int C, int H, int W, int K, void* ws, size_t ws_bytes, void* stream, float sig_lo) {
     CN_CHECK_ARG(heat && wh && det && ws && B > 0 && C > 0 && H > 0 && W > 0, "cn_ctdet_decode: bad args");
     if (ws_bytes < cn_ctdet_decode_workspace_bytes(B, C, K)) { cn_set_error("cn_ctdet_decode: workspace too small"); return CN_EWORKSPACE; }
     if ((int64_t)C * K > 32768) CN_UNSUPPORTED("cn_ctdet_decode: C*K=%d exceeds 32768", C * K);
     hipStream_t st = (hipStream_t)stream;
     float* s1 = (float*)ws;
     int32_t* i1 = (int32_t*)(s1 + (size_t)B * C * K);
-    int rc = launch_topk_channel(heat, s1, i1, B * C, H, W, K, 1, st);
+    int rc = launch_topk_channel(heat, s1, i1, B * C, H, W, K, 1, st, sig_lo);
     if (rc) return rc;
     CN_LAUNCH_CHECK("cn_ctdet_decode(stage1)");
     if (C * K <= 32 * TS_THREADS && K <= TS_CAND && topk_stream_enabled()) {

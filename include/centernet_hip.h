@@ -465,6 +465,11 @@ size_t cn_ctdet_decode_workspace_bytes(int B, int C, int K);
 int cn_ctdet_decode(const float* heat, const float* wh, const float* reg /* nullable */, float* det,
                     int64_t* inds, int32_t* clses, int B, int C, int H, int W, int K,
                     void* ws, size_t ws_bytes, void* stream);
+/* cn_ctdet_decode on the LOGITS of the class heat map: the top-K kernel applies clamp(sigmoid(x), lo, 1 - lo) on load (the arithmetic of
+ * cn_sigmoid_clamp_fwd, bit-identical detections), the map is left untouched — no sigmoid pass over the map in inference
+ * (centernet_detection.py:183-187).  128x128 maps only: CN_EUNSUPPORTED otherwise (run cn_sigmoid_clamp_fwd + cn_ctdet_decode). */
+int cn_ctdet_decode_logits(const float* heat_logits, const float* wh, const float* reg, float* det, int64_t* inds, int32_t* clses,
+                           int B, int C, int H, int W, int K, float lo, void* ws, size_t ws_bytes, void* stream);
 /* fused multi_pose_decode (decode/multi_pose.py:7-96): det fp32 [B,K,5+2J+1+J] */
 size_t cn_multi_pose_decode_workspace_bytes(int B, int J, int K);
 int cn_multi_pose_decode(const float* heat, const float* wh, const float* kps, const float* reg /* nullable */,

@@ -438,6 +438,28 @@ def test_fused_sigmoid_focal_matches_two_step():
     assert alt.dtype == torch.bfloat16 and tuple(alt.shape) == (2, 128, 128, 80) and torch.equal(alt, ref)
 
 
+@pytest.mark.parametrize("cfg", [(2, 80, 128, 128, 100, 0), (3, 5, 128, 128, 40, 1), (1, 17, 128, 128, 7, 2), (2, 3, 64, 64, 20, 0)])
+def test_ctdet_decode_from_logits_equals_sigmoid_then_decode(cfg):
+    """cn_ctdet_decode_logits: the top-K kernel applies clamp(sigmoid(x), lo, 1 - lo) to the logits it loads — the arithmetic of
+    cn_sigmoid_clamp_fwd — so detections, indices and classes are BIT-identical to sigmoid_clamped + ctdet_decode
+    (centernet_detection.py:183-187) and the logits stay untouched.  Quantised logits (many ties), saturating logits (sigmoid = clamp
+    bound: plateaus of equal scores) included; a 64x64 map takes the two-step fallback."""
+    from centernet_amd.decode.ctdet import ctdet_decode
+    from centernet_amd.utils.decode import sigmoid_clamped
+    B, C, H, W, K, kind = cfg
+    z = rng.t_normal(77, f"z{cfg}", (B, C, H, W))
+    z = z * 0.5 - 2.19 if kind == 0 else ((z * 4).round() / 4 if kind == 1 else z * 12.0)
+    wh = rng.t_uniform(77, f"wh{cfg}", (B, 2, H, W), 1, 30).to(DEV)
+    reg = rng.t_uniform(77, f"reg{cfg}", (B, 2, H, W)).to(DEV)
+    zl = z.to(DEV).contiguous()
+    keep = zl.clone()
+    got = ctdet_decode(zl, wh, reg, K=K, return_aux=True, logits_clamp=1e-4)
+    assert torch.equal(zl, keep), "the logits are left untouched"
+    ref = ctdet_decode(sigmoid_clamped(zl.clone(), 1e-4), wh, reg, K=K, return_aux=True)
+    for a, b, nm in zip(got, ref, ("det", "inds", "classes")):
+        assert torch.equal(a, b), nm
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_ctdet_decode_fuzz_bit_exact(seed):
     """Random map sizes (both NMS code paths: rows that divide the 1024-thread strip layout and rows that do not), class

@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--arch", default="dla_34"); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--size", type=int, default=512); ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--task", default="ctdet")
+ap.add_argument("--two-step", action="store_true", help="sigmoid_clamped pass + ctdet_decode instead of the decode on logits")
 args = ap.parse_args()
 from centernet_amd import synth
 from centernet_amd.centernet_detection import CenterNetDetection
@@ -21,7 +22,9 @@ x = x.repeat((args.batch + 7) // 8, 1, 1, 1)[:args.batch].to(dev)
 def infer():
     with torch.no_grad():
         out = model(x)[-1]
-        return ctdet_decode(sigmoid_clamped(out["heatmap"]), out["width_height"], reg=out["regression"])
+        if args.two_step:
+            return ctdet_decode(sigmoid_clamped(out["heatmap"]), out["width_height"], reg=out["regression"])
+        return ctdet_decode(out["heatmap"], out["width_height"], reg=out["regression"], logits_clamp=1e-4)
 
 for _ in range(3):
     det = infer()
