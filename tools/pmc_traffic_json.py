@@ -23,6 +23,14 @@ KERNELS = {
     "dcn_wgrad_bm_kernel": ("dcn_wgrad_bm_kernel", CSRC + "dcn_bm.hip", "weight gradient of the DCN layers (launch mix)"),
     "topk_map128_kernel": ("topk_map128_kernel<true>", CSRC + "topk_stream.h", "B=64, C=80, 128x128 fp32 maps: 335.5 MB algorithmic read (SURVEY 8d)"),
     "bn_bwd_apply_kernel<unsigned short": ("bn_bwd_apply_kernel<bf16>", CSRC + "bn.hip", "launch mix of all BN layers"),
+    "conv3x3_c16r_kernel<1, 1, 2>": ("conv3x3_c16r_kernel<1,1,AFF>", CSRC + "conv_c16.hip",
+                                     "level0 forward 16->16 @512^2 with the stem's BN + ReLU applied on load: 537 MB in + 537 MB out algorithmic"),
+    "conv3x3_c16r_kernel<1, 1, 0>": ("conv3x3_c16r_kernel<1,1,0>", CSRC + "conv_c16.hip",
+                                     "level0 data gradient 16->16 @512^2 with the BN-backward statistics hook: 537 MB dy + 537 MB x in, 537 MB out algorithmic"),
+    "conv3x3_c16r_kernel<2, 2, 2>": ("conv3x3_c16r_kernel<2,2,AFF>", CSRC + "conv_c16.hip",
+                                     "level1 forward 16->32 stride 2: 537 MB in + 268 MB out algorithmic"),
+    "stem7_rows_kernel": ("stem7_rows_kernel", CSRC + "wgrad_c16.hip", "stem 3->16 @512^2: 201 MB fp32 image in + 537 MB out algorithmic"),
+    "pack_weight_batch_kernel": ("pack_weight_batch_kernel", CSRC + "conv_igemm.hip", "170 MB fp32 source (every weight read once per packing mode) + 86 MB bf16 out algorithmic"),
 }
 raw = [l.strip() for l in open(sys.argv[1]) if l.strip()]
 vals = {}
