@@ -21,6 +21,7 @@
 // row it does not belong to — not a concern for activations that are finite, which everything downstream needs anyway.
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(4))) float c16_f32x4;
 typedef __attribute__((ext_vector_type(2))) float c16_f32x2;
@@ -113,8 +114,19 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
         colB[gq] = (iwB * g.x_ld + half * 8) * 2 + (tsel ? rowpitch : 0);
     }
     const int64_t img = (int64_t)n * g.H * rowpitch;
-    // raw loads of input row ih: a = La(ih) (with_b: and b = Lb(ih))
-    auto load_row = [&](C16Slot& s, int ih, bool with_b) {
+    const char* const Xb = reinterpret_cast<const char*>(X) + img;
+    // raw loads of input row ih: a = La(ih) (with_b: and b = Lb(ih)).  FAST (an INTERIOR wave, see below): every row and column it touches
+    // is inside the image — a scalar row base plus this lane's 32-bit column offset, no masks, no address selects
+    auto load_row = [&](auto fast, C16Slot& s, int ih, bool with_b) {
+        if constexpr (decltype(fast)::value) {
+            const char* const rp = Xb + (int64_t)ih * rowpitch;            // uniform
+#pragma unroll
+            for (int gq = 0; gq < CR_G; ++gq) {
+                s.a[gq] = ldg16(rp + (unsigned)colA[gq]);
+                if (with_b) s.b[gq] = ldg16(rp + (unsigned)colB[gq]);
+            }
+            return;
+        }
         const bool rv0 = (unsigned)ih < (unsigned)g.H, rv1 = (unsigned)(ih + 1) < (unsigned)g.H;
         const bool rvb = tsel ? rv1 : rv0;
         const int64_t rbase = img + (int64_t)ih * rowpitch;
@@ -130,8 +142,16 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
         }
     };
     // the affine map of a slot whose loads were issued a step ago (no-op without AFF)
-    auto fix_row = [&](C16Slot& s, int ih, bool with_b) {
+    auto fix_row = [&](auto fast, C16Slot& s, int ih, bool with_b) {
         if constexpr (AFF != 0) {
+            if constexpr (decltype(fast)::value) {
+#pragma unroll
+                for (int gq = 0; gq < CR_G; ++gq) {
+                    s.a[gq] = c16_fix<AFF>(s.a[gq], sc, sh, true);
+                    if (with_b) s.b[gq] = c16_fix<AFF>(s.b[gq], sc, sh, true);
+                }
+                return;
+            }
             const bool rv0 = (unsigned)ih < (unsigned)g.H, rv1 = (unsigned)(ih + 1) < (unsigned)g.H;
             const bool rvb = tsel ? rv1 : rv0;
 #pragma unroll
@@ -154,9 +174,19 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
         for (int r = 0; r < 4; ++r) { s0[cb][r] = 0.f; s1[cb][r] = 0.f; }
 
     // one output row from the slots holding input rows S oh - 1 (m), S oh (z: only .a) and S oh + 1 (p)
-    auto out_row = [&](const C16Slot& m, const C16Slot& z, const C16Slot& p, int oh) {
-        if (oh >= g.OH) return;
+    // epilogue constants: ReLU as max(v, lo) with a uniform bound, this lane's store offset inside an output row
+    const float relu_lo = g.relu == 1 ? 0.f : -INFINITY;
+    unsigned yofs[CR_G][NCB];
+#pragma unroll
+    for (int gq = 0; gq < CR_G; ++gq)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) yofs[gq][cb] = (unsigned)(((ow0 + gq * 16 + px) * g.y_ld + cb * 16 + 4 * kc) * 2);
+    auto out_row = [&](auto fast, const C16Slot& m, const C16Slot& z, const C16Slot& p, int oh) {
+        constexpr bool FAST = decltype(fast)::value;   // every pixel of the wave inside the row, every channel of the row real: no guards
+        if (!FAST && oh >= g.OH) return;
         const int64_t yrow = ((int64_t)n * g.OH + oh) * g.OW;
+        char* const yrp = reinterpret_cast<char*>(Y) + yrow * g.y_ld * 2;                          // uniform
+        const char* const xrp = reinterpret_cast<const char*>(g.bnb_x) + yrow * g.y_ld * 2;       // (bnb only)
 #pragma unroll
         for (int gq = 0; gq < CR_G; ++gq) {
             const int ow = ow0 + gq * 16 + px;
@@ -169,18 +199,18 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][3], __builtin_bit_cast(bf16x8_t, m.b[gq]), acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][4], __builtin_bit_cast(bf16x8_t, p.b[gq]), acc, 0, 0, 0);
                 const int ch = cb * 16 + 4 * kc;
-                if (ow < g.OW && ch < g.y_ld) {                // y_ld is a multiple of 4; padding channels are written as zeros
-                    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+                if (FAST || (ow < g.OW && ch < g.y_ld)) {      // y_ld is a multiple of 4; padding channels are written as zeros
+                    float v[4] = {fmaxf(acc[0], relu_lo), fmaxf(acc[1], relu_lo), fmaxf(acc[2], relu_lo), fmaxf(acc[3], relu_lo)};
+                    if constexpr (!FAST) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (g.relu == 1) v[r] = fmaxf(v[r], 0.f);
-                        if (ch + r >= g.Co) v[r] = 0.f;
+                        for (int r = 0; r < 4; ++r)
+                            if (ch + r >= g.Co) v[r] = 0.f;
                     }
                     uint2 o;
                     o.x = pk_bf16(v[0], v[1]); o.y = pk_bf16(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(Y + (yrow + ow) * g.y_ld + ch) = o;
+                    *reinterpret_cast<uint2*>(yrp + yofs[gq][cb]) = o;
                     if (bnb) {
-                        const uint2 xq = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.bnb_x) + (yrow + ow) * g.y_ld + ch);
+                        const uint2 xq = *reinterpret_cast<const uint2*>(xrp + yofs[gq][cb]);
                         bnb_lane_add(bl, o, xq, g.bnb_relu, s0[0], s1[0]);
                     } else if (stats) {
                         const float a0 = __uint_as_float(o.x << 16), a1 = __uint_as_float(o.x & 0xffff0000u);
@@ -194,42 +224,50 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
         }
     };
 
-    if (ow0 < g.OW) {
+    // INTERIOR waves (wave-uniform: all of the wave's columns and rows, halo included, inside the image; the whole output block inside the
+    // map; no channel padding) run the guard-free instantiation of the row loop.  With the branch-free masked form everywhere the kernel
+    // issued ~120 VALU instructions per 16-pixel group and row next to 5 MFMAs (40 of them selects): VALU-issue bound at 4.3 TB/s.
+    const bool interior = S * ow0 - 1 >= 0 && S * (ow0 + 16 * CR_G - 1) + 1 < g.W && ow0 + 16 * CR_G <= g.OW && g.Co == g.y_ld &&
+                          g.y_ld == 16 * NCB && S * oh0 - 1 >= 0 && S * (oh0 + R - 1) + 2 + S < g.H && oh0 + R <= g.OH;   // (+ S: the rows the last prefetch touches)
+    auto run = [&](auto fast) {
         if constexpr (S == 1) {
             // ring of four row slots: rows h - 1, h, h + 1 multiply while row h + 2 is in flight
             C16Slot s[4];
-            load_row(s[0], oh0 - 1, true); load_row(s[1], oh0, true); load_row(s[2], oh0 + 1, true);
-            fix_row(s[0], oh0 - 1, true); fix_row(s[1], oh0, true);
+            load_row(fast, s[0], oh0 - 1, true); load_row(fast, s[1], oh0, true); load_row(fast, s[2], oh0 + 1, true);
+            fix_row(fast, s[0], oh0 - 1, true); fix_row(fast, s[1], oh0, true);
 #pragma unroll 1
             for (int r = 0; r < R; r += 4) {
                 const int h = oh0 + r;
                 if (h >= g.OH) break;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    load_row(s[(u + 3) & 3], h + u + 2, true);
-                    fix_row(s[(u + 2) & 3], h + u + 1, true);
-                    out_row(s[u], s[(u + 1) & 3], s[(u + 2) & 3], h + u);
+                    load_row(fast, s[(u + 3) & 3], h + u + 2, true);
+                    fix_row(fast, s[(u + 2) & 3], h + u + 1, true);
+                    out_row(fast, s[u], s[(u + 1) & 3], s[(u + 2) & 3], h + u);
                 }
             }
         } else {
             // odd input rows 2 k + 1 (both loads) and even rows 2 k (La only) in rings of three, indexed by the local step
             C16Slot od[3], ev[3];
-            load_row(od[2], 2 * oh0 - 1, true); load_row(ev[0], 2 * oh0, false); load_row(od[0], 2 * oh0 + 1, true);
-            fix_row(od[2], 2 * oh0 - 1, true);
+            load_row(fast, od[2], 2 * oh0 - 1, true); load_row(fast, ev[0], 2 * oh0, false); load_row(fast, od[0], 2 * oh0 + 1, true);
+            fix_row(fast, od[2], 2 * oh0 - 1, true);
 #pragma unroll 1
             for (int r = 0; r < R; r += 3) {
                 const int oh = oh0 + r;
                 if (oh >= g.OH) break;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    load_row(ev[(u + 1) % 3], 2 * (oh + u) + 2, false);
-                    load_row(od[(u + 1) % 3], 2 * (oh + u) + 3, true);
-                    fix_row(ev[u], 2 * (oh + u), false);
-                    fix_row(od[u], 2 * (oh + u) + 1, true);
-                    out_row(od[(u + 2) % 3], ev[u], od[u], oh + u);
+                    load_row(fast, ev[(u + 1) % 3], 2 * (oh + u) + 2, false);
+                    load_row(fast, od[(u + 1) % 3], 2 * (oh + u) + 3, true);
+                    fix_row(fast, ev[u], 2 * (oh + u), false);
+                    fix_row(fast, od[u], 2 * (oh + u) + 1, true);
+                    out_row(fast, od[(u + 2) % 3], ev[u], od[u], oh + u);
                 }
             }
         }
+    };
+    if (ow0 < g.OW) {
+        if (interior) run(std::true_type{}); else run(std::false_type{});
     }
     if (stats) {
         __shared__ float red[4 * 32];
@@ -251,7 +289,7 @@ bool conv_c16r_launch(const ConvGeom& g, int dtype, int S, hipStream_t st) {
     if (S == 1 && !(g.Co <= 16 && g.y_ld <= 16 && g.co_pad >= 16 && g.OH == g.H && g.OW == g.W)) return false;
     if (S == 2 && !(g.Co > 16 && g.Co <= 32 && g.y_ld <= 32 && g.co_pad >= 32 && g.sm == 2 && g.so == 1)) return false;
     if (g.pre_ss && g.pre_relu != 0 && g.pre_relu != 1) return false;
-    if ((int64_t)g.W * g.x_ld * 2 * g.H >= (int64_t)1 << 31) return false;
+    if ((int64_t)g.W * g.x_ld * 2 * g.H >= (int64_t)1 << 31 || (int64_t)g.OW * g.y_ld * 2 >= (int64_t)1 << 31) return false;
     int R = S == 1 ? (g.OH >= 256 ? 32 : 16) : 12;
     const int sblocks = (g.OW + 64 * CR_G - 1) / (64 * CR_G), rblocks = (g.OH + R - 1) / R;
     const int64_t blocks = (int64_t)8 * ((g.N + 7) / 8) * sblocks * rblocks;

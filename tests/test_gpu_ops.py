@@ -48,6 +48,8 @@ CONVS = [  # N,H,W,Ci,Co,k,s,p,bias,relu
     (1, 33, 129, 16, 16, 3, 1, 1, False, False),
     (1, 70, 45, 16, 16, 3, 1, 1, True, False),      # row-walking 16-channel kernel: several ring rounds per wave, ragged last round
     (1, 75, 45, 16, 32, 3, 2, 1, True, True),       # ... stride 2 (level1 forward), odd sizes
+    (1, 64, 200, 16, 32, 3, 2, 1, False, False),    # ... wide enough for INTERIOR waves (the guard-free instantiation of the row loop)
+    (1, 52, 130, 16, 16, 3, 1, 1, False, False),
     (2, 17, 19, 32, 48, 3, 1, 1, True, True),
     (1, 16, 16, 64, 128, 3, 2, 1, False, False),
     (2, 38, 70, 16, 32, 3, 2, 1, False, False),     # level1 shape: its data gradient runs on dgrad_s2_c32to16_kernel<1,1>
@@ -798,6 +800,8 @@ BN_STAT_PRODUCERS = [  # kind, N, H, W, Ci, Co, k, stride  (which kernel: see th
     ("dcn", 2, 12, 20, 128, 64, 3, 1),        # gather DCNv2 forward with the LDS-staged epilogue (128 -> 64: neither matrix-core-blend nor tile kernel)
     ("conv", 2, 9, 70, 16, 16, 3, 1),         # row-walking 16-channel kernel (DLA level0)
     ("conv", 2, 38, 70, 16, 32, 3, 2),        # ... stride 2, two output-channel blocks (DLA level1)
+    ("conv", 1, 64, 200, 16, 32, 3, 2),       # ... with interior waves
+    ("conv", 1, 52, 130, 16, 16, 3, 1),
     ("stem", 2, 37, 41, 3, 16, 7, 1),         # 7x7 stem on the NCHW fp32 image (DLA base_layer)
 ]
 
@@ -861,7 +865,7 @@ def test_bn_statistics_from_the_producer_epilogue(cfg, fused, monkeypatch):
         assert float((u - v).abs().max()) <= 2e-2 * float(v.abs().max()) + 1e-3, nm
 
 
-@pytest.mark.parametrize("cfg", [(2, 40, 70, 16, 1, True), (1, 75, 45, 32, 2, True), (2, 9, 33, 16, 1, False)])
+@pytest.mark.parametrize("cfg", [(2, 40, 70, 16, 1, True), (1, 75, 45, 32, 2, True), (2, 9, 33, 16, 1, False), (1, 64, 200, 32, 2, True)])
 def test_conv_applies_previous_bn_on_load(cfg):
     """cn_conv_pre_affine_arm: the 16-input-channel kernels take the RAW output of the previous conv and apply that layer's BN
     (+ ReLU) on the way into the matrix cores; the result must be BIT-identical to convolving the tensor cn_scale_shift_act stores
