@@ -6,10 +6,15 @@
 // The blend-matrix kernels (dcn_bm.hip) run the blend as a second MFMA; they sit at 0.15-0.25 MFMA-pipe busy with 14-22 VALU
 // instructions per MFMA (profiles/r04_pmc_sq.txt): selects that build blend-matrix rows, zero fills, a barrier per tap for the
 // weight slices, every tile's loads exposed.  Here:
-//   * the blend is TWO v_dot2_f32_bf16 per channel: a lane reads the four corner pixels of its footprint from the workgroup's halo
-//     image in LDS (16 bytes = 8 channels each), v_perm pairs the horizontal neighbours channel by channel, and
-//         S = dot2({x00, x01}, {w00 m, w01 m}) + dot2({x10, x11}, {w10 m, w11 m})
-//     (the weights enter as bf16, like the blend-matrix kernels' do; products and sums are fp32);
+//   * the blend is FOUR packed-fp16 FMAs per channel PAIR: the halo image sits in LDS as fp16 (converted from the bf16 activations
+//     once per halo pixel: exact for |x| < 65 504, +-inf beyond — fp16 has 3 more mantissa bits than bf16 and the layer inputs are
+//     BatchNorm outputs), a lane reads the four corner pixels of its footprint (16 bytes = 8 channels each) and
+//         S = x00 * w00 m + x01 * w01 m + x10 * w10 m + x11 * w11 m         (v_pk_mul_f16 + 3 v_pk_fma_f16 per 2 channels,
+//     the weights broadcast from packed fp16 pairs with op_sel) — no unpacking, no pairing, no conversion: the fp16 result pairs
+//     ARE the operand of v_mfma_f32_32x32x16_f16 (the weights are converted bf16 -> fp16 once per workgroup, exactly).  The
+//     instruction count is what bounds these kernels: every VALU instruction costs a SIMD 4 cycles, two waves per SIMD — measured
+//     on the two bf16 forms of this kernel (v_perm pairing + v_dot2_f32_bf16: 44 instructions per (unit, k-step), 361 cycles; a
+//     pre-paired image: 30, 233 cycles); this form has 22.  The blend weights and S round to fp16 (2^-11; the bf16 kernels: 2^-8);
 //   * lane = (pixel, channel half): the dot2 results of a lane, packed to bf16, ARE the B operand of the contraction MFMA
 //     (lane = pixel column, 8 consecutive channels per k-step) — nothing is transposed, nothing goes back through LDS;
 //   * the geometry of a (pixel, tap) — two packed weight pairs and the LDS positions of its four corner pixels — is a 16-byte
@@ -18,11 +23,12 @@
 //   * the weights are STATIONARY IN REGISTERS: the two waves that share a 4x8 pixel group split the 18 (tap, channel half) units
 //     9 : 9, each holding its 9 x 16 registers of W fragments for the whole launch (persistent workgroups, one per CU), and meet
 //     once per tile through LDS.  No weight traffic in the loop, no barrier per tap: a tile is four barriers;
-//   * the halo image and the raw offsets of tile t+1 travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging
-//     registers, no VALU but the address) into the other image buffer WHILE tile t is computed.
+//   * the bf16 halo and the raw offsets of tile t+1 travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging
+//     registers, no VALU but the address) into a staging buffer WHILE tile t is computed — one 1 KB piece per wave behind each of
+//     the first eight units; the fp16 image is made from the staging buffer at the top of the tile.
 // Halo image: 15 rows x 24 pixel slots x 128 B per 8x16-pixel tile (offsets up to |d| < 2 px stay inside), the eight 16-byte
-// chunks of pixel slot n XOR-swizzled with (n >> 1) & 7 (applied to the DMA SOURCE address), 24 slots per row: the 16 lanes of a
-// ds_read_b128 group (4x8 pixel groups) then touch 16 different slot numbers mod 16 and tile all 64 banks.
+// chunks of pixel slot n XOR-swizzled with (n >> 1) & 7, 24 slots per row: the 16 lanes of a ds_read_b128 group (4x8 pixel groups)
+// then touch 16 different slot numbers mod 16 and tile all 64 banks.
 // Samples whose footprint leaves the halo: their four corner pixels are copied from global memory into spare pixel slots behind
 // the image (32 slots = 8 such samples per pass) and the record points there — the hot loop knows nothing about them; a tile with
 // more runs the unit loop again for the next 8 with every other record pointed at an all-zero pixel (any offset field is handled;
@@ -38,16 +44,18 @@
 #define GQ_NPIX (GQ_TH * GQ_TW)                  // 128
 #define GQ_NREC (GQ_NPIX * 9)                    // 1152 records x 16 B
 #define GQ_IMG_SLOTS ((GQ_ROWS + 2) * GQ_P)      // 408: the image (360 slots) + 48 spare slots (zero pixel, far corners)
-#define GQ_IMG_BYTES (GQ_IMG_SLOTS * 128)        // 52 224 per buffer
+#define GQ_IMG_BYTES (GQ_IMG_SLOTS * 128)        // 52 224: fp16 image (offset 0)
 #define GQ_ZERO_SLOT (GQ_ROWS * GQ_P)            // slot 360: all-zero pixel
 #define GQ_FAR_SLOT0 (GQ_ROWS * GQ_P + 8)        // slots 368 .. 399: far corners (4 per sample)
 #define GQ_FAR_PER_PASS 8
-#define GQ_REC_OFS (2 * GQ_IMG_BYTES)            // 104 448
+#define GQ_STG_OFS GQ_IMG_BYTES                  // bf16 staging buffer of the NEXT tile's halo: 360 slots x 128 B, linear (DMA target)
+#define GQ_REC_OFS (GQ_STG_OFS + GQ_ROWS * GQ_P * 128)       // 98 304
 #define GQ_OMS_OFS (GQ_REC_OFS + GQ_NREC * 16)   // raw offsets / mask logits [pixel][28 floats] (DMA: 7 granules per pixel)
 #define GQ_HW_OFS (GQ_OMS_OFS + GQ_NPIX * 112)   // corner 00 of every record in image coordinates (int16 pair; read by the far path)
 #define GQ_BIAS_OFS (GQ_HW_OFS + GQ_NREC * 4)    // 64 floats
 #define GQ_BMP_OFS (GQ_BIAS_OFS + 256)           // 36 dwords: bitmap of the records whose footprint left the halo; dword 36: their count
-#define GQ_SMEM (GQ_BMP_OFS + 160)               // 142 240
+#define GQ_SMEM (GQ_BMP_OFS + 160)               // 136 096
+#define GQ_NPIECE (45 + 14)                      // DMA pieces per tile: 45 image (row r = J / 3, slots 8 (J % 3) .. + 7), 14 offsets
 
 #ifdef GS_PROBE   // development build only (tools/gs_probe.py): cycle stamps of waves 0 / 1 of the first workgroups, first 4 tiles
 __device__ unsigned long long gs_ts[64 * 2 * 4 * 16];
@@ -69,14 +77,38 @@ struct GsFwdGeom {
     int tiles_w, tiles_img, ntiles;
 };
 
-__device__ static inline float gs_dot2(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2g, a), __builtin_bit_cast(bf16x2g, b), c, false);
+typedef _Float16 f16x2g __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+__device__ static inline uint32_t gq_pk_f16(float a, float b) {
+    const f32x2g v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2g));
 }
-// a.lo * b.lo + a.hi * b.hi with the VOP3P form and an inline 0 addend (the builtin selects v_dot2c + a v_mov 0 per result)
-__device__ static inline float gs_dot2z(uint32_t a, uint32_t b) {
-    float d;
-    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+// a packed bf16 pair as a packed fp16 pair (exact below 65 504 in magnitude)
+__device__ static inline uint32_t gq_bf2h(uint32_t d) { return gq_pk_f16(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u)); }
+__device__ static inline u32x4g gq_bf2h4(u32x4g v) { return u32x4g{gq_bf2h(v[0]), gq_bf2h(v[1]), gq_bf2h(v[2]), gq_bf2h(v[3])}; }
+// packed fp16: x * w.lo, x * w.lo + c, x * w.hi + c  (the weight half broadcast to both lanes with op_sel)
+__device__ static inline uint32_t gq_mul_lo(uint32_t x, uint32_t w) {
+    uint32_t d;
+    asm("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(w));
     return d;
+}
+__device__ static inline uint32_t gq_fma_lo(uint32_t x, uint32_t w, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "v"(w), "v"(c));
+    return d;
+}
+__device__ static inline uint32_t gq_fma_hi(uint32_t x, uint32_t w, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_fma_f16 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(d) : "v"(x), "v"(w), "v"(c));
+    return d;
+}
+// the blend of 8 channels: four corner vectors, two weight pairs
+__device__ static inline u32x4g gq_blend(const u32x4g& a, const u32x4g& b, const u32x4g& c, const u32x4g& d, uint32_t w01, uint32_t w23) {
+    u32x4g o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = gq_fma_hi(d[i], w23, gq_fma_lo(c[i], w23, gq_fma_hi(b[i], w01, gq_mul_lo(a[i], w01))));
+    return o;
 }
 
 // position code of pixel slot n inside an image buffer: byte offset of its chunk 0 | swizzle key << 4; logical 16-byte chunk q of
@@ -94,44 +126,45 @@ __device__ static inline int gs_tile_of(int b, int G, int j, int ntiles) {
     return t < lim ? t : -1;
 }
 
-// ---- one tile's halo image and raw offsets by LDS-DMA: 45 + 14 one-KB pieces, piece J = 8 p + wave.  Lane l of an image piece
-//      fills physical chunk l & 7 of pixel slot 8 J + (l >> 3) and fetches the logical chunk that lives there; pixels outside the
-//      image fetch the zero page.  Offsets: granule g = 64 J' + l = (pixel g / 7, 16-byte part g % 7) -> [pixel][28 floats]. ----
-__device__ static inline void gq_issue_tile(const GsFwdGeom& g, int t, unsigned lds_img, unsigned lds_oms, int wave, int lane) {
-    const int n = t / g.tiles_img, rt = t - n * g.tiles_img;
-    const int ty0 = (rt / g.tiles_w) * GQ_TH, tx0 = (rt % g.tiles_w) * GQ_TW;
-    const int64_t img = (int64_t)n * g.H * g.W;
-    const char* const Xb = reinterpret_cast<const char*>(g.x + img * 64);
-    const char* const Ob = reinterpret_cast<const char*>(g.om + img * 32);
-    int ln = lane;
-    asm volatile("" : "+v"(ln));                // per-lane addressing recomputed per tile: hoisted out of the tile loop it pins registers
+// ---- one 1 KB piece J of a tile's bf16 halo (J < 45: halo row J / 3, pixel slots 8 (J % 3) .. + 7, lane l = chunk l & 7 of slot
+//      l >> 3; pixels outside the image fetch the zero page) or of its raw offsets (granule g = 64 (J - 45) + l = (pixel g / 7,
+//      16-byte part g % 7) -> [pixel][28 floats]) by LDS-DMA into the staging areas ----
+__device__ static inline void gq_issue_piece(const GsFwdGeom& g, int J, const char* Xb, const char* Ob, int ty0, int tx0, unsigned lds_base, int ln) {
     const char* const zp = reinterpret_cast<const char*>(gq_zero_page) + (ln & 7) * 16;
-#pragma unroll 1
-    for (int J = wave; J < 45 + 14; J += 8) {
-        const char* src;
-        unsigned dst;
-        if (J < 45) {
-            const int slot = J * 8 + (ln >> 3), r = slot / GQ_P, c = slot - r * GQ_P;
-            const int hy = ty0 - GQ_MG + r, hx = tx0 - GQ_MG + c;
-            const bool ok = (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
-            const int ql = (ln & 7) ^ ((slot >> 1) & 7);
-            src = ok ? Xb + (uint32_t)((hy * g.W + hx) * 128 + ql * 16) : zp;
-            dst = lds_img + (unsigned)(J * 1024);
-        } else {
-            const int gi = (J - 45) * 64 + ln, p = gi / 7, part = gi - 7 * p;
-            const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
-            const bool ok = y < g.H && x < g.W;
-            src = ok ? Ob + (uint32_t)((y * g.W + x) * 128 + part * 16) : zp;
-            dst = lds_oms + (unsigned)((J - 45) * 1024);
+    const char* src;
+    unsigned dst;
+    if (J < 45) {
+        const int r = J / 3, seg = J - 3 * r;
+        const int hy = ty0 - GQ_MG + r, hx = tx0 - GQ_MG + 8 * seg + (ln >> 3);
+        const bool ok = (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
+        src = ok ? Xb + (uint32_t)((hy * g.W + hx) * 128 + (ln & 7) * 16) : zp;
+        dst = lds_base + (unsigned)(GQ_STG_OFS + J * 1024);
+    } else {
+        const int gi = (J - 45) * 64 + ln, p = gi / 7, part = gi - 7 * p;
+        const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
+        const bool ok = y < g.H && x < g.W;
+        src = ok ? Ob + (uint32_t)((y * g.W + x) * 128 + part * 16) : zp;
+        dst = lds_base + (unsigned)(GQ_OMS_OFS + (J - 45) * 1024);
+    }
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// ---- the fp16 image of a tile from the bf16 staging buffer: item = (pixel slot, 16-byte chunk), 2 880 items, 5-6 per thread ----
+__device__ static inline void gq_convert_image(unsigned char* smem, int tid) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int i = tid + 512 * k;
+        if (i < GQ_ROWS * GQ_P * 8) {
+            const u32x4g v = *reinterpret_cast<const u32x4g*>(smem + GQ_STG_OFS + i * 16);
+            *reinterpret_cast<u32x4g*>(smem + (gq_code(i >> 3) ^ (uint32_t)((i & 7) << 4))) = gq_bf2h4(v);
         }
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
 }
 
 // ---- geometry records of a tile: built from the staged offsets by all 512 threads ----
-// record (tap, pixel) = { P0 = bf16 pair (w00 m, w01 m), P1 = (w10 m, w11 m), position codes of the corner pixels 00 | 01 << 16 and
+// record (tap, pixel) = { P0 = fp16 pair (w00 m, w01 m), P1 = (w10 m, w11 m), position codes of the corner pixels 00 | 01 << 16 and
 // 10 | 11 << 16 (relative to the image buffer) }.  Corners outside the image have weight 0.  A footprint outside the halo is noted
 // in the bitmap and pointed at the zero pixel until gq_place_far gives it slots.
 __device__ static inline void gq_build_records(unsigned char* smem, int tid, int ty0, int tx0, int H, int W) {
@@ -160,8 +193,8 @@ __device__ static inline void gq_build_records(unsigned char* smem, int tid, int
             const float wa = (1.f - ly) * m, wb = ly * m;
             const bool h0ok = (unsigned)h0 < (unsigned)H, h1ok = (unsigned)(h0 + 1) < (unsigned)H;
             const bool w0ok = (unsigned)w0 < (unsigned)W, w1ok = (unsigned)(w0 + 1) < (unsigned)W;
-            const uint32_t P0 = pk_bf16((h0ok && w0ok) ? wa * (1.f - lx) : 0.f, (h0ok && w1ok) ? wa * lx : 0.f);
-            const uint32_t P1 = pk_bf16((h1ok && w0ok) ? wb * (1.f - lx) : 0.f, (h1ok && w1ok) ? wb * lx : 0.f);
+            const uint32_t P0 = gq_pk_f16((h0ok && w0ok) ? wa * (1.f - lx) : 0.f, (h0ok && w1ok) ? wa * lx : 0.f);
+            const uint32_t P1 = gq_pk_f16((h1ok && w0ok) ? wb * (1.f - lx) : 0.f, (h1ok && w1ok) ? wb * lx : 0.f);
             const int wr = h0 - (ty0 - GQ_MG), wc = w0 - (tx0 - GQ_MG);
             const bool nz = ((P0 | P1) & 0x7fff7fffu) != 0u;
             const bool inwin = (unsigned)wr <= (unsigned)(GQ_ROWS - 2) && (unsigned)wc <= (unsigned)(GQ_P - 3);
@@ -208,7 +241,7 @@ __device__ static __attribute__((noinline)) void gq_place_far(unsigned char* sme
             const uint32_t code = gq_code(s0 + cnr);
 #pragma unroll 1
             for (int q = 0; q < 8; ++q)
-                *reinterpret_cast<u32x4g*>(imgb + (code ^ (uint32_t)(q << 4))) = *reinterpret_cast<const u32x4g*>(xb + (uint32_t)((hc * W + wcc) * 128 + q * 16));
+                *reinterpret_cast<u32x4g*>(imgb + (code ^ (uint32_t)(q << 4))) = gq_bf2h4(*reinterpret_cast<const u32x4g*>(xb + (uint32_t)((hc * W + wcc) * 128 + q * 16)));
         }
         cp[0] = gq_code(s0) | (gq_code(s0 + 1) << 16);
         cp[1] = gq_code(s0 + 2) | (gq_code(s0 + 3) << 16);
@@ -222,23 +255,33 @@ __global__ __launch_bounds__(512) void dcn_fwd_gs_kernel(const GsFwdGeom g) {
     const u32x4g* const REC = reinterpret_cast<const u32x4g*>(smem + GQ_REC_OFS);
     uint32_t* const BMP = reinterpret_cast<uint32_t*>(smem + GQ_BMP_OFS);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    unsigned char* const IMG = smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave & 1, grp = wave >> 1;            // the two waves of a pixel group split the 18 (tap, channel half) units
     const int nl = lane & 31, hh = lane >> 5;
 
-    // zero pixel + far slots of both buffers, bias
-    for (int i = tid; i < 2 * 48 * 32; i += 512)
-        reinterpret_cast<uint32_t*>(smem + (i / (48 * 32)) * GQ_IMG_BYTES + GQ_ZERO_SLOT * 128)[i % (48 * 32)] = 0u;
+    // zero pixel + far slots, bias
+    for (int i = tid; i < 48 * 32; i += 512) reinterpret_cast<uint32_t*>(smem + GQ_ZERO_SLOT * 128)[i] = 0u;
     if (tid < 64) reinterpret_cast<float*>(smem + GQ_BIAS_OFS)[tid] = g.bias[tid];
 
-    const int t0 = gs_tile_of(blockIdx.x, gridDim.x, 0, g.ntiles);
-    if (t0 >= 0) gq_issue_tile(g, t0, lds_base, lds_base + GQ_OMS_OFS, wave, lane);
+    // the first tile's pieces
+    {
+        const int t0 = gs_tile_of(blockIdx.x, gridDim.x, 0, g.ntiles);
+        if (t0 >= 0) {
+            const int n = t0 / g.tiles_img, rt = t0 - n * g.tiles_img;
+            const int64_t img = (int64_t)n * g.H * g.W;
+#pragma unroll 1
+            for (int J = wave; J < GQ_NPIECE; J += 8)
+                gq_issue_piece(g, J, reinterpret_cast<const char*>(g.x + img * 64), reinterpret_cast<const char*>(g.om + img * 32),
+                               (rt / g.tiles_w) * GQ_TH, (rt % g.tiles_w) * GQ_TW, lds_base, lane);
+        }
+    }
 
     // ---- this wave's nine W fragments sets, for the whole launch: unit u <-> (tap, half) = ((9 role + u) >> 1, (9 role + u) & 1);
     //      fragment (s, cb): A operand, lane = output channel 32 cb + nl, 8 input channels 32 half + 16 s + 8 hh .. +7 of the tap
-    //      (wp = mode-1 pack [Co][tap * 64 + ci]) ----
+    //      (wp = mode-1 pack [Co][tap * 64 + ci], bf16 -> fp16: exact, the weights are far inside the fp16 range) ----
     u32x4g wf[9][2][2];
 #pragma unroll
     for (int u = 0; u < 9; ++u) {
@@ -247,7 +290,7 @@ __global__ __launch_bounds__(512) void dcn_fwd_gs_kernel(const GsFwdGeom g) {
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                wf[u][s][cb] = *reinterpret_cast<const u32x4g*>(g.wp + (int64_t)(32 * cb + nl) * 576 + tap * 64 + 32 * hf + 16 * s + 8 * hh);
+                wf[u][s][cb] = gq_bf2h4(*reinterpret_cast<const u32x4g*>(g.wp + (int64_t)(32 * cb + nl) * 576 + tap * 64 + 32 * hf + 16 * s + 8 * hh));
     }
 
     const int recpix = grp * 32 + nl;                     // record index of this lane's pixel
@@ -263,25 +306,27 @@ __global__ __launch_bounds__(512) void dcn_fwd_gs_kernel(const GsFwdGeom g) {
         const int ty0 = (rt / g.tiles_w) * GQ_TH, tx0 = (rt % g.tiles_w) * GQ_TW;
         const int64_t img = (int64_t)n * g.H * g.W;
         const bf16_t* __restrict__ X = g.x + img * 64;
-        unsigned char* const IMG = smem + (j & 1) * GQ_IMG_BYTES;
+        // the next tile: its DMA pieces are issued from inside the unit loop
+        const int tn = gs_tile_of(blockIdx.x, gridDim.x, j + 1, g.ntiles);
+        const int nn = tn >= 0 ? tn / g.tiles_img : 0, rtn = tn >= 0 ? tn - nn * g.tiles_img : 0;
+        const int tyn = (rtn / g.tiles_w) * GQ_TH, txn = (rtn % g.tiles_w) * GQ_TW;
+        const char* const Xn = reinterpret_cast<const char*>(g.x + (int64_t)nn * g.H * g.W * 64);
+        const char* const On = reinterpret_cast<const char*>(g.om + (int64_t)nn * g.H * g.W * 32);
 
         // (the thread index is laundered once per tile: the compiler otherwise hoists per-thread index arithmetic out of the tile loop,
         //  finds no registers for it next to the W sets, and reloads it from scratch)
-        int tidv = tid;
-        asm volatile("" : "+v"(tidv));
+        int tidv = tid, lnv = lane;
+        asm volatile("" : "+v"(tidv), "+v"(lnv));
         GS_STAMP(0);
         if (tidv < 37) BMP[tidv] = 0u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this tile's DMA (and the previous tile's stores) retired
-        __syncthreads();              // [S1] image + raw offsets visible; everybody is done with the previous tile's LDS
+        __syncthreads();              // [S1] staging + raw offsets visible; everybody is done with the previous tile's LDS
         GS_STAMP(1);
-        gq_build_records(smem, tidv, ty0, tx0, g.H, g.W);
+        gq_convert_image(smem, tidv);
         GS_STAMP(2);
-        __syncthreads();              // [S2]
+        gq_build_records(smem, tidv, ty0, tx0, g.H, g.W);
         GS_STAMP(3);
-        {
-            const int tn = gs_tile_of(blockIdx.x, gridDim.x, j + 1, g.ntiles);
-            if (tn >= 0) gq_issue_tile(g, tn, lds_base + ((j + 1) & 1) * GQ_IMG_BYTES, lds_base + GQ_OMS_OFS, wave, lane);
-        }
+        __syncthreads();              // [S2]
         GS_STAMP(4);
         const int nfar = __builtin_amdgcn_readfirstlane((int)BMP[36]);
         const int npass = nfar ? (nfar + GQ_FAR_PER_PASS - 1) / GQ_FAR_PER_PASS : 1;
@@ -299,37 +344,31 @@ __global__ __launch_bounds__(512) void dcn_fwd_gs_kernel(const GsFwdGeom g) {
                 gq_place_far(smem, IMG, X, tid, pass, g.H, g.W);
                 __syncthreads();
             }
+            const bool dma = pass == 0 && tn >= 0;
             // Software pipeline over the 18 (unit, k-step) steps: the four 16-byte corner reads of step i+1 are in flight while step i's
-            // pairing, dot products and MFMAs issue; sched_barriers keep the compiler from hoisting more (the W sets leave ~60 registers)
+            // blend and MFMAs issue; sched_barriers keep the compiler from hoisting more (the W sets leave ~60 registers)
             uint32_t P0, P1, c0, c1, c2, c3;
-            const unsigned char* const ib = IMG;
             {
                 const u32x4g rec = REC[((9 * role) >> 1) * GQ_NPIX + recpix];
                 const uint32_t xq = (uint32_t)((((9 * role) & 1) * 4 + hh) << 4);
                 P0 = rec[0]; P1 = rec[1];
                 c0 = (rec[2] & 0xffffu) ^ xq; c1 = (rec[2] >> 16) ^ xq; c2 = (rec[3] & 0xffffu) ^ xq; c3 = (rec[3] >> 16) ^ xq;
             }
-            u32x4g q0 = *reinterpret_cast<const u32x4g*>(ib + c0), q1 = *reinterpret_cast<const u32x4g*>(ib + c1);
-            u32x4g q2 = *reinterpret_cast<const u32x4g*>(ib + c2), q3 = *reinterpret_cast<const u32x4g*>(ib + c3);
+            u32x4g q0 = *reinterpret_cast<const u32x4g*>(IMG + c0), q1 = *reinterpret_cast<const u32x4g*>(IMG + c1);
+            u32x4g q2 = *reinterpret_cast<const u32x4g*>(IMG + c2), q3 = *reinterpret_cast<const u32x4g*>(IMG + c3);
 #pragma unroll
             for (int u = 0; u < 9; ++u) {
                 // ---- k-step 0; k-step 1's reads (logical chunk + 2: position ^ 32) go out first ----
-                const u32x4g r0 = *reinterpret_cast<const u32x4g*>(ib + (c0 ^ 32u)), r1 = *reinterpret_cast<const u32x4g*>(ib + (c1 ^ 32u));
-                const u32x4g r2 = *reinterpret_cast<const u32x4g*>(ib + (c2 ^ 32u)), r3 = *reinterpret_cast<const u32x4g*>(ib + (c3 ^ 32u));
+                const u32x4g r0 = *reinterpret_cast<const u32x4g*>(IMG + (c0 ^ 32u)), r1 = *reinterpret_cast<const u32x4g*>(IMG + (c1 ^ 32u));
+                const u32x4g r2 = *reinterpret_cast<const u32x4g*>(IMG + (c2 ^ 32u)), r3 = *reinterpret_cast<const u32x4g*>(IMG + (c3 ^ 32u));
                 u32x4g nrec = {0u, 0u, 0u, 0u};
                 if (u < 8) nrec = REC[((9 * role + u + 1) >> 1) * GQ_NPIX + recpix];
                 __builtin_amdgcn_sched_barrier(0);
                 {
-                    u32x4g sb;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const float lo = gs_dot2(__builtin_amdgcn_perm(q3[d], q2[d], 0x05040100u), P1, gs_dot2z(__builtin_amdgcn_perm(q1[d], q0[d], 0x05040100u), P0));
-                        const float hi = gs_dot2(__builtin_amdgcn_perm(q3[d], q2[d], 0x07060302u), P1, gs_dot2z(__builtin_amdgcn_perm(q1[d], q0[d], 0x07060302u), P0));
-                        sb[d] = pk_bf16(lo, hi);
-                    }
+                    const u32x4g sb = gq_blend(q0, q1, q2, q3, P0, P1);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[u][0][cb]), __builtin_bit_cast(bf16x8_t, sb), acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8g, wf[u][0][cb]), __builtin_bit_cast(f16x8g, sb), acc[cb], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- k-step 1; the next unit's record is decoded and its k-step 0 reads go out first ----
@@ -338,26 +377,30 @@ __global__ __launch_bounds__(512) void dcn_fwd_gs_kernel(const GsFwdGeom g) {
                     const uint32_t xq = (uint32_t)((((9 * role + u + 1) & 1) * 4 + hh) << 4);
                     P0 = nrec[0]; P1 = nrec[1];
                     c0 = (nrec[2] & 0xffffu) ^ xq; c1 = (nrec[2] >> 16) ^ xq; c2 = (nrec[3] & 0xffffu) ^ xq; c3 = (nrec[3] >> 16) ^ xq;
-                    q0 = *reinterpret_cast<const u32x4g*>(ib + c0); q1 = *reinterpret_cast<const u32x4g*>(ib + c1);
-                    q2 = *reinterpret_cast<const u32x4g*>(ib + c2); q3 = *reinterpret_cast<const u32x4g*>(ib + c3);
+                    q0 = *reinterpret_cast<const u32x4g*>(IMG + c0); q1 = *reinterpret_cast<const u32x4g*>(IMG + c1);
+                    q2 = *reinterpret_cast<const u32x4g*>(IMG + c2); q3 = *reinterpret_cast<const u32x4g*>(IMG + c3);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 {
-                    u32x4g sb;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const float lo = gs_dot2(__builtin_amdgcn_perm(r3[d], r2[d], 0x05040100u), P1c, gs_dot2z(__builtin_amdgcn_perm(r1[d], r0[d], 0x05040100u), P0c));
-                        const float hi = gs_dot2(__builtin_amdgcn_perm(r3[d], r2[d], 0x07060302u), P1c, gs_dot2z(__builtin_amdgcn_perm(r1[d], r0[d], 0x07060302u), P0c));
-                        sb[d] = pk_bf16(lo, hi);
-                    }
+                    const u32x4g sb = gq_blend(r0, r1, r2, r3, P0c, P1c);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
-                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[u][1][cb]), __builtin_bit_cast(bf16x8_t, sb), acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8g, wf[u][1][cb]), __builtin_bit_cast(f16x8g, sb), acc[cb], 0, 0, 0);
                 }
+                // one DMA piece of the next tile behind each of the first eight units (its issue hides behind the MFMAs)
+#ifndef GQ_DMA_AFTER
+                if (u < 8 && dma && wave + 8 * u < GQ_NPIECE) gq_issue_piece(g, wave + 8 * u, Xn, On, tyn, txn, lds_base, lnv);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
+#ifdef GQ_DMA_AFTER      // timing experiment: all pieces behind the unit loop
+        if (tn >= 0) {
+#pragma unroll 1
+            for (int J = wave; J < GQ_NPIECE; J += 8) gq_issue_piece(g, J, Xn, On, tyn, txn, lds_base, lnv);
+        }
+#endif
         GS_STAMP(5);
         __syncthreads();              // [S3] every wave is done with the image and the records: they become the exchange / staging area
         GS_STAMP(6);

@@ -48,7 +48,7 @@ else:
     ts = buf.reshape(64, 2, 4, 16).astype(np.int64)
     print(f"launch {e0.elapsed_time(e1) * 1e3:.1f} us, offsets sigma {sigma}")
     med = lambda v: f"median {np.median(v):8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}"
-    names = ["wait for the DMA + barrier S1", "records", "barrier S2", "issue next tile's DMA", "unit loop (9 units)", "barrier S3", "exchange + barrier S4", "epilogue"]
+    names = ["wait for the DMA + barrier S1", "staging -> fp16 image", "records", "barrier S2", "unit loop (9 units + DMA issue)", "barrier S3", "exchange + barrier S4", "epilogue"]
     for role in (0, 1):
         t = ts[:, role, 1:, :]            # skip the first tile (weights still arriving)
         t = t.reshape(-1, 16)
