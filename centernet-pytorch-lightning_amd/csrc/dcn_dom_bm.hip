@@ -57,12 +57,29 @@ struct DomBmGeom {
 typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
 typedef float f32x2w __attribute__((ext_vector_type(2)));
 
+// acc + sum of the 8 bf16 products of two 16-byte vectors (4 x v_dot2c_f32_bf16; the elements are named one by one: with the
+// vectors subscripted by an unrolled loop variable hipcc 7.2 used element 0 four times)
+typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
+__device__ static inline float dom_dot8(const u32x4w& a, const u32x4w& b, float acc) {
+    const uint32_t a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w, b0 = b.x, b1 = b.y, b2 = b.z, b3 = b.w;
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2w, a0), __builtin_bit_cast(bf16x2w, b0), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2w, a1), __builtin_bit_cast(bf16x2w, b1), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2w, a2), __builtin_bit_cast(bf16x2w, b2), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2w, a3), __builtin_bit_cast(bf16x2w, b3), acc, false);
+    return acc;
+}
+
 __device__ static inline float half_sum(float v) {      // v(lane) + v(lane ^ 32) in every lane
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-template <int COP>   // channels of dY (contraction length of the first product): 64 or 128
+// GA (round 5): the corner dot products by a direct GATHER instead of the second MFMA product — every lane reads the 16-byte chunks of
+// its own four corner pixels that hold the channels of its dcol registers (4 chunks x 4 corners) from the halo image and runs
+// v_dot2c_f32_bf16 over them: ~150 VALU instructions and 8 MFMAs per tap instead of ~290 and ~22 (the row-pair products and their
+// separable reductions; profiles/r04_pmc_sq.txt: 20 VALU instructions per MFMA), no data-dependent loop, all 16 reads in flight at
+// once, and the in-window test is the TILE's halo (16 x 24) instead of the group's 12 x 16 window.
+template <int COP, bool GA>   // channels of dY (contraction length of the first product): 64 or 128
 __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
     CN_MAIN_PRIO_SET();
     constexpr int KS = COP / 16;
@@ -226,16 +243,20 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
         const int wr = h0 - wy_org, wc = w0 - wx_org;                                   // ... and its window coordinates
         const float ly = pyr - fy, lx = pxr - fx;
         const bool active = m != 0.f;                                                   // inside the image (the table holds 0 outside)
-        const bool inwin = (unsigned)wr <= 10u && (unsigned)wc <= 14u;
+        const int tr = wr + grow, tc = wc + gcol;                                       // ... and its coordinates in the tile's halo image
+        const bool inwin = GA ? ((unsigned)tr <= (unsigned)(DB_WR - 2) && (unsigned)tc <= (unsigned)(DB_WC - 2)) : ((unsigned)wr <= 10u && (unsigned)wc <= 14u);
         const bool winmiss = active && !inwin;
         // row pairs of the window anybody in the wave samples (rows wr and wr + 1 of every active in-window lane)
-        uint32_t pairs = (active && inwin) ? ((1u << (wr >> 1)) | (1u << ((wr + 1) >> 1))) : 0u;
-        pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-        pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
-        pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0x141, 0xF, 0xF, true);    // row_half_mirror
-        pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0x140, 0xF, 0xF, true);    // row_mirror
-        uint32_t pm = (uint32_t)__builtin_amdgcn_readlane((int)pairs, 0) | (uint32_t)__builtin_amdgcn_readlane((int)pairs, 16) |
-                      (uint32_t)__builtin_amdgcn_readlane((int)pairs, 32) | (uint32_t)__builtin_amdgcn_readlane((int)pairs, 48);
+        uint32_t pairs = (!GA && active && inwin) ? ((1u << (wr >> 1)) | (1u << ((wr + 1) >> 1))) : 0u;
+        uint32_t pm = 0u;
+        if (!GA) {
+            pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+            pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+            pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0x141, 0xF, 0xF, true);    // row_half_mirror
+            pairs |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pairs, 0x140, 0xF, 0xF, true);    // row_mirror
+            pm = (uint32_t)__builtin_amdgcn_readlane((int)pairs, 0) | (uint32_t)__builtin_amdgcn_readlane((int)pairs, 16) |
+                 (uint32_t)__builtin_amdgcn_readlane((int)pairs, 32) | (uint32_t)__builtin_amdgcn_readlane((int)pairs, 48);
+        }
         // the first pair's window fragments are requested before the first product (their latency hides behind its 8-16 MFMAs)
         int j = pm ? __builtin_ctz(pm) : 0;
         const bool any = pm != 0;
@@ -249,7 +270,19 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
                 for (int s = 0; s < KS; ++s) wloc[cb][s] = *reinterpret_cast<const u32x4w*>(Ws + (tap & 1) * (2 * KS * 1024) + ((cb * KS + s) * 64 + lane) * 16);
         }
         u32x4w (&W)[2][KS] = WLDS ? wloc : wf;
-        if (WLDS) {
+        // GA: position codes of the four corner pixels (byte offset of the pixel | swizzle key << 4: chunk c sits at code ^ (c << 4)) and
+        // the first half of the gather (channel block 0) go out before the first product
+        uint32_t cc[4];
+        u32x4w ga[4][2];
+        if (GA) {
+            const int n00 = inwin ? tr * DB_WC + tc : 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int nk = n00 + (k >> 1) * DB_WC + (k & 1);
+                cc[k] = (((uint32_t)nk << 7) | ((((uint32_t)nk >> 1) & 7u) << 4)) ^ (uint32_t)(hh << 4);
+            }
+        }
+        if (WLDS && !GA) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xop[s] + j * (2 * DB_ROW));
         }
@@ -267,13 +300,22 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
                 dc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, W[cb][s]), __builtin_bit_cast(bf16x8_t, dyf[s]), dc[cb], 0, 0, 0);
         if (!WLDS) {                                         // single register set: re-loaded right after its last use
             wload(wf, tap < 8 ? tap + 1 : 8);
+            if (!GA) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xop[s] + j * (2 * DB_ROW));
+                for (int s = 0; s < 4; ++s) xa[s] = *reinterpret_cast<const u32x4w*>(xop[s] + j * (2 * DB_ROW));
+            }
+        }
+        if (GA) {        // channel block 0 of the four corners: chunks 0 (+ hh, folded into the codes) and 2
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ga[k][0] = *reinterpret_cast<const u32x4w*>(Xw + cc[k]);
+                ga[k][1] = *reinterpret_cast<const u32x4w*>(Xw + (cc[k] ^ 32u));
+            }
         }
         // ---- column weights of this lane's 8 window columns (register i of a pair row <-> column 8 (i >> 2) + 4 hh + (i & 3)); VALU
         //      work placed behind the MFMAs it does not depend on ----
         f32x2w cg[8];                                        // {bilinear weight, derivative sign} of column i for this pixel
-        {
+        if (!GA) {
             const int wcl = inwin ? wc - 4 * hh : -100;      // corner column relative to this lane half's first column
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -295,7 +337,29 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
         // ---- D^T[q][p] per touched row pair, reduced with the separable weights; the next pair's fragments are requested between the
         //      MFMAs of this pair and its reduction (sched_barrier: the compiler otherwise sinks the reads to the next iteration's top
         //      and every pair pays a full LDS latency) ----
-        if (any) {
+        if (GA) {
+            // ---- the four corner dots D_ab = sum_ci dcol[ci] x_ab[ci] over this lane's 32 channels: dcb[s] = channels 16 s + 8 hh .. + 7
+            //      = chunk 2 s + hh of a pixel ----
+            float d4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) d4[k] = dom_dot8(ga[k][s], dcb[s], d4[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                    // channel block 1: chunks 4 and 6
+                ga[k][0] = *reinterpret_cast<const u32x4w*>(Xw + (cc[k] ^ 64u));
+                ga[k][1] = *reinterpret_cast<const u32x4w*>(Xw + (cc[k] ^ 96u));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) d4[k] = dom_dot8(ga[k][s], dcb[2 + s], d4[k]);
+            if (active && inwin) {
+                sm = (1.f - ly) * ((1.f - lx) * d4[0] + lx * d4[1]) + ly * ((1.f - lx) * d4[2] + lx * d4[3]);
+                sy = (1.f - lx) * (d4[2] - d4[0]) + lx * (d4[3] - d4[1]);
+                sx = (1.f - ly) * (d4[1] - d4[0]) + ly * (d4[3] - d4[2]);
+            }
+        } else         if (any) {
             while (true) {
                 f32x16_t D;
 #pragma unroll
@@ -448,12 +512,11 @@ bool dcn_dom_bm_launch(const void* dy, const void* wd2, const void* x, const flo
     if (tiles > 0x7fffffff) return false;
     const dim3 grid((unsigned)tiles, blocks);
     const size_t smem = (size_t)DB_WR * DB_ROW + 4 * 32 * 29 * 4 + (dy_ld == 64 ? 2 * 8 * 1024 : 0);
-    if (dy_ld == 64) {
-        (void)hipFuncSetAttribute((const void*)dcn_dom_bm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(dcn_dom_bm_kernel<64>, grid, dim3(256), smem, st, g);
-    } else {
-        (void)hipFuncSetAttribute((const void*)dcn_dom_bm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(dcn_dom_bm_kernel<128>, grid, dim3(256), smem, st, g);
-    }
+    static const bool gather = getenv("CN_DISABLE_DOM_GATHER") == nullptr;
+#define CN_DOMB(COP_, GA_) do { (void)hipFuncSetAttribute((const void*)dcn_dom_bm_kernel<COP_, GA_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+                                hipLaunchKernelGGL((dcn_dom_bm_kernel<COP_, GA_>), grid, dim3(256), smem, st, g); } while (0)
+    if (dy_ld == 64) { if (gather) CN_DOMB(64, true); else CN_DOMB(64, false); }
+    else { if (gather) CN_DOMB(128, true); else CN_DOMB(128, false); }
+#undef CN_DOMB
     return true;
 }

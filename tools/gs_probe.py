@@ -43,13 +43,13 @@ else:
     e0.record(); run(); e1.record()
     torch.cuda.synchronize()
     lib = ctypes.CDLL(SO)
-    buf = np.zeros(64 * 2 * 4 * 16, dtype=np.uint64)
+    buf = np.zeros(64 * 3 * 4 * 16, dtype=np.uint64)
     assert lib.gs_probe_dump(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    ts = buf.reshape(64, 2, 4, 16).astype(np.int64)
+    ts = buf.reshape(64, 3, 4, 16).astype(np.int64)
     print(f"launch {e0.elapsed_time(e1) * 1e3:.1f} us, offsets sigma {sigma}")
     med = lambda v: f"median {np.median(v):8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}"
-    names = ["wait for the DMA + barrier S1", "staging -> fp16 image", "records", "barrier S2", "unit loop (9 units + DMA issue)", "barrier S3", "exchange + barrier S4", "epilogue"]
-    for role in (0, 1):
+    names = ["issue loads + barrier S1", "halo -> fp16 image (+ load wait)", "records (+ barrier)", "barrier S2", "unit loop (6 units)", "barrier S3", "exchange + barrier S4", "epilogue"]
+    for role in (0, 1, 2):
         t = ts[:, role, 1:, :]            # skip the first tile (weights still arriving)
         t = t.reshape(-1, 16)
         t = t[t[:, 8] != 0]
