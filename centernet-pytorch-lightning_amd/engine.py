@@ -283,6 +283,47 @@ class GradSync:
             dist.broadcast(buf, 0, group=self.group)
 
 
+def _watchdog_backlog():
+    """Collectives the NCCL / RCCL process groups' watchdog threads have not retired yet (enqueued - completed sequence numbers of
+    every group, from the flight recorder's status block), or None when this build does not report it."""
+    try:
+        import pickle
+        from torch._C import _distributed_c10d as c10d
+        st = pickle.loads(c10d._dump_nccl_trace(includeCollectives=False, includeStackTraces=False, onlyActive=True)).get("pg_status")
+    except Exception:
+        return None
+    if not isinstance(st, dict):
+        return None
+    backlog = 0
+    for v in st.values():
+        try:
+            backlog += max(0, int(v["last_enqueued_collective"]) - int(v["last_completed_collective"]))
+        except Exception:
+            return None
+    return backlog
+
+
+def drain_watchdog(timeout=5.0):
+    """Block until the process groups' watchdog threads have retired every collective issued so far (the caller has already
+    synchronised the device, so they are complete: this waits for the watchdog's next pass, which drops them from its poll list).
+    Deterministic where the status block is available; otherwise (or on timeout) three watchdog periods of sleep."""
+    import time
+    if not torch.cuda.is_available():
+        return True          # gloo: no device events, nothing polls during a capture
+    end = time.monotonic() + timeout
+    while True:
+        n = _watchdog_backlog()
+        if n is None:
+            break
+        if n == 0:
+            return True
+        if time.monotonic() > end:
+            break
+        time.sleep(0.002)
+    time.sleep(0.35)
+    return False
+
+
 def init_distributed():
     """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and join the RCCL world."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -494,13 +535,14 @@ class TrainStep:
         WeightsEpoch.bump()
         torch.cuda.synchronize()
         if dist.is_initialized():
-            # the process group's watchdog thread wakes every 100 ms to reap finished collectives; let it retire the warm-up steps'
-            # work objects before the capture starts, so that it has nothing to poll while this stream (and RCCL's own, which
-            # joins the capture) is capturing — an event query landing in that window ends the process (hipErrorCapturedEvent,
-            # seen in about one of four runs of test_rccl_exchange_next_to_graphs)
-            import time
-            time.sleep(0.35)
-        if os.environ.get("CN_FAIL_CAPTURE"):
+            # The process group's watchdog thread polls the completion events of every collective it has not yet retired (it wakes
+            # every 100 ms); an event query landing while this stream (and RCCL's own, which joins the capture) is capturing ends the
+            # process (hipErrorCapturedEvent, seen in about one of four runs of test_rccl_exchange_next_to_graphs).  The warm-up
+            # steps' collectives have finished on the device (synchronize above); wait until the watchdog has RETIRED them, so that
+            # it has nothing left to poll — read off its own bookkeeping, not off a timer.
+            drain_watchdog()
+        fail = os.environ.get("CN_FAIL_CAPTURE")       # test hook for the eager fallback: "1" = every rank, "rank:<r>" = that rank only
+        if fail and (not fail.startswith("rank:") or int(fail[5:]) == (dist.get_rank() if dist.is_initialized() else 0)):
             raise RuntimeError("CN_FAIL_CAPTURE set (test hook for the eager fallback)")
         self._g1, self._g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # with a process group alive, its watchdog thread polls events while we capture: only police THIS thread's calls
@@ -541,16 +583,25 @@ class TrainStep:
                 self._throttle()
             return loss
         if self._g1 is None:
+            err = None
             try:
                 self._capture(batch)
             except Exception as e:      # e.g. a runtime that refuses capture next to a live process group: keep training
+                err = e
+                self._g1 = self._g2 = None
+                self._abort_backward()
+                if self.opt.flat_p.is_cuda:
+                    torch.cuda.synchronize()
+            # The launch mode is a COLLECTIVE decision: a rank replaying a captured graph and a rank issuing eager buckets post
+            # different collective sequences (one graph launch vs one all-reduce per bucket) and would hang each other.  Every rank
+            # reports whether its capture succeeded; one failure anywhere puts all of them on eager launches.
+            if not self._agree(err is None):
                 import sys
-                print(f"[centernet_amd] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches",
+                why = f"{type(err).__name__}: {err}" if err is not None else "another rank's capture failed"
+                print(f"[centernet_amd] hipGraph capture failed ({why}); falling back to eager launches on every rank",
                       file=sys.stderr, flush=True)
                 self._g1 = self._g2 = None
                 self.graph = False
-                self._abort_backward()
-                torch.cuda.synchronize()
                 return self._eager(batch, batch_idx)
         if batch[0] is not self._sx:
             self._sx.copy_(batch[0], non_blocking=True)
@@ -564,8 +615,17 @@ class TrainStep:
         self._g2.replay()
         for m in self._bns:
             m._pending += 1
-        self._throttle()
+        if self.opt.flat_p.is_cuda:
+            self._throttle()
         return self._loss
+
+    def _agree(self, ok):
+        """AND of `ok` over the ranks that exchange gradients with this one (no-op without a process group)"""
+        if self.sync is None or self.sync.world < 2 or not dist.is_initialized():
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.opt.flat_p.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.sync.group)
+        return bool(int(flag.item()))
 
     _ns_next = 0
     MAX_STEPS_AHEAD = int(os.environ.get("CN_MAX_STEPS_AHEAD", 3))

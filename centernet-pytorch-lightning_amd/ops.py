@@ -486,7 +486,8 @@ class SideGrads:
         # faster the critical chain runs — DLA-34 bs 64: 1 413 / 1 432 / 1 437 / 1 460 / 1 480 / 1 478 / 1 368 / 1 165 images/s with
         # 768 / 512 / 384 / 192 / 160 / 128 / 96 / 64 workgroups (below ~128 the side stream itself becomes the critical path)
         cls.thin = int(_os.environ.get("CN_WGRAD_BLOCKS", (384 if fp32 else 160) if on else 1536))
-        call("cn_set_wgrad_parallelism", cls.thin)
+        if torch.cuda.is_available():        # (a CPU-only TrainStep — the gloo tests of the data-parallel path — has no kernels to shape)
+            call("cn_set_wgrad_parallelism", cls.thin)
         return on
 
     thin = 1536

@@ -171,6 +171,106 @@ def test_gradient_buckets_over_gloo(world, between_graphs):
     torch.testing.assert_close(out[0][:n], opt.flat_p[:n], rtol=1e-5, atol=1e-6)
 
 
+class _ToyModule(torch.nn.Module):
+    """the TrainStep contract on CPU: training_step(batch, idx) -> scalar loss normalised by the LOCAL sample count"""
+
+    def __init__(self, seed):
+        super().__init__()
+        self.net, self.dead = _toy_net(seed)
+
+    def training_step(self, batch, batch_idx):
+        return self.net(batch[0]).square().mean()
+
+
+class _FakeGraph:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def replay(self):
+        self.fn()
+
+
+def _capture_worker(rank, world, port, out, fail_rank):
+    """TrainStep in graph mode at world 2 over gloo; the capture itself is stubbed (no device here): it 'succeeds' on every rank but
+    `fail_rank`, where the CN_FAIL_CAPTURE hook raises.  What is under test is the DECISION: every rank must leave the first call
+    in the same launch mode, and keep exchanging gradients correctly afterwards."""
+    import torch.distributed as dist
+    from centernet_amd import engine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if fail_rank is not None:
+        os.environ["CN_FAIL_CAPTURE"] = f"rank:{fail_rank}"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _ToyModule(100 + rank)
+
+    def fake_capture(self, batch):
+        fail = os.environ.get("CN_FAIL_CAPTURE")
+        if fail and int(fail[5:]) == dist.get_rank():
+            raise RuntimeError("CN_FAIL_CAPTURE set (test hook for the eager fallback)")
+        self._sx, self._st = batch
+
+        def g1():                      # what TrainStep._capture records into its first graph
+            self.opt.zero_grad()
+            loss = self.model.training_step((self._sx, self._st), 0)
+            self.sync.begin()
+            loss.backward()
+            self.sync.finish()
+            self._loss = loss.detach()
+
+        def g2():                      # ... and into its second: the optimizer's device half (prepare_step already advanced t)
+            self.opt.t -= 1
+            self.opt.step()
+
+        self._g1, self._g2 = _FakeGraph(g1), _FakeGraph(g2)
+
+    engine.TrainStep._capture = fake_capture
+    step = engine.TrainStep(m, lr=1e-2, distributed=True, graph=True, side_grads=False)
+    for it in range(3):
+        step((_toy_batch(it, rank), {}), it)
+    out[rank] = (step.graph, step._g1 is None, step.opt.flat_p.clone())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [1, 0])
+def test_capture_failure_on_one_rank_puts_every_rank_on_eager_launches(fail_rank):
+    """round-4 VERDICT: a per-rank fallback would leave one rank issuing eager buckets against a rank replaying a graph (different
+    collective sequences -> hang).  The launch mode is agreed with one MIN all-reduce after the capture attempt."""
+    port = 31000 + os.getpid() % 2000 + fail_rank
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_capture_worker, args=(2, port, out, fail_rank), nprocs=2, join=True)
+    assert [out[r][0] for r in range(2)] == [False, False] and all(out[r][1] for r in range(2))
+    assert torch.equal(out[0][2], out[1][2])
+    # ... and the three steps equal one process that averages the per-rank (locally normalised) gradients itself
+    from centernet_amd.engine import FlatAdam
+    net, dead = _toy_net(100)
+    opt = FlatAdam(list(net.parameters()) + list(dead.parameters()), lr=1e-2)
+    for it in range(3):
+        opt.zero_grad()
+        for r in range(2):
+            (net(_toy_batch(it, r)).square().mean() / 2).backward()
+        opt.step()
+    n = sum(p.numel() for p in net.parameters())
+    torch.testing.assert_close(out[0][2][:n], opt.flat_p[:n], rtol=1e-5, atol=1e-6)
+
+
+def test_capture_success_everywhere_keeps_the_graph_and_matches_eager():
+    """the same two ranks with no failure stay in (stubbed) graph mode, and end bit-identical to the eager-fallback run: both launch
+    modes reach the same summed gradients"""
+    port = 31500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out, out_e = mgr.dict(), mgr.dict()
+    mp.spawn(_capture_worker, args=(2, port, out, None), nprocs=2, join=True)
+    mp.spawn(_capture_worker, args=(2, port + 1, out_e, 1), nprocs=2, join=True)
+    assert [out[r][0] for r in range(2)] == [True, True] and not any(out[r][1] for r in range(2))
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][2], out_e[0][2])
+
+
+def test_watchdog_drain_reads_the_process_groups_own_bookkeeping():
+    from centernet_amd import engine
+    assert engine._watchdog_backlog() in (0, None)          # no NCCL group in this process
+    assert engine.drain_watchdog(timeout=0.01) is True
+
+
 def test_grad_sync_counts_direct_deposits():
     """Gradients that bypass autograd (weight-gradient kernels, BN backward) report through ops.GradReady: a bucket must not
     leave before its last DIRECT deposit was reported, and an un-reported deposit is caught by the first-step audit."""
