@@ -289,11 +289,16 @@ def _watchdog_backlog():
     try:
         import pickle
         from torch._C import _distributed_c10d as c10d
-        st = pickle.loads(c10d._dump_nccl_trace(includeCollectives=False, includeStackTraces=False, onlyActive=True)).get("pg_status")
+        st = pickle.loads(c10d._dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True)).get("pg_status")
     except Exception:
         return None
     if not isinstance(st, dict):
         return None
+    if not st:
+        # no status block: either no NCCL group exists, or the flight recorder is off (TORCH_NCCL_TRACE_BUFFER_SIZE unset when the
+        # group was created — init_distributed sets it) and nothing can be read off it
+        nccl = dist.is_initialized() and torch.cuda.is_available() and "nccl" in str(dist.get_backend()).lower()
+        return None if nccl else 0
     backlog = 0
     for v in st.values():
         try:
@@ -334,6 +339,10 @@ def init_distributed():
     if (world > 1 or os.environ.get("CN_FORCE_EXCHANGE")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # the flight recorder's status block is how drain_watchdog learns that the watchdog has retired the warm-up collectives
+        # (the group only keeps it when a trace buffer is configured at creation)
+        os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")
+        os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
         dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
     return rank, local, world
 
@@ -540,7 +549,7 @@ class TrainStep:
             # process (hipErrorCapturedEvent, seen in about one of four runs of test_rccl_exchange_next_to_graphs).  The warm-up
             # steps' collectives have finished on the device (synchronize above); wait until the watchdog has RETIRED them, so that
             # it has nothing left to poll — read off its own bookkeeping, not off a timer.
-            drain_watchdog()
+            self.drained = drain_watchdog()
         fail = os.environ.get("CN_FAIL_CAPTURE")       # test hook for the eager fallback: "1" = every rank, "rank:<r>" = that rank only
         if fail and (not fail.startswith("rank:") or int(fail[5:]) == (dist.get_rank() if dist.is_initialized() else 0)):
             raise RuntimeError("CN_FAIL_CAPTURE set (test hook for the eager fallback)")

@@ -421,6 +421,7 @@ for graph in (False, True, "between"):
     assert step.sync is not None and step.sync.exchange and step.side, "weight gradients stay on the side stream under DP"
     out["graph" if graph else "eager"] = [float(step(batch)) for _ in range(4)]
     out["is_graph_" + str(graph)] = bool(step.graph)
+    out["drained_" + str(graph)] = bool(getattr(step, "drained", False))
     # buckets leave DURING backward (for the graph: during the captured backward): (bucket, #parameters produced at launch)
     out["log_" + ("graph" if graph else "eager")] = step.sync.launch_log
     out["live"] = len(step.sync.live)
@@ -442,6 +443,7 @@ def test_rccl_exchange_next_to_graphs(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res["is_graph_True"], "capture fell back to eager next to the process group:\n" + r.stderr[-2000:]
+    assert res["drained_True"], "the watchdog was not drained by its own bookkeeping (timer fallback taken)"
     assert all(np.isfinite(res["eager"])) and all(np.isfinite(res["graph"]))
     for mode in ("eager", "graph"):
         log = res["log_" + mode]
