@@ -214,7 +214,7 @@ def pmc_traffic(kernel):
     collected in separate rocprofv3 --pmc runs; recipe and the gfx950 correction are in the JSON).  The record is stamped with the
     git blob hash of the kernel's source file: when the source has changed since the measurement the number is stale -> None."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(root, "profiles", fn)) as f:
                 rec = json.load(f)
@@ -248,6 +248,27 @@ def rocprof_avg_us(kernel):
                 return {"file": os.path.relpath(fn, root), "kernel": best[0], "calls": best[1], "avg_us": best[2]}
         except OSError:
             continue
+    return None
+
+
+def pmc_sq(kernel):
+    """MFMA-pipe busy fraction and VALU instructions per MFMA of `kernel` from the newest committed SQ counter pass
+    (profiles/rNN_pmc_sq.txt, tools/pmc_sq.sh): what limits a kernel that is far from both roofs."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.abspath(__file__))
+    for fn in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_sq.txt")), reverse=True):
+        try:
+            lines = open(fn).read().splitlines()
+        except OSError:
+            continue
+        for i, ln in enumerate(lines):
+            if ln and not ln.startswith((" ", "#")) and kernel.split("<")[0] in ln and (kernel in ln or "<" not in kernel):
+                for l2 in lines[i + 1:i + 3]:
+                    m = re.search(r"MFMA pipe busy ([\d.]+);\s+VALU per MFMA ([\d.]+|n/a)", l2)
+                    if m:
+                        return {"file": os.path.relpath(fn, root), "mfma_pipe_busy": float(m.group(1)),
+                                "valu_per_mfma": None if m.group(2) == "n/a" else float(m.group(2))}
     return None
 
 
@@ -357,7 +378,7 @@ def cpu_baseline(full=False):
             run("res_18", bs, False, 5)
     dt = time.time() - t_all
     head = legs["dla_34 train step + decode bs=2"]
-    return {"value": head["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+    return {"value": head["images_per_s"], "unit": "images/s", "cores": cores, "cores_available": avail, "kind": "port", "cpu": _cpu_model(),
             "sample": f"median of {head['timed']} timed steps after 3 warm-ups of DLA-34 ctdet train step (fwd+loss+bwd+Adam) + decode, "
                       f"batch 2, 512x512, fp32, torch-CPU oracle (pure-torch DCNv2), {cores} threads; all legs {dt:.0f} s "
                       f"({'full plan' if full else 'bounded: batch-8 legs 1 warm-up + 2 timed'})",
@@ -690,6 +711,11 @@ def main():
                 gbps = 3.0 * mb_img * args.batch / step_s / 1e3
                 step_roof.update({"gbps": round(gbps, 1), "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4),
                                   "bytes_per_image": f"3 x {mb_img} MB unfused bf16 traffic (SURVEY 8d)"})
+        if step_roof and mb_img:
+            # per-layer max(t_MFMA, t_HBM) bound of the forward = mb_img / 6.3 TB/s per image (46 us for DLA-34 ctdet); x3 for
+            # the train step.  frac_of_layerwise_bound = that bound / the measured step
+            lb = 3.0 * (mb_img * 1e6 / 6.3e12) * args.batch
+            step_roof.update({"layerwise_bound_ms": round(lb * 1e3, 3), "frac_of_layerwise_bound": round(lb / step_s, 4)})
         if probe and probe.ops:
             by = probe.mfma_kernels()
             kern, (fl, tt, n, nbytes) = max(by.items(), key=lambda kv: kv[1][1])
@@ -712,15 +738,28 @@ def main():
                               "flop_per_byte": round(v[0] / v[3], 1)})
                 return r
 
-            # which roof is the nearer one is a label, not a finding: say what actually limits the kernel when neither roof is close
-            limiter = ("neither roof binds (both fractions < 0.25): issue-bound on the VALU / LDS work around the MFMAs — SQ counters in "
-                       "profiles/r04_pmc_sq.txt" if max(gbps / PEAK_HBM_GBPS, ach / peak) < 0.25 else ("HBM" if hbm_bound else "MFMA"))
-            roof = {"bound": "hbm" if hbm_bound else "mfma", "limiter": limiter,
-                    "achieved": round(gbps, 1) if hbm_bound else round(ach, 2),
+            # The line leads with the number a reader can recompute from the committed trace: the kernel's average duration in the
+            # newest profiles/rNN_bench_kernel_stats.txt (replayed steps, the other stream's kernels next to it).  The HIP-event time of
+            # the serialised eager launches measured here is kept as *_eager (it ran 11 % optimistic in round 4: 341 vs 378 us).
+            rp = rocprof_avg_us(kern)
+            t_launch = rp["avg_us"] * 1e-6 if rp else tt / n
+            ach_t, gbps_t = fl / n / t_launch / 1e12, nbytes / n / t_launch / 1e9
+            # which roof is the nearer one is a label, not a finding: when neither is close the kernel is bound by instruction issue
+            # around its MFMAs, and the machine-readable field says so (SQ counters of the committed pass next to it)
+            far = max(gbps_t / PEAK_HBM_GBPS, ach_t / peak) < 0.25
+            sq = pmc_sq(kern)
+            limiter = ("neither roof binds (both fractions < 0.25): bound by VALU / LDS instruction issue around the MFMAs (a wave issues one "
+                       "VALU instruction per ~4.9 cycles: tools/probe/valu_rate.hip)" if far else ("HBM" if hbm_bound else "MFMA"))
+            roof = {"bound": "valu" if far else ("hbm" if hbm_bound else "mfma"), "nearer_roof": "hbm" if hbm_bound else "mfma",
+                    "limiter": limiter, "sq": sq,
+                    "achieved": round(gbps_t, 1) if hbm_bound else round(ach_t, 2),
                     "peak": PEAK_HBM_GBPS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round(gbps / PEAK_HBM_GBPS, 4) if hbm_bound else round(ach / peak, 4),
+                    "frac": round(gbps_t / PEAK_HBM_GBPS, 4) if hbm_bound else round(ach_t / peak, 4),
+                    "frac_from": "rocprof.avg_us (committed kernel trace)" if rp else "avg_launch_us (HIP events, eager launches: no committed trace found)",
+                    "achieved_eager": round(gbps, 1) if hbm_bound else round(ach, 2),
+                    "frac_eager": round(gbps / PEAK_HBM_GBPS, 4) if hbm_bound else round(ach / peak, 4),
                     "traffic": pmc_traffic(kern),
-                    "rocprof": rocprof_avg_us(kern),
+                    "rocprof": rp,
                     "how": f"HIP events around each launch, {args.probe_steps} eagerly launched step(s) of the same workload right after "
                            f"the timed region; dominant = largest total time among the kernel templates of ALL MFMA entry points; bound = "
                            f"hbm when the kernel's algorithmic flop/byte ({ai:.0f}) is below the ridge ({ridge:.0f}), else mfma; both "

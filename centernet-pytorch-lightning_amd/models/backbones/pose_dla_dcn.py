@@ -115,6 +115,10 @@ class DLA(nn.Module):
         super().__init__()
         self.channels = channels
         self.compute_dtype = compute_dtype
+        # forward() returns all six levels like the reference (pose_dla_dcn.py:372-378), so level0's output is materialised
+        # (BN + ReLU applied) by default.  A caller that never reads y[0] (DLASeg: first_level >= 1) clears this, and level0's last BN
+        # is then left to level1's first conv (applied on load; y[0] is None instead of a raw, un-normalised tensor).
+        self.expose_level0 = True
         self.base_layer = nn.Sequential(hnn.StemConv(3, channels[0], 7, 1, 3), hnn.BatchNorm2d(channels[0]), nn.Identity())
         self.level0 = self._make_conv_level(channels[0], channels[0], levels[0])
         self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2)
@@ -152,10 +156,11 @@ class DLA(nn.Module):
         y = []
         for i in range(6):
             level = getattr(self, f"level{i}")
-            x = self._run_conv_level(level, x, self.level1[0] if i == 0 else None) if i < 2 else level(x)
+            x = self._run_conv_level(level, x, self.level1[0] if i == 0 and not self.expose_level0 else None) if i < 2 else level(x)
             if i >= 2:
                 x = ops.share(x)        # a level's output feeds the next level and the up path
-            y.append(x)
+            # a deferred level0 output is a RAW conv output (its BN + ReLU live in level1's first conv): never hand that out
+            y.append(None if getattr(x, "_cn_pre", None) is not None else x)
         return y
 
 
@@ -238,6 +243,7 @@ class DLASeg(nn.Module):
         self.last_level = last_level
         self.nchw_out = False                 # True: return the reference's NCHW fp32 map instead of the NHWC handle
         self.base = globals()[base_name](pretrained=pretrained, compute_dtype=compute_dtype)
+        self.base.expose_level0 = self.first_level == 0      # y[0] is read only when the up path starts at stride 1
         channels = self.base.channels
         scales = [2 ** i for i in range(len(channels[self.first_level:]))]
         self.dla_up = DLAUp(self.first_level, channels[self.first_level:], scales)
