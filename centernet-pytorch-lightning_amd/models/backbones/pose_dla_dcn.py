@@ -119,6 +119,10 @@ class DLA(nn.Module):
         # (BN + ReLU applied) by default.  A caller that never reads y[0] (DLASeg: first_level >= 1) clears this, and level0's last BN
         # is then left to level1's first conv (applied on load; y[0] is None instead of a raw, un-normalised tensor).
         self.expose_level0 = True
+        # mixed precision (round-4 VERDICT item 5, measured in profiles/r05_mixed_precision.txt): the first `fp32_levels` stages
+        # (1 = base_layer + level0, 2 = + level1, 3 = + level2, ...) compute and store fp32, everything behind them runs in
+        # `compute_dtype`.  0 (default) = one dtype throughout.
+        self.fp32_levels = int(os.environ.get("CN_DLA_FP32_LEVELS", 0))
         self.base_layer = nn.Sequential(hnn.StemConv(3, channels[0], 7, 1, 3), hnn.BatchNorm2d(channels[0]), nn.Identity())
         self.level0 = self._make_conv_level(channels[0], channels[0], levels[0])
         self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2)
@@ -152,15 +156,21 @@ class DLA(nn.Module):
     def forward(self, img):
         # base_layer -> level0 -> level1 are plain conv -> BN -> ReLU chains on the two largest tensors of the network (16 channels
         # at full resolution): in training their normalised activations are never stored — the next conv applies the BN on load
-        x = hnn.stem_bn_act(self.base_layer[0], self.base_layer[1], img, self.compute_dtype, defer=self._takes_raw(self.level0[0]))
+        mixed = self.fp32_levels if self.compute_dtype != torch.float32 else 0
+        x = hnn.stem_bn_act(self.base_layer[0], self.base_layer[1], img, torch.float32 if mixed else self.compute_dtype,
+                            defer=self._takes_raw(self.level0[0]))
         y = []
         for i in range(6):
             level = getattr(self, f"level{i}")
+            if mixed and i == mixed:
+                x = x.to(self.compute_dtype)        # the fp32 prefix ends here
             x = self._run_conv_level(level, x, self.level1[0] if i == 0 and not self.expose_level0 else None) if i < 2 else level(x)
             if i >= 2:
                 x = ops.share(x)        # a level's output feeds the next level and the up path
             # a deferred level0 output is a RAW conv output (its BN + ReLU live in level1's first conv): never hand that out
             y.append(None if getattr(x, "_cn_pre", None) is not None else x)
+        if mixed:
+            y = [t if t is None or t.dtype == self.compute_dtype else t.to(self.compute_dtype) for t in y]
         return y
 
 
