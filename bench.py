@@ -151,10 +151,10 @@ class ConvProbe:
         self.hip, self.ops, self.orig, self.tn = hip, [], hip.call, tn
 
     def __enter__(self):
-        def call(name, *args):
+        def call(name, *args, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = self.orig(name, *args)
+            r = self.orig(name, *args, **kw)
             e1.record()
             self.ops.append((name, tuple(a for a in args if isinstance(a, (int, float)) and not isinstance(a, bool)), e0, e1))
             return r
@@ -771,7 +771,7 @@ def main():
                     "frac_hbm": round(gbps / PEAK_HBM_GBPS, 4),
                     "step": step_roof,
                     # the dominant template may be a weight-gradient kernel: those run on the side stream with a deliberately thin
-                    # grid (cn_set_wgrad_parallelism, 160 workgroups: fewer CUs taken from the critical chain), which is the grid the
+                    # grid (cn_hooks.wgrad_blocks = 160 workgroups: fewer CUs taken from the critical chain), which is the grid the
                     # probe times them on; the largest template of the LAUNCH-STREAM chain (what decides the step) is named next to it
                     "side_stream_grid": side_grid,
                     "launch_stream_dominant": (lambda kv: dict(kernel=kv[0], **row(kv[1])))(

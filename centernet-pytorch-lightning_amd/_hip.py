@@ -46,6 +46,31 @@ def _ctype(t):
     return _CT[t.replace("const ", "").strip()]
 
 
+def parse_struct(name, path=HEADER):
+    """-> [(field, type_str), ...] of `typedef struct <name> { ... } <name>;` in declaration order"""
+    src = re.sub(r"/\*.*?\*/", " ", open(path).read(), flags=re.S)
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), src, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if decl:
+            mm = re.match(r"(.*?)(\w+)$", decl)
+            fields.append((mm.group(2), mm.group(1).strip()))
+    return fields
+
+
+class Hooks(ctypes.Structure):
+    """`cn_hooks` (include/centernet_hip.h): the optional extras of ONE call — input pre-affine, BatchNorm statistics sinks of the
+    output, weight-gradient grid — handed to the `_h` twin of an entry point.  The field list is read from the header, like the
+    prototypes.  Host memory, read (and `bn_taken` / `bnb_taken` written) during the call only: nothing stays armed in the library."""
+    _fields_ = [(f, _ctype(t)) for f, t in parse_struct("cn_hooks")]
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, _arg(v))
+        return self
+
+
 _lib = None
 _protos = None
 
@@ -91,23 +116,33 @@ def _arg(a):
 TRACE = False      # debugging aid: name every call on stderr before it is issued (with HIP_LAUNCH_BLOCKING=1 the last line is the culprit)
 
 
-def call(name, *args):
-    """Invoke cn_<name>; tensors become device pointers; the current torch stream is appended."""
+def _hooks_args(name, hooks):
+    """(entry-point name, leading part of its trailing arguments): with per-call hooks (`Hooks`) the `_h` twin is called"""
+    if hooks is None:
+        return name, ()
+    return name + "_h", (ctypes.addressof(hooks),)
+
+
+def call(name, *args, hooks=None):
+    """Invoke cn_<name> (its `_h` twin when `hooks` — a `Hooks` — is given); tensors become device pointers; the current torch
+    stream is appended."""
     L = lib()
+    name, tail = _hooks_args(name, hooks)
     fn = getattr(L, name)
     if TRACE:
         import sys
         sys.stderr.write("CALL " + name + " " + " ".join(str(tuple(a.shape)) if isinstance(a, torch.Tensor) else str(a) for a in args) + "\n")
         sys.stderr.flush()
-    rc = fn(*[_arg(a) for a in args], stream_ptr())
+    rc = fn(*[_arg(a) for a in args], *tail, stream_ptr())
     if rc != 0:
         raise RuntimeError(f"{name} failed (status {rc}): {L.cn_last_error().decode()}")
 
 
-def try_call(name, *args):
+def try_call(name, *args, hooks=None):
     """Like `call`, for entry points that decline shapes: -> False on CN_EUNSUPPORTED (the caller runs its general path)."""
     L = lib()
-    rc = getattr(L, name)(*[_arg(a) for a in args], stream_ptr())
+    name, tail = _hooks_args(name, hooks)
+    rc = getattr(L, name)(*[_arg(a) for a in args], *tail, stream_ptr())
     if rc == -2:
         return False
     if rc != 0:

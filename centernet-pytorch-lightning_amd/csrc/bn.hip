@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
     if (c >= C) return;
     double s = 0.0, q = 0.0;
     for (int b = lane; b < nblk; b += 64) { s += (double)part[((int64_t)b * 2) * C + c]; q += (double)part[((int64_t)b * 2 + 1) * C + c]; }
-    if (clear) {            // statistics sink of a producing kernel (cn_bn_stats_arm): hand it back all-zero
+    if (clear) {            // statistics sink of a producing kernel (cn_hooks.bn_part): hand it back all-zero
         for (int b = lane; b < nblk; b += 64) { clear[((int64_t)b * 2) * C + c] = 0.f; clear[((int64_t)b * 2 + 1) * C + c] = 0.f; }
     }
     s = wave_sum_d(s); q = wave_sum_d(q);
@@ -517,31 +517,15 @@ extern "C" int cn_bn_train_fwd(const void* x, const void* residual, void* y, con
 }
 
 // ---- statistics sink: the kernel that PRODUCES x accumulates sum x / sum x^2 in its epilogue (N1: conv + BN + ReLU in training) ----
-// cn_bn_stats_arm(part, slots, C) arms the next forward launch of this host thread (cn_conv2d_fwd, cn_conv1x1_cat_fwd, cn_dcn_fwd,
-// cn_stem_conv_fwd): if the kernel it dispatches to has the hook, every workgroup adds the per-channel sums of the values it STORES
-// (after rounding to the output dtype) to row (workgroup % slots) of part[slots][2][C] with fp32 atomics, and cn_bn_stats_taken()
-// returns 1; otherwise nothing is touched and it returns 0 (the caller then lets cn_bn_train_fwd read x itself).  `part` must be
-// all-zero when armed; cn_bn_train_fwd_stats hands it back all-zero.
-static thread_local BnSink bn_sink_armed = {nullptr, 0, 0};
-static thread_local int bn_sink_taken_flag = 0;
-BnSink bn_sink_take() {
-    const BnSink s = bn_sink_armed;
-    bn_sink_armed = BnSink{nullptr, 0, 0};
-    bn_sink_taken_flag = 0;
-    return s;
-}
-void bn_sink_mark_taken() { bn_sink_taken_flag = 1; }
-
+// cn_hooks.bn_part of a forward call (cn_conv2d_fwd_h, cn_conv1x1_cat_fwd_h, cn_dcn_fwd_h, cn_stem_conv_fwd_h): if the kernel the call
+// dispatches to has the hook, every workgroup adds the per-channel sums of the values it STORES (after rounding to the output dtype)
+// to row (workgroup % slots) of part[slots][2][C] with fp32 atomics and the call sets cn_hooks.bn_taken; otherwise nothing is touched
+// (the caller then lets cn_bn_train_fwd read x itself).  `part` must be all-zero on entry; cn_bn_train_fwd_stats hands it back all-zero.
+extern "C" size_t cn_hooks_size(void) { return sizeof(cn_hooks); }
 extern "C" int cn_bn_stats_slots(void) { return BN_STAT_SLOTS; }
-extern "C" int cn_bn_stats_arm(float* part, int slots, int C) {
-    CN_CHECK_ARG(part && slots > 0 && slots <= BN_MAX_BLOCKS && C > 0 && C % 8 == 0 && ((uintptr_t)part & 15) == 0, "cn_bn_stats_arm: bad args");
-    bn_sink_armed = BnSink{part, slots, C};
-    bn_sink_taken_flag = 0;
-    return CN_OK;
-}
-extern "C" int cn_bn_stats_taken(void) { return bn_sink_taken_flag; }
 
-// cn_bn_train_fwd with the statistics already in `part` (filled through cn_bn_stats_arm by the kernel that wrote x): finalize
+
+// cn_bn_train_fwd with the statistics already in `part` (filled through cn_hooks.bn_part by the kernel that wrote x): finalize
 // (+ running-stat update) and the apply pass only — x is read once instead of twice.  `part` is cleared on the way.
 extern "C" int cn_bn_train_fwd_stats(const void* x, const void* residual, void* y, const float* gamma, const float* beta,
                                      float* running_mean, float* running_var, float* save_mean, float* save_invstd,
@@ -565,7 +549,7 @@ extern "C" int cn_bn_train_fwd_stats(const void* x, const void* residual, void* 
 }
 
 // The statistics half of cn_bn_train_fwd_stats on its own: finalize from `part` (batch mean / invstd, running-stat update, scale | shift
-// into save_scale_shift[2][C]) with NO apply pass — the consumer of x applies the affine map itself (cn_conv_pre_affine_arm).
+// into save_scale_shift[2][C]) with NO apply pass — the consumer of x applies the affine map itself (cn_hooks.pre_ss).
 // `part` is handed back all-zero.
 extern "C" int cn_bn_finalize_sink(float* part, int slots, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                    float* save_mean, float* save_invstd, float* save_scale_shift, int64_t npix, int C, float momentum,
@@ -732,7 +716,7 @@ extern "C" int cn_bn_train_bwd_sink(const void* dy, const void* x, const void* y
 }
 
 // the apply half of cn_bn_train_bwd_sink alone: `sink` already holds the statistics (cn_bn_bwd_stats, or the epilogue of the kernel that
-// produced dy: cn_bn_bwd_stats_arm)
+// produced dy: cn_hooks.bnb_part)
 extern "C" int cn_bn_train_bwd_apply(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
                                      const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
                                      float* dgamma, float* dbeta, int accumulate, const float* sink, int slots, float* clear, int64_t clear_n,

@@ -10,7 +10,9 @@
 typedef unsigned short bf16_t;  // raw bfloat16 bits
 
 void cn_set_error(const char* fmt, ...);
-int cn_wgrad_target_blocks();   // target workgroup count of the split-K weight-gradient kernels (cn_set_wgrad_parallelism)
+// target workgroup count of the split-K weight-gradient kernels of ONE call (cn_hooks.wgrad_blocks; <= 0: the library default)
+#define CN_WGRAD_DEFAULT_BLOCKS 1536
+static inline int cn_wgrad_target(const cn_hooks* h) { return (h && h->wgrad_blocks > 0) ? h->wgrad_blocks : CN_WGRAD_DEFAULT_BLOCKS; }
 
 #define CN_CHECK_ARG(cond, ...)                                                                     \
     do {                                                                                            \
@@ -72,18 +74,25 @@ __device__ static inline uint32_t pk_bf16(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 
-// statistics sink of the training-mode BatchNorm (bn.hip: cn_bn_stats_arm): part[slots][2][C] fp32, all-zero when armed
+// statistics sink of the training-mode BatchNorm (bn.hip: cn_hooks.bn_part): part[slots][2][C] fp32, all-zero when handed over
 #define BN_STAT_SLOTS 128
 struct BnSink { float* part; int slots; int C; };
-BnSink bn_sink_take();            // the sink armed for this host thread's next forward launch (disarms; {nullptr} when none)
-void bn_sink_mark_taken();        // called by a launch function whose kernel accumulates into the sink
-// BN backward statistics sink armed for this host thread's next cn_conv2d_fwd (cn_bn_bwd_stats_arm, conv_igemm.hip)
+// The per-call hooks of include/centernet_hip.h (cn_hooks), unpacked.  Nothing is remembered between calls: an entry point reads the
+// struct it is handed and a launch function that honours a sink reports it through the `taken` pointer of its geometry.
+static inline BnSink hooks_sink(cn_hooks* h) {
+    if (h) h->bn_taken = 0;
+    const bool ok = h && h->bn_part && h->bn_slots > 0 && h->bn_slots <= 1024 && h->bn_C > 0 && h->bn_C % 8 == 0 && ((uintptr_t)h->bn_part & 15) == 0;
+    return ok ? BnSink{h->bn_part, h->bn_slots, h->bn_C} : BnSink{nullptr, 0, 0};
+}
+static inline void mark_taken(int* p) { if (p) *p = 1; }
 struct BnbArm { float* part; int slots; int C; const void* x; const float* stats; int relu; };
-BnbArm bnb_take();                // disarms; {nullptr} when none
-void bnb_mark_taken();
-// input pre-affine armed for this host thread's next cn_conv2d_fwd / cn_conv2d_wgrad (cn_conv_pre_affine_arm, conv_igemm.hip)
+static inline BnbArm hooks_bnb(cn_hooks* h) {
+    if (h) h->bnb_taken = 0;
+    const bool ok = h && h->bnb_part && h->bnb_slots > 0 && h->bnb_slots <= 1024 && h->bnb_C > 0 && h->bnb_x && h->bnb_stats && ((uintptr_t)h->bnb_x & 15) == 0;
+    return ok ? BnbArm{h->bnb_part, h->bnb_slots, h->bnb_C, h->bnb_x, h->bnb_stats, h->bnb_relu} : BnbArm{nullptr, 0, 0, nullptr, nullptr, 0};
+}
 struct PreAffine { const float* ss; int C; int relu; };
-PreAffine pre_affine_take();      // disarms; {nullptr} when none
+static inline PreAffine hooks_pre(const cn_hooks* h) { return (h && h->pre_ss) ? PreAffine{h->pre_ss, h->pre_C, h->pre_relu} : PreAffine{nullptr, 0, 0}; }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -184,7 +193,7 @@ __device__ static inline unsigned wave_sum_u(unsigned v) {
 #endif
 #define CN_MAIN_PRIO_SET() do { if (CN_MAIN_PRIO) __builtin_amdgcn_s_setprio(CN_MAIN_PRIO); } while (0)
 
-// ---- BatchNorm statistics in a producer's epilogue (sink protocol: bn.hip, cn_bn_stats_arm) ----
+// ---- BatchNorm statistics in a producer's epilogue (sink protocol: bn.hip, cn_hooks.bn_part) ----
 // a thread adds the 8 bf16 values it is about to store (packed pairs w) to its running (sum, sum of squares)
 __device__ static inline void bn_stat_add(float (&s0)[8], float (&s1)[8], const uint32_t (&w)[4]) {
 #pragma unroll

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void dgrad_s2_c32to16_kernel(const ConvGeom g)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
                 wa[nb][k][t] = __builtin_bit_cast(bf16x8_t, ldg16(Wp + (int64_t)(16 * nb + px) * g.ktot + t * CO + 32 * k + 8 * kc));
-    // BatchNorm backward statistics of the stored gradient (cn_bn_bwd_stats_arm; 16 output channels only)
+    // BatchNorm backward statistics of the stored gradient (cn_hooks.bnb_part; 16 output channels only)
     const bool bnb = NB == 1 && g.bnb_part != nullptr;
     BnbLane bl;
     bnb_lane_init(bl, bnb ? g.bnb_stats : nullptr, g.y_ld, 4 * kc);
@@ -366,7 +366,7 @@ bool dgrad_s2_c32to16_launch(const ConvGeom& g, hipStream_t st) {
     int64_t blocks = (strips + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (g.bnb_part) {
-        if (g.Ci == 32 && g.Co == 16 && g.bnb_slots > 0) bnb_mark_taken(); else const_cast<ConvGeom&>(g).bnb_part = nullptr;
+        if (g.Ci == 32 && g.Co == 16 && g.bnb_slots > 0) mark_taken(g.bnb_taken); else const_cast<ConvGeom&>(g).bnb_part = nullptr;
     }
     if (g.Ci == 32 && g.Co == 16) hipLaunchKernelGGL((dgrad_s2_c32to16_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, g);
     else if (g.Ci == 64 && g.Co == 32) hipLaunchKernelGGL((dgrad_s2_c32to16_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -398,7 +398,7 @@ bool conv3x3s2_launch(const ConvGeom& g, int dtype, hipStream_t st) {
     static const bool no_tile = getenv("CN_DISABLE_EPI_TILE") != nullptr;
     const_cast<ConvGeom&>(g).epi_tile = (conv_epi_tile_ok(g, dtype) && !no_tile) ? 1 : 0;
     if (g.bn_part) {                                   // BN statistics sink: the LDS-staged epilogue has the hook
-        if (g.epi_tile) bn_sink_mark_taken(); else const_cast<ConvGeom&>(g).bn_part = nullptr;
+        if (g.epi_tile) mark_taken(g.bn_taken); else const_cast<ConvGeom&>(g).bn_part = nullptr;
     }
     int bn = 32, bnb = (g.Co + 31) / 32;
     for (int c : {64, 128}) {
@@ -423,14 +423,14 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
         const int64_t strips = (int64_t)g.N * g.H * ((g.W + 16 * C16_GROUPS - 1) / (16 * C16_GROUPS));
         int64_t blocks = (strips + 3) / 4;
         if (blocks > 4096) blocks = 4096;
-        if (g.bn_part) bn_sink_mark_taken();            // the direct 16-channel kernel has the statistics hook
+        if (g.bn_part) mark_taken(g.bn_taken);            // the direct 16-channel kernel has the statistics hook
         hipLaunchKernelGGL(conv3x3_c16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
         return true;
     }
     if (conv3x3_ws_launch(g, dtype, st)) return true;  // 64 input channels, enough tiles: weight-stationary persistent kernel
     if (conv3x3_kp_launch(g, dtype, st)) return true;  // >= 128 input channels on 16-pixel-aligned maps: K-pipelined persistent kernel (no BN statistics hook: the sink stays untaken)
     if (g.bn_part) {                                   // BN statistics sink: the LDS-staged epilogue has the hook
-        if (g.epi_tile) bn_sink_mark_taken(); else const_cast<ConvGeom&>(g).bn_part = nullptr;
+        if (g.epi_tile) mark_taken(g.bn_taken); else const_cast<ConvGeom&>(g).bn_part = nullptr;
     }
     int bn = 32, bnb = (g.Co + 31) / 32;               // same rule as pick_tile(): fewest channel blocks
     for (int c : {64, 128}) {

@@ -15,7 +15,7 @@
 //     into ONE L2.
 //   * AFF: the input is the RAW output of the previous convolution and the training-mode BatchNorm (+ ReLU) of that layer is applied
 //     on the way into the MFMA operand — x' = bf16(max(fma(x, scale[c], shift[c]), 0)), bit-identical to what bn_fwd_apply_sink_kernel
-//     would have stored — so the normalised activation is never written or read (cn_conv_pre_affine_arm).  Zero padding is applied
+//     would have stored — so the normalised activation is never written or read (cn_hooks.pre_ss).  Zero padding is applied
 //     AFTER the affine map.  The transform runs when a ring slot is first used, not where its loads are issued.
 // The zero half of the fifth weight operand multiplies real data (the row below): a non-finite input there would leak as NaN into a
 // row it does not belong to — not a concern for activations that are finite, which everything downstream needs anyway.
@@ -295,10 +295,10 @@ bool conv_c16r_launch(const ConvGeom& g, int dtype, int S, hipStream_t st) {
     const int64_t blocks = (int64_t)8 * ((g.N + 7) / 8) * sblocks * rblocks;
     if (blocks > 0x7fffffff) return false;
     if (g.bn_part) {
-        if (g.bn_slots > 0) bn_sink_mark_taken(); else const_cast<ConvGeom&>(g).bn_part = nullptr;
+        if (g.bn_slots > 0) mark_taken(g.bn_taken); else const_cast<ConvGeom&>(g).bn_part = nullptr;
     }
     if (g.bnb_part) {
-        if (S == 1 && g.bnb_slots > 0 && !g.bn_part) bnb_mark_taken(); else const_cast<ConvGeom&>(g).bnb_part = nullptr;
+        if (S == 1 && g.bnb_slots > 0 && !g.bn_part) mark_taken(g.bnb_taken); else const_cast<ConvGeom&>(g).bnb_part = nullptr;
     }
     const int aff = g.pre_ss ? 1 + g.pre_relu : 0;
 #define CR_GO(S_, NCB_, AFF_) hipLaunchKernelGGL((conv3x3_c16r_kernel<S_, NCB_, AFF_>), dim3((unsigned)blocks), dim3(256), 0, st, g, R, sblocks, rblocks)

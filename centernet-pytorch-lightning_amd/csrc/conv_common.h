@@ -40,10 +40,12 @@ struct ConvGeom {
     // 1x1 conv over the channel CONCATENATION of nsrc tensors of the same N,H,W (DLA Root, pose_dla_dcn.py:180-188): the K loop
     // walks the sources one after the other, so torch.cat(x, 1) is never materialised.  nsrc == 0: the single input `x`.
     int nsrc;
-    // BatchNorm statistics sink (training-mode conv + BN, bn.hip: cn_bn_stats_arm): every workgroup adds sum / sum of squares of the
+    // BatchNorm statistics sink (training-mode conv + BN, bn.hip: cn_hooks.bn_part): every workgroup adds sum / sum of squares of the
     // values it stores to part[workgroup % bn_slots][2][y_ld]; only the LDS-staged bf16 epilogue has the hook
     float* bn_part;
     int bn_slots;
+    int* bn_taken;            // host pointer (cn_hooks.bn_taken), set to 1 by the launch function whose kernel fills bn_part; nullable
+    int* bnb_taken;           // the same for bnb_part
     const void* xs[CN_MAX_SRC];
     int xs_c[CN_MAX_SRC];     // channels (= pixel pitch) of each source, multiples of the K slice
     int xs_k0[CN_MAX_SRC];    // first K index of each source
@@ -52,11 +54,11 @@ struct ConvGeom {
     const float* head_w;
     const float* head_b;
     int head_nc;
-    // pre-affine of the INPUT (cn_conv_pre_affine_arm; conv_c16.hip): x is the raw output of the previous conv, the kernel applies
+    // pre-affine of the INPUT (cn_hooks.pre_ss; conv_c16.hip): x is the raw output of the previous conv, the kernel applies
     // x' = bf16(fma(x, pre_ss[c], pre_ss[Ci + c])) (pre_relu: max(., 0)) — that layer's training-mode BatchNorm — on the way in
     const float* pre_ss;
     int pre_relu;
-    // BatchNorm BACKWARD statistics sink (cn_bn_bwd_stats_arm; the 16-channel data-gradient kernels have the hook): y is the gradient
+    // BatchNorm BACKWARD statistics sink (cn_hooks.bnb_part; the 16-channel data-gradient kernels have the hook): y is the gradient
     // w.r.t. the output of a training-mode BN (+ ReLU) whose input was bnb_x (pitch y_ld); every workgroup adds, over the values it
     // STORES, sum g and sum g * xhat (g = relu ? (fma(x, sc, sh) > 0 ? y : 0) : y, xhat = (x - mean) * invstd) to bnb_part[slots][2][y_ld]
     float* bnb_part;
@@ -374,12 +376,12 @@ __device__ static inline void dcn_dom_accumulate(const ConvGeom& g, f32x16_t (&a
 void dcn_bwd_dx_launch(const ConvGeom& g, int dtype, hipStream_t st);
 void dcn_fwd_launch(const ConvGeom& g, int dtype, hipStream_t st);
 bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                         int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st);
+                         int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st);
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st);   // dcn_bm.hip: blend on the matrix cores
+                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st);   // dcn_bm.hip: blend on the matrix cores
 bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld);
 bool dcn_fwd_gs_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st);   // dcn_gs.hip: gather-sample (dot2 on a pair image), W in registers
+                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st);   // dcn_gs.hip: gather-sample (dot2 on a pair image), W in registers
 bool dcn_fwd_gs_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld);
 bool dcn_dx_bm_shape_ok(int Ci, int dy_ld, int om_ld);
 bool dcn_fwd_tile_shape_ok(int Ci, int x_ld, int Co, int y_ld);

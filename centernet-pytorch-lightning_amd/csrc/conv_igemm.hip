@@ -391,7 +391,7 @@ static void launch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
     ConvGeom gg = g;
     gg.epi_tile = (!no_tile && conv_epi_tile_ok(g, sizeof(T) == 2 ? CN_BF16 : CN_F32)) ? 1 : 0;
     if (gg.bn_part) {                                  // BN statistics sink: the LDS-staged epilogue has the hook
-        if (gg.epi_tile) bn_sink_mark_taken(); else gg.bn_part = nullptr;
+        if (gg.epi_tile) mark_taken(gg.bn_taken); else gg.bn_part = nullptr;
     }
     hipLaunchKernelGGL((conv_igemm_kernel<T, BN, BK>), grid, dim3(256), 0, st, gg);
 }
@@ -451,56 +451,17 @@ static int dispatch_igemm(const ConvGeom& g, int ncls, hipStream_t st) {
 }
 
 // ---- pre-affine of the input: the consumer applies the previous layer's training-mode BatchNorm (+ ReLU) ----
-// cn_conv_pre_affine_arm(ss, C, relu) arms the next cn_conv2d_fwd / cn_conv2d_wgrad of this host thread: x is then the RAW output of
-// the previous convolution and the kernel applies x' = bf16(fma(x, ss[c], ss[C + c])) (relu: max(., 0)) — exactly what
-// cn_bn_train_fwd_sink would have stored — on the way in, so the normalised activation is never materialised (zero padding applies to
-// x').  ss = the layer's saved scale | shift (fp32 [2][C], device memory, written by cn_bn_finalize_sink earlier on the stream).
-// Only the 16-input-channel kernels have the hook (conv_c16.hip, wgrad_c16.hip): any other shape fails with CN_EUNSUPPORTED — there
-// is no fallback that would silently convolve the raw tensor.
-static thread_local PreAffine pre_affine_armed = {nullptr, 0, 0};
-PreAffine pre_affine_take() {
-    const PreAffine p = pre_affine_armed;
-    pre_affine_armed = PreAffine{nullptr, 0, 0};
-    return p;
-}
-// ---- BatchNorm backward statistics from the kernel that PRODUCES the gradient ----
-// cn_bn_bwd_stats_arm(sink, slots, C, x, stats, relu) arms the next cn_conv2d_fwd of this host thread (a data gradient: transposed != 0):
-// its output y is the gradient w.r.t. the output of a training-mode BN (+ ReLU) with input x (NHWC, pitch C == y_ld) and saved
-// statistics stats = fp32 [4][C] mean | invstd | scale | shift.  When the kernel it dispatches to has the hook (the 16-channel bf16
-// data-gradient kernels), it adds per channel sum g and sum g * xhat of the values it stores to sink[slots][2][C] (all-zero when armed)
-// — what cn_bn_bwd_stats would compute in a pass of its own over (y, x) — and cn_bn_bwd_stats_taken() returns 1; otherwise the sink
-// is untouched and it returns 0.
-static thread_local BnbArm bnb_armed = {nullptr, 0, 0, nullptr, nullptr, 0};
-static thread_local int bnb_taken_flag = 0;
-BnbArm bnb_take() {
-    const BnbArm b = bnb_armed;
-    bnb_armed = BnbArm{nullptr, 0, 0, nullptr, nullptr, 0};
-    bnb_taken_flag = 0;
-    return b;
-}
-void bnb_mark_taken() { bnb_taken_flag = 1; }
-extern "C" int cn_bn_bwd_stats_arm(float* sink, int slots, int C, const void* x, const float* stats, int relu) {
-    CN_CHECK_ARG(sink && slots > 0 && slots <= 1024 && C > 0 && x && stats && (relu == 0 || relu == 1) && ((uintptr_t)x & 15) == 0,
-                 "cn_bn_bwd_stats_arm: bad args");
-    bnb_armed = BnbArm{sink, slots, C, x, stats, relu};
-    bnb_taken_flag = 0;
-    return CN_OK;
-}
-extern "C" int cn_bn_bwd_stats_taken(void) { return bnb_taken_flag; }
-
-extern "C" int cn_conv_pre_affine_arm(const float* ss, int C, int relu) {
-    CN_CHECK_ARG(ss && C > 0 && (relu == 0 || relu == 1) && ((uintptr_t)ss & 3) == 0, "cn_conv_pre_affine_arm: bad args");
-    pre_affine_armed = PreAffine{ss, C, relu};
-    return CN_OK;
-}
-
-extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
-                             int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
-                             int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype,
-                             void* stream) {
-    const BnSink sink = bn_sink_take();   // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm): disarmed before ANY early return
-    const PreAffine pre = pre_affine_take();
-    const BnbArm bnb = bnb_take();
+// cn_hooks (include/centernet_hip.h) carries the optional extras of ONE call: the input pre-affine (only the 16-input-channel kernels
+// have the hook, conv_c16.hip / wgrad_c16.hip: any other shape fails with CN_EUNSUPPORTED — there is no fallback that would silently
+// convolve the raw tensor), the BatchNorm statistics sink of the output and the BN-backward statistics sink of a data gradient.  The
+// entry point unpacks the struct it is handed (common.h: hooks_sink / hooks_pre / hooks_bnb); nothing is remembered between calls.
+extern "C" int cn_conv2d_fwd_h(const void* x, const void* wp, const float* bias, const void* residual, void* y,
+                               int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
+                               int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype,
+                               cn_hooks* hooks, void* stream) {
+    const BnSink sink = hooks_sink(hooks);
+    const PreAffine pre = hooks_pre(hooks);
+    const BnbArm bnb = hooks_bnb(hooks);
     CN_CHECK_ARG(x && wp && y, "cn_conv2d_fwd: null pointer");
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0, "cn_conv2d_fwd: bad dims");
     if (Ci % 16 != 0 || Ci <= 0) CN_UNSUPPORTED("cn_conv2d_fwd: Ci=%d must be a positive multiple of 16", Ci);
@@ -521,10 +482,11 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     int ncls = build_geom(g, KH, KW, stride, pad, transposed);
     if (ncls < 0) CN_UNSUPPORTED("cn_conv2d_fwd: kernel %dx%d stride %d not supported", KH, KW, stride);
     // the sink is honoured by the kernels that have the hook
-    if (sink.part && dtype == CN_BF16 && out_dtype == dtype && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
+    if (sink.part && dtype == CN_BF16 && out_dtype == dtype && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; g.bn_taken = &hooks->bn_taken; }
     if (dtype != CN_F32 && dtype != CN_BF16) CN_CHECK_ARG(false, "cn_conv2d_fwd: bad dtype %d", dtype);
     if (bnb.part && transposed && dtype == CN_BF16 && out_dtype == dtype && bnb.C == y_ld && !sink.part) {   // honoured by the kernels that have the hook
         g.bnb_part = bnb.part; g.bnb_slots = bnb.slots; g.bnb_x = bnb.x; g.bnb_stats = bnb.stats; g.bnb_relu = bnb.relu;
+        g.bnb_taken = &hooks->bnb_taken;
     }
     if (pre.ss) {                         // input pre-affine: only the 16-input-channel row-walking kernel has the hook
         CN_CHECK_ARG(pre.C == Ci, "cn_conv2d_fwd: pre-affine armed for %d channels, conv has %d", pre.C, Ci);
@@ -568,6 +530,14 @@ extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, c
     return CN_OK;
 }
 
+extern "C" int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
+                             int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
+                             int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype,
+                             void* stream) {
+    return cn_conv2d_fwd_h(x, wp, bias, residual, y, N, H, W, Ci, x_ld, OH, OW, Co, y_ld, res_ld, KH, KW, stride, pad, transposed, relu,
+                           dtype, out_dtype, nullptr, stream);
+}
+
 // A 2-channel task head in one launch (heads.py:9-15 `conv3x3 -> ReLU -> conv1x1`; width_height / regression): out fp32 NCHW
 // [N, 2, H, W] (ALL-ZERO at launch: the kernel adds) = conv1x1(relu(conv3x3(x) + b1)) + b2, x NHWC bf16 with 64 channels, wp1 = the
 // hidden conv's weights packed with mode 1 ([Ch_pad32][9 * 64]), w2 fp32 [2][Ch], Ch a multiple of 64.  The hidden activation is never
@@ -605,11 +575,11 @@ extern "C" int cn_conv1x1_nchw_fwd(const void* x, const void* wp, const float* b
 }
 
 // 1x1 / stride 1 conv over the channel concatenation of up to CN_MAX_SRC NHWC tensors (each contiguous: pitch = its channel count)
-extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
-                                  int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
-                                  const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
-                                  int dtype, void* stream) {
-    const BnSink sink = bn_sink_take();   // armed statistics sink: disarmed before any early return
+extern "C" int cn_conv1x1_cat_fwd_h(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
+                                    int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
+                                    const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
+                                    int dtype, cn_hooks* hooks, void* stream) {
+    const BnSink sink = hooks_sink(hooks);
     const void* xs[CN_MAX_SRC] = {x0, x1, x2, x3, x4, x5};
     const int cs[CN_MAX_SRC] = {c0, c1, c2, c3, c4, c5};
     CN_CHECK_ARG(nsrc >= 1 && nsrc <= CN_MAX_SRC && wp && y && N > 0 && H > 0 && W > 0 && Co > 0 && y_ld >= Co,
@@ -631,7 +601,7 @@ extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2
     g.N = N; g.H = H; g.W = W; g.Ci = k; g.x_ld = cs[0]; g.OH = H; g.OW = W; g.Co = Co; g.y_ld = y_ld; g.res_ld = res_ld;
     g.ktot = k; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu;
     const int ncls = build_geom(g, 1, 1, 1, 0, 0);
-    if (sink.part && dtype == CN_BF16 && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; }
+    if (sink.part && dtype == CN_BF16 && sink.C == y_ld) { g.bn_part = sink.part; g.bn_slots = sink.slots; g.bn_taken = &hooks->bn_taken; }
     // tile choice of dispatch_igemm with the K slice bounded by the smallest source granule
     ConvGeom gp = g;
     gp.Ci = div;                                // pick_tile() only looks at divisibility
@@ -649,6 +619,13 @@ extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2
 #undef CN_IGC
     CN_LAUNCH_CHECK("cn_conv1x1_cat_fwd");
     return CN_OK;
+}
+extern "C" int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
+                                  int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
+                                  const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
+                                  int dtype, void* stream) {
+    return cn_conv1x1_cat_fwd_h(x0, x1, x2, x3, x4, x5, c0, c1, c2, c3, c4, c5, nsrc, wp, bias, residual, y, N, H, W, Co, y_ld, res_ld, relu,
+                                dtype, nullptr, stream);
 }
 
 // dom / dx_far of the DCNv2 backward, fused into the GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2: [9*Ci][Co_pad16])
@@ -741,9 +718,10 @@ extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
 
 // Fused DCNv2 forward (sampling -> LDS -> MFMA, dcn_fused.hip): y = act(bias + sum_k W_k * mask_k * bilinear_k(x) [+ residual]).
 // wp = cn_pack_weight mode 1 of the layer weight ([Co_pad32][tap*Ci + ci]); om fp32 [P][om_ld]; bias fp32[Co] nullable.
-extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,
-                          int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, void* stream) {
-    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (the blend-matrix kernel has the hook)
+extern "C" int cn_dcn_fwd_h(const void* x, const float* om, const void* wp, const float* bias, void* y,
+                            int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, cn_hooks* hooks, void* stream) {
+    const BnSink sink = hooks_sink(hooks);       // BatchNorm statistics sink of this call (the kernels with an LDS-staged epilogue have the hook)
+    int* const taken = hooks ? &hooks->bn_taken : nullptr;
     CN_CHECK_ARG(x && om && wp && y && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "cn_dcn_fwd: bad args");
     if (Ci % 16 != 0) CN_UNSUPPORTED("cn_dcn_fwd: Ci=%d must be a multiple of 16", Ci);
     if (N > 65535) CN_UNSUPPORTED("cn_dcn_fwd: batch %d", N);
@@ -757,22 +735,26 @@ extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const 
     g.dcn_om = om; g.dcn_omld = om_ld;
     const bool sink_ok = sink.part && dtype == CN_BF16 && sink.C == y_ld;
     if (dtype == CN_BF16 && dcn_fwd_gs_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
-                                              sink.slots, (hipStream_t)stream)) {
+                                              sink.slots, taken, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_fwd(gs)");
         return CN_OK;
     }
     if (dtype == CN_BF16 && dcn_fwd_bm_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
-                                              sink.slots, (hipStream_t)stream)) {
+                                              sink.slots, taken, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_fwd(bm)");
         return CN_OK;
     }
     if (!(dtype == CN_BF16 && dcn_fwd_tile_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr, sink.slots,
-                                                  (hipStream_t)stream))) {
-        if (sink_ok) { g.bn_part = sink.part; g.bn_slots = sink.slots; }      // honoured where the gather kernel runs its LDS-staged epilogue
+                                                  taken, (hipStream_t)stream))) {
+        if (sink_ok) { g.bn_part = sink.part; g.bn_slots = sink.slots; g.bn_taken = taken; }      // honoured where the gather kernel runs its LDS-staged epilogue
         dcn_fwd_launch(g, dtype, (hipStream_t)stream);
     }
     CN_LAUNCH_CHECK("cn_dcn_fwd");
     return CN_OK;
+}
+extern "C" int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,
+                          int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, void* stream) {
+    return cn_dcn_fwd_h(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, relu, dtype, nullptr, stream);
 }
 
 // dx of the DCNv2 backward (adjoint-gather + contraction, dcn_fused.hip).  wpd0 = cn_pack_weight mode 0 of the layer weight

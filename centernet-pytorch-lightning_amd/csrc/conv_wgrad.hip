@@ -31,10 +31,10 @@ __device__ static inline bf16x8_t tr_frag(const bf16_t* tile, int pitch, int r0,
 }
 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
-                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st, const float* pre_ss, int pre_relu);   // stem.hip
+                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st, const float* pre_ss, int pre_relu, int target);   // stem.hip
 
 bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                       hipStream_t st);                                                                 // conv_wgrad3x3.hip
+                       hipStream_t st, int target);                                                     // conv_wgrad3x3.hip
 
 struct WgradGeom {
     const void* x;
@@ -47,6 +47,7 @@ struct WgradGeom {
     int ci_tiles;
     int64_t P;          // N*OH*OW
     int64_t chunk;      // pixels per split-K chunk (multiple of the K tile)
+    int target;         // workgroups wanted over the whole launch (host side only: cn_hooks.wgrad_blocks)
 };
 
 template <typename T, int BMW, int BNW>
@@ -272,16 +273,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
     }
 }
 
-// Weight-gradient kernels split K (= pixels) over this many workgroups.  Alone on the GPU they want ~6 per CU (1536); when
-// they run on a side stream next to the data-gradient chain a THIN grid (~384) leaves the CUs to the chain that is on the
-// critical path: measured +4 % step throughput on DLA-34 (the side work has 2x slack).
-static int g_wgrad_target = 1536;
-int cn_wgrad_target_blocks() { return g_wgrad_target; }
-extern "C" int cn_set_wgrad_parallelism(int blocks) {
-    CN_CHECK_ARG(blocks >= 1 && blocks <= 65536, "cn_set_wgrad_parallelism: blocks=%d", blocks);
-    g_wgrad_target = blocks;
-    return CN_OK;
-}
+// Weight-gradient kernels split K (= pixels) over cn_hooks.wgrad_blocks workgroups (cn_wgrad_target: CN_WGRAD_DEFAULT_BLOCKS without
+// hooks).  Alone on the GPU they want ~6 per CU (1536); when they run on a side stream next to the data-gradient chain a THIN
+// grid (~384) leaves the CUs to the chain that is on the critical path: measured +4 % step throughput on DLA-34 (the side work
+// has 2x slack).  The count is an argument of the call — there is no process-wide setting.
 
 template <typename T, int BMW, int BNW>
 static void launch_wgrad(WgradGeom& g, int taps, hipStream_t st) {
@@ -289,7 +284,7 @@ static void launch_wgrad(WgradGeom& g, int taps, hipStream_t st) {
     int co_tiles = cdiv(g.Co, BMW);
     g.ci_tiles = cdiv(g.Ci, BNW);
     int base = co_tiles * g.ci_tiles * taps;
-    int64_t want = (cn_wgrad_target_blocks() * 4 / 3 + base - 1) / base;   // default: >= ~2048 workgroups
+    int64_t want = (g.target * 4 / 3 + base - 1) / base;   // default: >= ~2048 workgroups
     int64_t maxk = (g.P + 8 * BKP - 1) / (8 * BKP);    // at least 8 K tiles per workgroup
     if (want > maxk) want = maxk;
     if (want < 1) want = 1;
@@ -331,24 +326,29 @@ extern "C" int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld
 // reduction launch sums them — no fp32 atomics, no pre-zeroed packed gradient, no unpack launch, fixed summation order.
 // cn_conv2d_wgrad_direct_bytes: scratch size, 0 = shape not handled here (use cn_conv2d_wgrad + cn_unpack_wgrad).
 bool wgrad3x3s1_slab_launch(const void* x, const void* dy, float* slabs, float* dw, int accumulate, int N, int H, int W, int Ci, int x_ld,
-                            int Co, int dy_ld, int stride, hipStream_t st);
-size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld, int stride);
-extern "C" size_t cn_conv2d_wgrad_direct_bytes(int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld, int KH, int KW,
-                                               int stride, int pad, int dtype) {
+                            int Co, int dy_ld, int stride, hipStream_t st, int target);
+size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld, int stride, int target);
+extern "C" size_t cn_conv2d_wgrad_direct_bytes_h(int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld, int KH, int KW,
+                                                 int stride, int pad, int dtype, int wgrad_blocks) {
     if (dtype != CN_BF16 || KH != 3 || KW != 3 || (stride != 1 && stride != 2) || pad != 1 || Ci <= 16) return 0;
     if (OH != (H + 2 - 3) / stride + 1 || OW != (W + 2 - 3) / stride + 1) return 0;
-    return wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld, stride);
+    return wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld, stride, wgrad_blocks > 0 ? wgrad_blocks : CN_WGRAD_DEFAULT_BLOCKS);
 }
-extern "C" int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
-                                      int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
-                                      int KH, int KW, int stride, int pad, int dtype, void* stream) {
+extern "C" size_t cn_conv2d_wgrad_direct_bytes(int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld, int KH, int KW,
+                                               int stride, int pad, int dtype) {
+    return cn_conv2d_wgrad_direct_bytes_h(N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, 0);
+}
+extern "C" int cn_conv2d_wgrad_direct_h(const void* x, const void* dy, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
+                                        int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                                        int KH, int KW, int stride, int pad, int dtype, cn_hooks* hooks, void* stream) {
     CN_CHECK_ARG(x && dy && dw && ws, "cn_conv2d_wgrad_direct: null pointer");
-    const size_t need = cn_conv2d_wgrad_direct_bytes(N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype);
+    const int target = cn_wgrad_target(hooks);
+    const size_t need = cn_conv2d_wgrad_direct_bytes_h(N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, target);
     if (need == 0) CN_UNSUPPORTED("cn_conv2d_wgrad_direct: shape not handled (cn_conv2d_wgrad_direct_bytes == 0)");
     if (ws_bytes < need) { cn_set_error("cn_conv2d_wgrad_direct: workspace too small"); return CN_EWORKSPACE; }
     CN_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15) == 0 && x_ld >= Ci && dy_ld >= Co, "cn_conv2d_wgrad_direct: bad pointers / pitches");
     hipStream_t st = (hipStream_t)stream;
-    if (!wgrad3x3s1_slab_launch(x, dy, (float*)ws, dw, accumulate, N, H, W, Ci, x_ld, Co, dy_ld, stride, st))
+    if (!wgrad3x3s1_slab_launch(x, dy, (float*)ws, dw, accumulate, N, H, W, Ci, x_ld, Co, dy_ld, stride, st, target))
         CN_UNSUPPORTED("cn_conv2d_wgrad_direct: shape not handled");
     CN_LAUNCH_CHECK("cn_conv2d_wgrad_direct");
     if (db) {
@@ -357,11 +357,18 @@ extern "C" int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, 
     }
     return CN_OK;
 }
+extern "C" int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
+                                      int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                                      int KH, int KW, int stride, int pad, int dtype, void* stream) {
+    return cn_conv2d_wgrad_direct_h(x, dy, dw, db, accumulate, ws, ws_bytes, N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype,
+                                    nullptr, stream);
+}
 
-extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
-                               int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
-                               int KH, int KW, int stride, int pad, int dtype, void* stream) {
-    const PreAffine pre = pre_affine_take();     // input pre-affine armed for this launch (cn_conv_pre_affine_arm): disarmed before any early return
+extern "C" int cn_conv2d_wgrad_h(const void* x, const void* dy, float* dwp, float* db,
+                                 int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                                 int KH, int KW, int stride, int pad, int dtype, cn_hooks* hooks, void* stream) {
+    const PreAffine pre = hooks_pre(hooks);      // input pre-affine of this call (cn_hooks.pre_ss)
+    const int target = cn_wgrad_target(hooks);
     CN_CHECK_ARG(x && dy && dwp, "cn_conv2d_wgrad: null pointer");
     CN_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && Co > 0 && Ci > 0, "cn_conv2d_wgrad: bad dims");
     int V = dtype == CN_F32 ? 4 : 8;
@@ -375,18 +382,18 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float*
     g.x = x; g.dy = dy; g.dwp = dwp;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.OH = OH; g.OW = OW; g.Co = Co; g.dy_ld = dy_ld;
     g.KW = KW; g.stride = stride; g.pad = pad; g.ktot = KH * KW * Ci; g.co_pad = (Co + 31) / 32 * 32;
-    g.P = (int64_t)N * OH * OW;
+    g.P = (int64_t)N * OH * OW; g.target = target;
     hipStream_t st = (hipStream_t)stream;
     bool done_small = false;
-    if (pre.ss) CN_CHECK_ARG(pre.C == Ci, "cn_conv2d_wgrad: pre-affine armed for %d channels, conv has %d", pre.C, Ci);
-    if (Ci <= 16 && small_wgrad_packed(x, dy, dwp, N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, st, pre.ss, pre.relu)) {
+    if (pre.ss) CN_CHECK_ARG(pre.C == Ci, "cn_conv2d_wgrad: pre-affine given for %d channels, conv has %d", pre.C, Ci);
+    if (Ci <= 16 && small_wgrad_packed(x, dy, dwp, N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, st, pre.ss, pre.relu, target)) {
         CN_LAUNCH_CHECK("cn_conv2d_wgrad(small)");
         done_small = true;
     }
     if (pre.ss && !done_small)
-        CN_UNSUPPORTED("cn_conv2d_wgrad: an input pre-affine is armed but this shape has no kernel with the hook (bf16, 3x3 / pad 1, 16 input channels)");
+        CN_UNSUPPORTED("cn_conv2d_wgrad: an input pre-affine is given but this shape has no kernel with the hook (bf16, 3x3 / pad 1, 16 input channels)");
     if (!done_small && dtype == CN_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W &&
-        wgrad3x3s1_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, st)) {
+        wgrad3x3s1_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, st, target)) {
         CN_LAUNCH_CHECK("cn_conv2d_wgrad(3x3)");
         done_small = true;
     }
@@ -407,4 +414,9 @@ extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float*
         if (rc) return rc;
     }
     return CN_OK;
+}
+extern "C" int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
+                               int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                               int KH, int KW, int stride, int pad, int dtype, void* stream) {
+    return cn_conv2d_wgrad_h(x, dy, dwp, db, N, H, W, Ci, x_ld, OH, OW, Co, dy_ld, KH, KW, stride, pad, dtype, nullptr, stream);
 }

@@ -26,6 +26,7 @@ struct Wgrad3Geom {
     int tiles_h, tiles_w, ci_tiles;
     int tiles_per_block;
     int OH, OW;          // output (dY) size: H, W for stride 1; (H - 1) / 2 + 1 ... for the stride-2 variant
+    int target;          // workgroups wanted over the whole launch (cn_hooks.wgrad_blocks, cn_wgrad_target)
 };
 
 // 32(channel) x 16(pixel) operand from a [row][channel] LDS tile; the 16 pixels are rows row0 .. row0+15.
@@ -246,7 +247,7 @@ static size_t w3_slab_plan(Wgrad3Geom& g) {              // fills the tiling fie
     // the 8-wave all-taps tile runs one workgroup per CU and its slab is 295 KB: one round of workgroups (64 -> 256 @128^2: 298 us
     // with 256 workgroups, 368 with 384)
     static const int env_blocks = getenv("CN_WGRAD3X3_BLOCKS") ? atoi(getenv("CN_WGRAD3X3_BLOCKS")) : 0;            // A/B: this family's own grid
-    const int base_target = env_blocks > 0 ? env_blocks : cn_wgrad_target_blocks();
+    const int base_target = env_blocks > 0 ? env_blocks : g.target;
     const int target = (BMW == 128 && TAPS == 9 && base_target > 256) ? 256 : base_target;
     int64_t want = (target + par - 1) / par;
     if (want > ntiles) want = ntiles;
@@ -279,7 +280,7 @@ static void launch_w3(Wgrad3Geom& g, hipStream_t st) {
     g.ci_tiles = cdiv(g.Ci, BNW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
-    int64_t want = (cn_wgrad_target_blocks() + par - 1) / par;   // workgroups over the whole launch (see cn_set_wgrad_parallelism)
+    int64_t want = (g.target + par - 1) / par;   // workgroups over the whole launch (cn_hooks.wgrad_blocks)
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     g.tiles_per_block = (int)((ntiles + want - 1) / want);
@@ -293,13 +294,13 @@ static void launch_w3(Wgrad3Geom& g, hipStream_t st) {
 
 // bf16, 3x3 / stride 1 / pad 1, Ci > 16.  Returns false if the shape is not handled here.
 bool wgrad3x3s1_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                       hipStream_t st) {
+                       hipStream_t st, int target) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD3X3") != nullptr;
     if (disabled || Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) return false;
     Wgrad3Geom g;
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.dwp = dwp;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.ktot = 9 * Ci;
-    g.OH = H; g.OW = W;
+    g.OH = H; g.OW = W; g.target = target;
     g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
     if (Co > 64) launch_w3<128, 64, 3>(g, st);      // 68.6 KB LDS, 96 accumulator registers
     else launch_w3<64, 64, 9>(g, st);               // 59 KB LDS, 144 accumulator registers
@@ -314,23 +315,23 @@ static void w3_tiles(Wgrad3Geom& g, int stride) {
     g.OW = stride == 1 ? g.W : (g.W - 1) / 2 + 1;
     g.tiles_h = cdiv(g.OH, stride == 1 ? W3_TH : 4); g.tiles_w = cdiv(g.OW, W3_TW);
 }
-size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld, int stride) {
+size_t wgrad3x3s1_slab_bytes(int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld, int stride, int target) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD3X3") != nullptr || getenv("CN_DISABLE_WGRAD_SLABS") != nullptr;
     static const bool no_s2 = getenv("CN_DISABLE_WGRAD3X3_S2") != nullptr;
     if (disabled || Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0 || (stride != 1 && stride != 2) || (stride == 2 && no_s2)) return 0;
     Wgrad3Geom g;
-    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.target = target;
     w3_tiles(g, stride);
     static const bool taps9 = getenv("CN_WGRAD3X3_WIDE_TAPS3") == nullptr;      // A/B: the 4-wave 128 x 64 tile with one tap row per workgroup
     return Co > 64 ? ((taps9 || stride == 2) ? w3_slab_plan<128, 64, 9>(g) : w3_slab_plan<128, 64, 3>(g)) : w3_slab_plan<64, 64, 9>(g);
 }
 
 bool wgrad3x3s1_slab_launch(const void* x, const void* dy, float* slabs, float* dw, int accumulate, int N, int H, int W, int Ci, int x_ld,
-                            int Co, int dy_ld, int stride, hipStream_t st) {
-    if (wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld, stride) == 0) return false;
+                            int Co, int dy_ld, int stride, hipStream_t st, int target) {
+    if (wgrad3x3s1_slab_bytes(N, H, W, Ci, x_ld, Co, dy_ld, stride, target) == 0) return false;
     Wgrad3Geom g;
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.dwp = slabs;
-    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.ktot = 9 * Ci;
+    g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.ktot = 9 * Ci; g.target = target;
     w3_tiles(g, stride);
     static const bool taps9 = getenv("CN_WGRAD3X3_WIDE_TAPS3") == nullptr;
     if (stride == 2) {
@@ -356,6 +357,7 @@ struct DcnWgradGeom {
     int N, H, W, Ci, x_ld, Co, dy_ld, om_ld, ktot;
     int tiles_h, tiles_w, ci_tiles;
     int tiles_per_block;
+    int target;          // workgroups wanted over the whole launch (cn_hooks.wgrad_blocks)
 };
 
 template <int BMW, int BNW, int TAPS>
@@ -512,7 +514,7 @@ static void launch_dw(DcnWgradGeom& g, hipStream_t st) {
     g.ci_tiles = cdiv(g.Ci, BNW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     const int par = co_tiles * g.ci_tiles * (TAPS == 9 ? 1 : 3);
-    int64_t want = (cn_wgrad_target_blocks() + par - 1) / par;
+    int64_t want = (g.target + par - 1) / par;
     if (want > ntiles) want = ntiles;
     if (want < 1) want = 1;
     g.tiles_per_block = (int)((ntiles + want - 1) / want);
@@ -527,19 +529,21 @@ static void launch_dw(DcnWgradGeom& g, hipStream_t st) {
 bool dcn_wgrad_bm_launch(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
                          int om_ld, int target_blocks, hipStream_t st);
 
-extern "C" int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
-                            int Co, int dy_ld, int om_ld, int dtype, void* stream) {
+extern "C" int cn_dcn_wgrad_h(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
+                              int Co, int dy_ld, int om_ld, int dtype, cn_hooks* hooks, void* stream) {
     CN_CHECK_ARG(x && om && dy && dwp && N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0, "cn_dcn_wgrad: bad args");
     if (dtype != CN_BF16) CN_UNSUPPORTED("cn_dcn_wgrad: bf16 only (fp32 parity mode goes through cn_dcn_im2col + cn_conv2d_wgrad)");
     if (Ci % 8 != 0 || x_ld % 8 != 0 || dy_ld % 8 != 0) CN_UNSUPPORTED("cn_dcn_wgrad: channel counts must be multiples of 8");
     static const int env_blocks = getenv("CN_DCN_WGRAD_BLOCKS") ? atoi(getenv("CN_DCN_WGRAD_BLOCKS")) : 0;      // A/B: this family's own grid
-    if (dcn_wgrad_bm_launch(x, om, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, om_ld, env_blocks > 0 ? env_blocks : cn_wgrad_target_blocks(), (hipStream_t)stream)) {
+    const int target = env_blocks > 0 ? env_blocks : cn_wgrad_target(hooks);
+    if (dcn_wgrad_bm_launch(x, om, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, om_ld, target, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_wgrad(bm)");
         return CN_OK;
     }
     DcnWgradGeom g;
     g.x = (const bf16_t*)x; g.dy = (const bf16_t*)dy; g.om = om; g.dwp = dwp;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld; g.om_ld = om_ld; g.ktot = 9 * Ci;
+    g.target = cn_wgrad_target(hooks);
     g.tiles_h = cdiv(H, W3_TH); g.tiles_w = cdiv(W, W3_TW);
     // Co <= 64: all nine taps per workgroup (dY tile read once).  CN_DCN_WGRAD_TAPS3 = three taps per workgroup (blockIdx.z =
     // kernel row; 48 instead of 144 accumulator registers, three workgroups per CU): 12-28 % faster in isolation (545 -> 480 us on
@@ -551,4 +555,8 @@ extern "C" int cn_dcn_wgrad(const void* x, const float* om, const void* dy, floa
     else launch_dw<64, 64, 9>(g, (hipStream_t)stream);
     CN_LAUNCH_CHECK("cn_dcn_wgrad");
     return CN_OK;
+}
+extern "C" int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
+                            int Co, int dy_ld, int om_ld, int dtype, void* stream) {
+    return cn_dcn_wgrad_h(x, om, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, om_ld, dtype, nullptr, stream);
 }

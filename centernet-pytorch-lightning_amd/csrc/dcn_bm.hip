@@ -39,7 +39,7 @@ extern "C" int bm_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, H
 struct BmGeom {
     const bf16_t* x; const float* om; const bf16_t* wp; const float* bias; bf16_t* y;
     int N, H, W, x_ld, y_ld, om_ld, ktot, Co, relu;
-    float* bn_part; int bn_slots;        // BatchNorm statistics sink (cn_bn_stats_arm), nullable
+    float* bn_part; int bn_slots;        // BatchNorm statistics sink (cn_hooks.bn_part), nullable
 };
 
 typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
@@ -384,7 +384,7 @@ bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld) {
 
 // returns false when the shape is not handled here (caller falls back to the gather / LDS-tile kernels)
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st) {
+                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st) {
     if (!dcn_fwd_bm_shape_ok(Ci, x_ld, Co, y_ld, om_ld) || bias == nullptr || ((uintptr_t)om & 15) || ktot != 9 * 64 || N > 65535) return false;
     if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) return false;
     if ((uintptr_t)bias & 15) return false;
@@ -392,7 +392,7 @@ bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const flo
     g.x = (const bf16_t*)x; g.om = om; g.wp = (const bf16_t*)wp; g.bias = bias; g.y = (bf16_t*)y;
     g.N = N; g.H = H; g.W = W; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.Co = Co; g.relu = relu;
     g.bn_part = bn_part; g.bn_slots = bn_slots;
-    if (bn_part) bn_sink_mark_taken();
+    if (bn_part) mark_taken(bn_taken);
     const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N);
     if (Co == 64) {
         const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 64 * 16) + 512 + 4 * 32 * 29 * 4;

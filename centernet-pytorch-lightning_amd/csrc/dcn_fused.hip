@@ -439,7 +439,7 @@ void dcn_fwd_launch(const ConvGeom& g_, int dtype, hipStream_t st) {
     const bool fits = g.Ci % 64 == 0 || (g.Ci % 32 == 0 && bn == 32);
     g.epi_tile = (dtype == CN_BF16 && !no_tile && fits && conv_epi_tile_ok(g, dtype)) ? 1 : 0;
     if (g.bn_part) {
-        if (g.epi_tile) bn_sink_mark_taken(); else g.bn_part = nullptr;
+        if (g.epi_tile) mark_taken(g.bn_taken); else g.bn_part = nullptr;
     }
     if (dtype == CN_BF16) {
         if (g.Ci % 64 == 0) { if (bn == 128) launch_fwd<bf16_t, 128, 64>(g, st); else if (bn == 64) launch_fwd<bf16_t, 64, 64>(g, st); else launch_fwd<bf16_t, 32, 64>(g, st); }

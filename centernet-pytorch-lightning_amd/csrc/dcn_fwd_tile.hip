@@ -26,7 +26,7 @@
 struct FwdTileGeom {
     const bf16_t* x; const bf16_t* w; const float* om; const float* bias; bf16_t* y;
     int N, H, W, Ci, Co, x_ld, y_ld, om_ld, ktot, relu;
-    float* bn_part; int bn_slots;     // BatchNorm statistics sink (cn_bn_stats_arm), nullable: sum / sum of squares of the stored values
+    float* bn_part; int bn_slots;     // BatchNorm statistics sink (cn_hooks.bn_part), nullable: sum / sum of squares of the stored values
 };
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -287,14 +287,14 @@ bool dcn_fwd_tile_shape_ok(int Ci, int x_ld, int Co, int y_ld) {
 }
 
 bool dcn_fwd_tile_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                         int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st) {
+                         int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st) {
     if (!dcn_fwd_tile_shape_ok(Ci, x_ld, Co, y_ld) || relu > 1) return false;
     FwdTileGeom g;
     g.x = (const bf16_t*)x; g.w = (const bf16_t*)wp; g.om = om; g.bias = bias; g.y = (bf16_t*)y;
     g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.Co = Co; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.relu = relu;
     static const bool no_stats = getenv("CN_DISABLE_DCN_TILE_STATS") != nullptr;
     g.bn_part = (bn_slots > 0 && !no_stats) ? bn_part : nullptr; g.bn_slots = bn_slots;
-    if (g.bn_part) bn_sink_mark_taken();            // the LDS-staged epilogue has the statistics hook
+    if (g.bn_part) mark_taken(bn_taken);            // the LDS-staged epilogue has the statistics hook
     const int bn = (Co % 128 == 0) ? 128 : 64;
     const int nco = Co / bn;
     const int ntiles = ((H + FT_TH - 1) / FT_TH) * ((W + FT_TW - 1) / FT_TW) * N;

@@ -465,7 +465,7 @@ static int gs_grid(int ntiles) {
 
 // returns false when the shape is not handled here (caller falls back to the blend-matrix / gather kernels)
 bool dcn_fwd_gs_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, hipStream_t st) {
+                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st) {
     if (!dcn_fwd_gs_shape_ok(Ci, x_ld, Co, y_ld, om_ld) || bias == nullptr || ktot != 9 * 64) return false;
     if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)om | (uintptr_t)bias) & 15) return false;
     if (H > 32767 || W > 32767 || (int64_t)H * W * 128 > 0x7fffffff) return false;
@@ -478,7 +478,7 @@ bool dcn_fwd_gs_launch(const void* x, const float* om, const void* wp, const flo
     if (nt > 0x7fffffff) return false;
     g.ntiles = (int)nt;
     if (bn_part) {
-        bn_sink_mark_taken();
+        mark_taken(bn_taken);
         hipLaunchKernelGGL(dcn_fwd_gs_kernel<true>, dim3(gs_grid(g.ntiles)), dim3(GQ_NT), GQ_SMEM, st, g);
     } else {
         hipLaunchKernelGGL(dcn_fwd_gs_kernel<false>, dim3(gs_grid(g.ntiles)), dim3(GQ_NT), GQ_SMEM, st, g);

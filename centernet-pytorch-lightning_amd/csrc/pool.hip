@@ -574,9 +574,9 @@ extern "C" int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw, 
 
 // the x2 layers (k = 4, stride 2, pad 1, OH = 2 H, OW = 2 W, bf16, C in {64, 128, 256} or a multiple of 512) through the row-walking
 // kernel + slab reduction; ws: cn_dwdeconv_wgrad_ws_bytes(N, OH, C) bytes of scratch.  CN_EUNSUPPORTED for any other shape.
-static int dw_rows_grid(int N, int OH, int C, int* cvw_out) {
+static int dw_rows_grid(int N, int OH, int C, int* cvw_out, int target) {
     const int CV = C / 8, cvw = CV >= 64 ? 64 : CV, tpw = 64 / cvw;
-    int gx = cn_wgrad_target_blocks() / (CV / cvw);
+    int gx = target / (CV / cvw);
     const int need = (N * OH + 4 * tpw - 1) / (4 * tpw);
     if (gx > need) gx = need;
     if (gx > 512) gx = 512;
@@ -593,13 +593,13 @@ extern "C" size_t cn_dwdeconv_wgrad_ws_bytes(int N, int OH, int C) {
     if (C <= 0 || (C & 63)) return 0;
     return (size_t)512 * 16 * C * sizeof(float);            // the grid is capped at 512 row blocks
 }
-extern "C" int cn_dwdeconv_bwd_weight_rows(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
-                                           int stride, int pad, int OH, int OW, int dtype, void* stream) {
+extern "C" int cn_dwdeconv_bwd_weight_rows_h(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
+                                             int stride, int pad, int OH, int OW, int dtype, cn_hooks* hooks, void* stream) {
     CN_CHECK_ARG(x && dy && dw && ws && N > 0 && H > 0 && W > 0, "cn_dwdeconv_bwd_weight_rows: bad args");
     if (!dw_rows_ok(C, k, stride, pad, H, W, OH, OW, dtype) || (int64_t)N * OH >= (1ll << 30))
         CN_UNSUPPORTED("cn_dwdeconv_bwd_weight_rows: bf16 k=4 s=2 p=1 layers with 64/128/256/512n channels only");
     int cvw;
-    const int gx = dw_rows_grid(N, OH, C, &cvw);
+    const int gx = dw_rows_grid(N, OH, C, &cvw, cn_wgrad_target(hooks));
     const int CV = C / 8, ntasks = N * OH;
     if (ws_bytes < (size_t)gx * 16 * C * sizeof(float)) { cn_set_error("cn_dwdeconv_bwd_weight_rows: workspace too small"); return CN_EWORKSPACE; }
     dim3 grid(gx, CV / cvw);
@@ -613,6 +613,10 @@ extern "C" int cn_dwdeconv_bwd_weight_rows(const void* x, const void* dy, float*
     hipLaunchKernelGGL(dwdeconv_wgrad_reduce_kernel, dim3((C * 16 + 63) / 64), dim3(256), 0, st, wsf, dw, C, cvw * 8, gx);
     CN_LAUNCH_CHECK("cn_dwdeconv_bwd_weight_rows");
     return CN_OK;
+}
+extern "C" int cn_dwdeconv_bwd_weight_rows(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
+                                           int stride, int pad, int OH, int OW, int dtype, void* stream) {
+    return cn_dwdeconv_bwd_weight_rows_h(x, dy, dw, ws, ws_bytes, N, H, W, C, k, stride, pad, OH, OW, dtype, nullptr, stream);
 }
 
 extern "C" int cn_upsample2x_add(const void* a, const void* low, void* y, int N, int H, int W, int C, int dtype, void* stream) {

@@ -188,17 +188,17 @@ static bool launch_small_wgrad(const void* x, bool x_nchw, const T* dy, float* d
 
 // used by cn_conv2d_wgrad for Ci <= 16 (packed output layout dwp[co][tap*Ci + ci])
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                           int stride, int OH, int OW, hipStream_t st, const float* pre_ss, int pre_relu);
+                           int stride, int OH, int OW, hipStream_t st, const float* pre_ss, int pre_relu, int target);
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
-                           int OH, int OW, hipStream_t st, const void* bn_x, const float* bn_coef, int bn_relu);
+                           int OH, int OW, hipStream_t st, const void* bn_x, const float* bn_coef, int bn_relu, int target);
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
-                      int stride, int OH, int OW, float* bn_part, int bn_slots, hipStream_t st);
+                      int stride, int OH, int OW, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st);
 
 bool small_wgrad_packed(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co,
-                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st, const float* pre_ss, int pre_relu) {
+                        int dy_ld, int KH, int KW, int stride, int pad, int dtype, hipStream_t st, const float* pre_ss, int pre_relu, int target) {
     if (Ci > 16) return false;
     if (dtype == CN_BF16 && KH == 3 && KW == 3 && pad == 1 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
-        wgrad_c16_nhwc_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, stride, OH, OW, st, pre_ss, pre_relu))
+        wgrad_c16_nhwc_launch(x, dy, dwp, N, H, W, Ci, x_ld, Co, dy_ld, stride, OH, OW, st, pre_ss, pre_relu, target))
         return true;
     if (pre_ss) return false;                    // only the MFMA kernel above has the pre-affine hook
     if (dtype == CN_F32)
@@ -217,15 +217,16 @@ static int stem_check(int Ci, int KH, int KW, int stride) {
     return CN_OK;
 }
 
-extern "C" int cn_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H,
-                                int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream) {
-    const BnSink sink = bn_sink_take();          // BatchNorm statistics sink armed for this launch (cn_bn_stats_arm); disarmed first
+extern "C" int cn_stem_conv_fwd_h(const float* x, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H,
+                                  int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, cn_hooks* hooks,
+                                  void* stream) {
+    const BnSink sink = hooks_sink(hooks);       // BatchNorm statistics sink of this call (cn_hooks.bn_part)
     CN_CHECK_ARG(x && w && y && N > 0 && Co > 0, "cn_stem_conv_fwd: bad args");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
     const bool sink_ok = sink.part && dtype == CN_BF16 && sink.C == Co;
     if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H + 6 - 7) / stride + 1 && OW == (W + 6 - 7) / stride + 1 &&
-        stem7_fwd_launch(x, w, scale, bias, relu, y, N, Ci, H, W, Co, stride, OH, OW, sink_ok ? sink.part : nullptr, sink.slots, (hipStream_t)stream)) {
+        stem7_fwd_launch(x, w, scale, bias, relu, y, N, Ci, H, W, Co, stride, OH, OW, sink_ok ? sink.part : nullptr, sink.slots, hooks ? &hooks->bn_taken : nullptr, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_stem_conv_fwd(mfma)");
         return CN_OK;
     }
@@ -238,15 +239,19 @@ extern "C" int cn_stem_conv_fwd(const float* x, const float* w, const float* sca
     CN_LAUNCH_CHECK("cn_stem_conv_fwd");
     return CN_OK;
 }
+extern "C" int cn_stem_conv_fwd(const float* x, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H,
+                                int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream) {
+    return cn_stem_conv_fwd_h(x, w, scale, bias, y, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, relu, dtype, nullptr, stream);
+}
 
-extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int KH,
-                                  int KW, int stride, int pad, int OH, int OW, int dtype, void* stream) {
+extern "C" int cn_stem_conv_wgrad_h(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int KH,
+                                    int KW, int stride, int pad, int OH, int OW, int dtype, cn_hooks* hooks, void* stream) {
     CN_CHECK_ARG(x && dy && dw && N > 0 && Co > 0, "cn_stem_conv_wgrad: bad args");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
     bool ok;
     if (dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
-        wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream, nullptr, nullptr, 0))
+        wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream, nullptr, nullptr, 0, cn_wgrad_target(hooks)))
         ok = true;
     else if (dtype == CN_F32)
         ok = launch_small_wgrad<float>(x, true, (const float*)dy, dw, N, Ci, 0, H, W, Co, Co, KH, KW, stride, pad, OH, OW,
@@ -260,21 +265,30 @@ extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int
     CN_LAUNCH_CHECK("cn_stem_conv_wgrad");
     return CN_OK;
 }
+extern "C" int cn_stem_conv_wgrad(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int KH,
+                                  int KW, int stride, int pad, int OH, int OW, int dtype, void* stream) {
+    return cn_stem_conv_wgrad_h(x, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, dtype, nullptr, stream);
+}
 
 // cn_stem_conv_wgrad THROUGH the training-mode BatchNorm (+ ReLU) that follows the stem (pose_dla_dcn.py:283-287 base_layer): dy is
 // the gradient w.r.t. the BN OUTPUT, y_raw the stem's own (raw) output, coef = fp32 [5][Co] from cn_bn_bwd_coef_sink.  The kernel
 // forms the BN input gradient on load — g = relu ? (fma(y_raw, sc, sh) > 0 ? dy : 0) : dy, dx = fma(ca, g, fma(cp, y_raw, cq)), rounded
 // to bf16 like the tensor cn_bn_train_bwd_sink would have stored — so that tensor is never written or read.  bf16, 7x7 / pad 3, Ci <= 3,
 // Co a multiple of 16 only (CN_EUNSUPPORTED otherwise: the caller runs cn_bn_train_bwd_sink + cn_stem_conv_wgrad).
-extern "C" int cn_stem_conv_wgrad_bn(const float* x, const void* dy, const void* y_raw, const float* coef, float* dw, int N, int Ci, int H,
-                                     int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream) {
+extern "C" int cn_stem_conv_wgrad_bn_h(const float* x, const void* dy, const void* y_raw, const float* coef, float* dw, int N, int Ci,
+                                       int H, int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype,
+                                       cn_hooks* hooks, void* stream) {
     CN_CHECK_ARG(x && dy && y_raw && coef && dw && N > 0 && Co > 0, "cn_stem_conv_wgrad_bn: bad args");
     CN_CHECK_ARG((((uintptr_t)dy | (uintptr_t)y_raw) & 15) == 0, "cn_stem_conv_wgrad_bn: dy / y_raw must be 16-byte aligned");
     int rc = stem_check(Ci, KH, KW, stride);
     if (rc) return rc;
     if (!(dtype == CN_BF16 && KH == 7 && KW == 7 && pad == 3 && OH == (H - 1) / stride + 1 && OW == (W - 1) / stride + 1 &&
-          wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream, y_raw, coef, relu)))
+          wgrad_c16_stem_launch(x, dy, dw, N, Ci, H, W, Co, Co, stride, OH, OW, (hipStream_t)stream, y_raw, coef, relu, cn_wgrad_target(hooks))))
         CN_UNSUPPORTED("cn_stem_conv_wgrad_bn: bf16, 7x7 / pad 3, Ci <= 3, Co a multiple of 16");
     CN_LAUNCH_CHECK("cn_stem_conv_wgrad_bn");
     return CN_OK;
+}
+extern "C" int cn_stem_conv_wgrad_bn(const float* x, const void* dy, const void* y_raw, const float* coef, float* dw, int N, int Ci, int H,
+                                     int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream) {
+    return cn_stem_conv_wgrad_bn_h(x, dy, y_raw, coef, dw, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, relu, dtype, nullptr, stream);
 }

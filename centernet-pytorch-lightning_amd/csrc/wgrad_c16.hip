@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 #define C16_TW 16
 
 struct WgC16Geom {
+    int target;               // workgroup budget of this call (cn_hooks.wgrad_blocks)
     const void* x;
     const bf16_t* dy;
     float* dw;
@@ -33,7 +34,7 @@ struct WgC16Geom {
     // output; the kernel forms the BN input gradient on load: g = relu ? (fma(x, sc, sh) > 0 ? dy : 0) : dy, dx = fma(ca, g, fma(cp, x, cq))
     // (bn_bwd_apply_kernel's arithmetic), bn_coef = fp32 [5][bn_C]: ca | cp | cq | sc | sh (cn_bn_bwd_coef_sink)
     const bf16_t* bn_x; const float* bn_coef; int bn_C, bn_relu;
-    const float* pre_ss; int pre_relu;   // input pre-affine (cn_conv_pre_affine_arm): x' = bf16(fma(x, ss[c], ss[16 + c])), relu: max(., 0); padding stays 0
+    const float* pre_ss; int pre_relu;   // input pre-affine (cn_hooks.pre_ss): x' = bf16(fma(x, ss[c], ss[16 + c])), relu: max(., 0); padding stays 0
 };
 
 // 8 consecutive K (pixel) values of 16 columns out of a pixel-major LDS tile: rows are LDS element offsets row_of(k)
@@ -277,7 +278,7 @@ static void launch_c16(WgC16Geom& g, hipStream_t st) {
     g.tiles_h = cdiv(g.OH, C16_TH); g.tiles_w = cdiv(g.OW, C16_TW);
     const int64_t ntiles = (int64_t)g.N * g.tiles_h * g.tiles_w;
     int64_t blocks = (ntiles + 3) / 4;
-    const int cap = cn_wgrad_target_blocks() / 3 < 128 ? 128 : cn_wgrad_target_blocks() / 3;   // default 512
+    const int cap = g.target / 3 < 128 ? 128 : g.target / 3;   // default 512
     if (blocks > cap) blocks = cap;
     g.iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
     hipLaunchKernelGGL((wgrad_c16_kernel<XPIX, KH, KW, S, AFF, BNB, VEC4>), dim3((unsigned)blocks, (unsigned)cdiv(g.Co, 16)), dim3(256), 0, st, g);
@@ -285,13 +286,13 @@ static void launch_c16(WgC16Geom& g, hipStream_t st) {
 
 // bf16 NHWC x, 3x3 / stride 1|2 / pad 1, Ci == 16, Co in 16-channel blocks -> packed dwp[co][tap*16 + ci]
 bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld, int Co, int dy_ld,
-                           int stride, int OH, int OW, hipStream_t st, const float* pre_ss, int pre_relu) {
+                           int stride, int OH, int OW, hipStream_t st, const float* pre_ss, int pre_relu, int target) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
     if (disabled || Ci != 16 || (x_ld & 7) || (dy_ld & 7) || dy_ld < ((Co + 15) & ~15) || (stride != 1 && stride != 2)) return false;
     WgC16Geom g;
     g.x = x; g.dy = (const bf16_t*)dy; g.dw = dwp; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = x_ld; g.Co = Co; g.dy_ld = dy_ld;
     g.OH = OH; g.OW = OW;
-    g.os_co = 9 * Ci; g.os_ci = 1; g.os_tap = Ci;
+    g.os_co = 9 * Ci; g.os_ci = 1; g.os_tap = Ci; g.target = target;
     g.pre_ss = pre_ss; g.pre_relu = pre_relu;
     g.bn_x = nullptr; g.bn_coef = nullptr; g.bn_C = 0; g.bn_relu = 0;
     if (pre_ss) { if (stride == 1) launch_c16<16, 3, 3, 1, true>(g, st); else launch_c16<16, 3, 3, 2, true>(g, st); }
@@ -302,13 +303,13 @@ bool wgrad_c16_nhwc_launch(const void* x, const void* dy, float* dwp, int N, int
 // fp32 NCHW x (the image), 7x7 / stride 1|2 / pad 3, Ci <= 3, Co % 16 == 0 -> dw[co][ci][kh][kw]
 // bn_x != nullptr: dy is the gradient w.r.t. the output of the BatchNorm (+ ReLU) behind the stem, see WgC16Geom
 bool wgrad_c16_stem_launch(const float* x, const void* dy, float* dw, int N, int Ci, int H, int W, int Co, int dy_ld, int stride,
-                           int OH, int OW, hipStream_t st, const void* bn_x, const float* bn_coef, int bn_relu) {
+                           int OH, int OW, hipStream_t st, const void* bn_x, const float* bn_coef, int bn_relu, int target) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
     if (disabled || Ci > 3 || (Co & 15) || (dy_ld & 7) || dy_ld < Co || (stride != 1 && stride != 2)) return false;
     WgC16Geom g;
     g.x = x; g.dy = (const bf16_t*)dy; g.dw = dw; g.N = N; g.H = H; g.W = W; g.Ci = Ci; g.x_ld = 0; g.Co = Co; g.dy_ld = dy_ld;
     g.OH = OH; g.OW = OW;
-    g.os_co = Ci * 49; g.os_ci = 49; g.os_tap = 1;
+    g.os_co = Ci * 49; g.os_ci = 49; g.os_tap = 1; g.target = target;
     g.pre_ss = nullptr; g.pre_relu = 0;
     g.bn_x = (const bf16_t*)bn_x; g.bn_coef = bn_coef; g.bn_C = Co; g.bn_relu = bn_relu;
     static const bool no_vec4 = getenv("CN_DISABLE_STEM_WGRAD_VEC4") != nullptr;
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void stem7_rows_kernel(const float* __restr
 // bf16 output, 7x7 / stride 1|2 / pad 3, Ci <= 3, Co a multiple of 4; more than 64 output channels (Hourglass: 128) run as
 // 64-channel chunks over the same image (the 3-channel fp32 input is small next to the output).
 bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const float* bias, int relu, void* y, int N, int Ci, int H, int W, int Co,
-                      int stride, int OH, int OW, float* bn_part, int bn_slots, hipStream_t st) {
+                      int stride, int OH, int OW, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st) {
     static const bool disabled = getenv("CN_DISABLE_WGRAD_C16") != nullptr;
     if (disabled || Ci > 3 || (Co & 3) || (stride != 1 && stride != 2)) return false;
     const int tiles_h = cdiv(OH, C16_TH), tiles_w = cdiv(OW, C16_TW);
@@ -611,7 +612,7 @@ bool stem7_fwd_launch(const float* x, const float* w, const float* scale, const 
     if (blocks > 2048) blocks = 2048;
     const int iters = (int)((ntiles + blocks * 4 - 1) / (blocks * 4));
     constexpr int CHUNK = 16 * ST7_MAXCB;
-    if (bn_part && Co <= 16 && (Co & 3) == 0) bn_sink_mark_taken(); else bn_part = nullptr;     // statistics hook: one channel block only
+    if (bn_part && Co <= 16 && (Co & 3) == 0) mark_taken(bn_taken); else bn_part = nullptr;     // statistics hook: one channel block only
     static const bool no_rows = getenv("CN_DISABLE_STEM_ROWS") != nullptr;
     if (!no_rows && stride == 1 && Co <= 16 && OH == H && OW == W && (W & 3) == 0 && (((uintptr_t)x) & 15) == 0) {      // row-walking kernel (DLA base_layer)
         const int R = OH >= 256 ? 32 : 16;

@@ -475,7 +475,7 @@ class TrainStep:
             loss = self.model.training_step(batch, batch_idx)
         except BaseException:
             # a producer may have filled a BatchNorm statistics sink that its BN never got to consume (the sinks are persistent and
-            # must be all-zero when armed): clear them, or the next training-mode BN of that width normalises with stale sums
+            # must be all-zero when handed out): clear them, or the next training-mode BN of that width normalises with stale sums
             ops.BnStats.reset()
             PackArena.current, self._packs.recording = None, False
             ops.FarFlags.end()

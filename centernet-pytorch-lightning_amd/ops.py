@@ -8,7 +8,7 @@ import torch
 from torch.autograd import Function
 
 from . import _hip
-from ._hip import call, dtype_code
+from ._hip import Hooks, call, dtype_code
 
 import os as _os
 
@@ -117,15 +117,15 @@ def _far_buffer(shape, device):
 
 
 class BnStats:
-    """Training-mode conv + BN: the producing kernel accumulates the batch statistics of its output in its epilogue (sink protocol of
-    cn_bn_stats_arm).  `launch` arms a sink right before ONE C-ABI launch and remembers whether the kernel took it; the op wrappers
-    pick that up (`pop`) and tag the output tensor for `batch_norm_act`.
+    """Training-mode conv + BN: the producing kernel accumulates the batch statistics of its output in its epilogue (the `bn_part`
+    fields of cn_hooks).  `launch` hands a sink to ONE C-ABI call through its hooks argument and reads back whether the kernel
+    took it (`bn_taken`); the op wrappers pick that up (`pop`) and tag the output tensor for `batch_norm_act`.
 
     Sinks (fp32 [slots][2][C], persistent, all-zero when handed out) are reduced by the kernel that CONSUMES them
     (cn_bn_train_fwd_sink / cn_bn_train_bwd_sink: no finalize launch), and a kernel cannot clear what its own workgroups are still
     reading — so the sinks form a chain on the launch stream: a consumed sink is `retired`, and the NEXT sink-consuming launch
-    zeroes it on the way.  `acquire` hands out a sink of the right width that is known to be clean (never a retired or an armed
-    one); at any time exactly one sink per namespace is dirty between steps (the last one consumed), which a replayed hipGraph
+    zeroes it on the way.  `acquire` hands out a sink of the right width that is known to be clean (never a retired or a
+    handed-out one); at any time exactly one sink per namespace is dirty between steps (the last one consumed), which a replayed hipGraph
     reproduces, so host state and device state stay in step.  `ns` (set by a TrainStep) keeps the chains of different steps /
     graphs apart."""
     enabled = not _os.environ.get("CN_DISABLE_BN_EPILOGUE_STATS")
@@ -183,20 +183,19 @@ class BnStats:
         return clear
 
     @classmethod
-    def launch(cls, want, y, name, *args):
+    def launch(cls, want, y, name, *args, hooks=None):
+        """`hooks`: the call's other per-call extras (input pre-affine, backward-statistics sink), if any"""
         cls.last = None
         if not (want and cls.enabled and y.dtype == torch.bfloat16):
-            return call(name, *args)
+            return call(name, *args, hooks=hooks)
         part = cls.acquire("f", y.shape[-1], y.device)
-        if _hip.query("cn_bn_stats_arm", part.data_ptr(), part.shape[0], part.shape[2]) != 0:
-            cls.release(part)                # refused (width not a multiple of 8, ...): nothing is armed, BN reads x itself
-            return call(name, *args)
+        hooks = (hooks or Hooks()).set(bn_part=part, bn_slots=part.shape[0], bn_C=part.shape[2])
         try:
-            call(name, *args)
+            call(name, *args, hooks=hooks)
         except BaseException:
             cls.release(part)
             raise
-        if _hip.query("cn_bn_stats_taken"):
+        if hooks.bn_taken:                   # (0: the kernel this shape dispatched to has no hook, or the width is not a multiple of 8)
             cls.last = part
         else:
             cls.release(part)
@@ -221,7 +220,7 @@ class BnStats:
 
 
 class BnBwdSinks:
-    """Backward-statistics sinks filled by the kernel that PRODUCED a gradient tensor (cn_bn_bwd_stats_arm), kept next to that very
+    """Backward-statistics sinks filled by the kernel that PRODUCED a gradient tensor (the `bnb_part` fields of cn_hooks), kept next to that very
     tensor (same Python object, same version: the side-channel rule of SparseRows) until the BN backward that receives it picks the
     sink up.  What nobody picked up when the backward pass ends is zeroed and handed back."""
     enabled = not _os.environ.get("CN_DISABLE_BN_BWD_EPILOGUE_STATS")
@@ -485,12 +484,11 @@ class SideGrads:
         # kernels at two waves per SIMD, matrix-core DCN weight gradient): the side stream has slack, so the fewer CUs it occupies the
         # faster the critical chain runs — DLA-34 bs 64: 1 413 / 1 432 / 1 437 / 1 460 / 1 480 / 1 478 / 1 368 / 1 165 images/s with
         # 768 / 512 / 384 / 192 / 160 / 128 / 96 / 64 workgroups (below ~128 the side stream itself becomes the critical path)
-        cls.thin = int(_os.environ.get("CN_WGRAD_BLOCKS", (384 if fp32 else 160) if on else 1536))
-        if torch.cuda.is_available():        # (a CPU-only TrainStep — the gloo tests of the data-parallel path — has no kernels to shape)
-            call("cn_set_wgrad_parallelism", cls.thin)
+        cls.thin = cls.grid = int(_os.environ.get("CN_WGRAD_BLOCKS", (384 if fp32 else 160) if on else 1536))
         return on
 
     thin = 1536
+    grid = 1536           # cn_hooks.wgrad_blocks of the weight-gradient calls issued now (`wgrad_hooks`): `thin`, or the tail's wide grid
     fwd_order = 0         # convs seen in this step's forward pass (TrainStep resets it): the first few are the LAST of backward
     TAIL_LAYERS = int(_os.environ.get("CN_TAIL_LAYERS", 2))      # re-swept on the final tree: 3 -> 2: -0.1 ms (five interleaved pairs)
 
@@ -508,12 +506,21 @@ class SideGrads:
             return fn
 
         def wide():
-            call("cn_set_wgrad_parallelism", int(_os.environ.get("CN_TAIL_BLOCKS", 1536)))
+            cls.grid = int(_os.environ.get("CN_TAIL_BLOCKS", 1536))
             try:
                 fn()
             finally:
-                call("cn_set_wgrad_parallelism", cls.thin)
+                cls.grid = cls.thin
         return wide
+
+    @classmethod
+    def wgrad_hooks(cls, pre=None, Ci=0):
+        """cn_hooks of one weight-gradient call: the split-K grid of the moment (+ the input pre-affine of a deferred BN)"""
+        h = Hooks()
+        h.wgrad_blocks = cls.grid
+        if pre is not None:
+            h.set(pre_ss=pre[0], pre_C=Ci, pre_relu=int(pre[1]))
+        return h
 
     @classmethod
     def usable(cls, *params):
@@ -580,24 +587,19 @@ def conv_out(h, k, s, p):
 _SMALLK_WIDTHS = (64, 128, 256, 512, 1024, 2048)
 
 
-def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None, bn_stats=False, pre=None):
-    """pre = (ss fp32 [2][Ci], relu): x is the raw output of the previous conv; the kernel applies that layer's BN (+ ReLU) on load"""
+def _igemm(x, wp, bias, residual, Co, KH, KW, stride, pad, transposed, relu, OH, OW, out_dtype=None, bn_stats=False, pre=None, hooks=None):
+    """pre = (ss fp32 [2][Ci], relu): x is the raw output of the previous conv; the kernel applies that layer's BN (+ ReLU) on load
+    (a shape without that hook raises).  hooks: further per-call extras (the caller reads their `*_taken` fields afterwards)."""
     N, H, W, Ci = x.shape
     cp = rup(Co, 16)
     out_dtype = out_dtype or x.dtype
     y = torch.empty((N, OH, OW, cp), dtype=out_dtype, device=x.device)    # the kernels write the channel padding as zeros
     if pre is not None:
-        _arm_pre(pre, Ci)                                                 # taken by the launch below (unsupported shape: it raises)
+        hooks = (hooks or Hooks()).set(pre_ss=pre[0], pre_C=Ci, pre_relu=int(pre[1]))
     BnStats.launch(bn_stats, y, "cn_conv2d_fwd", x, wp, bias, residual, y, N, H, W, Ci, Ci, OH, OW, Co, cp,
                    residual.shape[-1] if residual is not None else 0, KH, KW, stride, pad, int(transposed), int(relu),
-                   dtype_code(x.dtype), dtype_code(out_dtype))
+                   dtype_code(x.dtype), dtype_code(out_dtype), hooks=hooks)
     return y
-
-
-def _arm_pre(pre, Ci):
-    """arm the input pre-affine for the NEXT cn_conv2d_fwd / cn_conv2d_wgrad of this thread (a shape without the hook then raises)"""
-    if _hip.query("cn_conv_pre_affine_arm", pre[0].data_ptr(), Ci, int(pre[1])) != 0:
-        raise RuntimeError("cn_conv_pre_affine_arm refused: " + _hip.lib().cn_last_error().decode())
 
 
 def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=None, pre=None):
@@ -607,9 +609,8 @@ def _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=None, pre=None):
     _, OH, OW, ld = dy.shape
     dwp = zeros((rup(Co, 32), KH * KW * Ci), torch.float32, x.device)
     db = db_into if db_into is not None else (zeros((Co,), torch.float32, x.device) if want_bias else None)
-    if pre is not None:
-        _arm_pre(pre, Ci)
-    call("cn_conv2d_wgrad", x, dy, dwp, db, N, H, W, Ci, Ci, OH, OW, Co, ld, KH, KW, stride, pad, dtype_code(x.dtype))
+    call("cn_conv2d_wgrad", x, dy, dwp, db, N, H, W, Ci, Ci, OH, OW, Co, ld, KH, KW, stride, pad, dtype_code(x.dtype),
+         hooks=SideGrads.wgrad_hooks(pre, Ci))
     return dwp, db
 
 
@@ -621,13 +622,14 @@ def _wgrad_param(x, dy, Co, Ci, KH, KW, stride, pad, into=None, want_bias=False,
     _, OH, OW, ld = dy.shape
     dt = dtype_code(x.dtype)
     if Cx == Ci and x.dtype == torch.bfloat16 and pre is None:
-        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes", N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW, stride, pad, dt))
+        hooks = SideGrads.wgrad_hooks()        # (the slab count, hence the scratch size, follows the grid)
+        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes_h", N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW, stride, pad, dt, hooks.wgrad_blocks))
         if n:
             ws = _hip.workspace(n, x.device, "wgrad_slabs")
             dw = into if into is not None else torch.empty((Co, Ci, KH, KW), dtype=torch.float32, device=x.device)
             db = db_into if db_into is not None else (zeros((Co,), torch.float32, x.device) if want_bias else None)
             call("cn_conv2d_wgrad_direct", x, dy, dw, db, int(into is not None), ws, n, N, H, W, Ci, Cx, OH, OW, Co, ld, KH, KW,
-                 stride, pad, dt)
+                 stride, pad, dt, hooks=hooks)
             return dw, db
     dwp, db = _wgrad(x, dy, Co, KH, KW, stride, pad, want_bias, db_into=db_into, pre=pre)
     if into is not None:
@@ -724,22 +726,20 @@ def _conv2d_bwd(x, weight, bias_ref, dy, stride, pad, has_bias, mask_dx, cell, o
                 # x is shared: what its other consumers sent rides in the epilogue's residual slot (the stride-2 shapes on the
                 # direct-from-global data-gradient kernel keep it: that kernel has no residual input)
                 skip = cell.take(like=x)
-            sink = None
+            sink = hooks = None
             if (pre is not None and len(pre) > 2 and skip is None and BnBwdSinks.enabled and BnStats.fused and x.dtype == torch.bfloat16
                     and Cx == pre[2].shape[1]):
                 # x is a raw conv output behind a deferred BN: ask the data-gradient kernel for that BN's backward statistics
                 sink = BnStats.acquire("b", Cx, x.device)
-                if _hip.query("cn_bn_bwd_stats_arm", sink.data_ptr(), sink.shape[0], Cx, x.data_ptr(), pre[2].data_ptr(), int(pre[1])) != 0:
-                    BnStats.release(sink)
-                    sink = None
+                hooks = Hooks().set(bnb_part=sink, bnb_slots=sink.shape[0], bnb_C=Cx, bnb_x=x, bnb_stats=pre[2], bnb_relu=int(pre[1]))
             try:
-                dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W)
+                dx = _igemm(dy, wpd, None, skip, Ci, KH, KW, stride, pad, True, False, H, W, hooks=hooks)
             except BaseException:
                 if sink is not None:
                     BnStats.release(sink)
                 raise
             if sink is not None:
-                if _hip.query("cn_bn_bwd_stats_taken"):
+                if hooks.bnb_taken:
                     BnBwdSinks.note(dx, sink)
                 else:
                     BnStats.release(sink)
@@ -909,12 +909,13 @@ class StemConvFn(Function):
         if SideGrads.usable(weight):
             def side_work(img=img, dy=dy):  # the kernel accumulates with atomics: deposit straight into weight.grad
                 call("cn_stem_conv_wgrad", img, dy, weight.grad, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2],
-                     dtype_code(dy.dtype))
+                     dtype_code(dy.dtype), hooks=SideGrads.wgrad_hooks())
                 GradReady.note(weight)
             SideGrads.submit(SideGrads.wide_if_tail(side_work, ctx.order), img, dy, claims=(weight,))
             return None, None, None, None, None, None
         dw = zeros_like(weight, torch.float32)
-        call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype))
+        call("cn_stem_conv_wgrad", img, dy, dw, N, Ci, H, W, Co, KH, KW, stride, pad, dy.shape[1], dy.shape[2], dtype_code(dy.dtype),
+             hooks=SideGrads.wgrad_hooks())
         return None, dw, None, None, None, None
 
 
@@ -1095,7 +1096,8 @@ class StemBnDeferFn(Function):
             GradReady.note(gamma, beta)
 
         def wgrad(dw):
-            call("cn_stem_conv_wgrad_bn", img, dy, y, coef, dw, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, int(relu), dt)
+            call("cn_stem_conv_wgrad_bn", img, dy, y, coef, dw, N, Ci, H, W, Co, KH, KW, stride, pad, OH, OW, int(relu), dt,
+                 hooks=SideGrads.wgrad_hooks())
 
         if SideGrads.usable(weight):
             def side_work():
@@ -1405,7 +1407,7 @@ class DCNv2Fn(Function):
             """dW / db of the deformable conv: fused re-sampling kernel in bf16, im2col + GEMM in fp32 parity mode"""
             if x.dtype == torch.bfloat16 and not _DCN_UNFUSED:
                 dwp_ = zeros((rup(Co, 32), 9 * Ci), torch.float32, x.device)
-                call("cn_dcn_wgrad", x, om, dy, dwp_, N, H, W, Ci, Ci, Co, dy.shape[-1], om.shape[-1], dt)
+                call("cn_dcn_wgrad", x, om, dy, dwp_, N, H, W, Ci, Ci, Co, dy.shape[-1], om.shape[-1], dt, hooks=SideGrads.wgrad_hooks())
                 db_ = db_into if db_into is not None else (zeros((Co,), torch.float32, x.device) if want_bias else None)
                 if db_ is not None:
                     call("cn_colsum", dy, db_, N * H * W, Co, dy.shape[-1], dt)
@@ -1826,7 +1828,8 @@ def _dwdeconv_wgrad(x, dy, dw, N, H, W, C, k, stride, pad, OH, OW):
     n = _hip.query("cn_dwdeconv_wgrad_ws_bytes", N, OH, C)
     if n and x.dtype == torch.bfloat16:
         ws = _hip.workspace(n, x.device, "dwwgrad")
-        if _hip.try_call("cn_dwdeconv_bwd_weight_rows", x, dy, dw, ws, n, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype)):
+        if _hip.try_call("cn_dwdeconv_bwd_weight_rows", x, dy, dw, ws, n, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype),
+                         hooks=SideGrads.wgrad_hooks()):
             return
     call("cn_dwdeconv_bwd_weight", x, dy, dw, N, H, W, C, k, stride, pad, OH, OW, dtype_code(x.dtype))
 

@@ -79,6 +79,44 @@ int cn_unpack_wgrad(const float* dwp, float* dw, int A, int B, int KH, int KW, i
  * dw_ld the full row length (the per-source weight gradients of cn_conv1x1_cat_fwd) */
 int cn_unpack_wgrad_cols(const float* dwp, float* dw, int A, int B, int inner_pad, int dw_ld, int accumulate, void* stream);
 
+/* ---- per-call hooks --------------------------------------------------------------------------
+ * Optional extras of ONE call, handed over explicitly (the `_h` twin of an entry point takes `cn_hooks* hooks` in front of the
+ * stream; NULL or a zeroed struct = the plain entry point).  Nothing is remembered between calls: the library keeps no armed
+ * state (SURVEY 8b "Threading": no mutable globals except kernel handles and the thread-local error string).  The struct
+ * lives in HOST memory; `bn_taken` / `bnb_taken` are written by the call.
+ *   pre_ss / pre_C / pre_relu   input pre-affine (cn_conv2d_fwd_h, cn_conv2d_wgrad_h): x is the RAW output of the previous
+ *        convolution and the kernel uses x' = bf16(fma(x, pre_ss[c], pre_ss[C + c])) (pre_relu: max(., 0)) — the training-mode
+ *        BN (+ ReLU) of pose_dla_dcn.py:283-296 applied by the consumer, bit-identical to the tensor cn_bn_train_fwd_sink
+ *        would have stored, zero padding applied to x'.  pre_ss = fp32 [2][C] scale | shift in device memory
+ *        (cn_bn_finalize_sink writes it).  Only the 16-input-channel bf16 3x3 kernels have the hook; any other shape returns
+ *        CN_EUNSUPPORTED (no silent fallback on the raw tensor).
+ *   bn_part / bn_slots / bn_C -> bn_taken   BatchNorm statistics of the OUTPUT from the producer's epilogue (cn_conv2d_fwd_h,
+ *        cn_conv1x1_cat_fwd_h, cn_dcn_fwd_h, cn_stem_conv_fwd_h; pose_dla_dcn.py:55-68, 435-454, msra_resnet.py:29-58): when the
+ *        kernel the call dispatches to has the hook (bf16, y_ld == bn_C), every workgroup adds per-channel sum / sum of squares
+ *        of the values it stores (after rounding to bf16) to row (workgroup % bn_slots) of bn_part[bn_slots][2][bn_C] (fp32
+ *        atomics; all-zero on entry, bn_slots <= 1024: cn_bn_stats_slots()) and bn_taken = 1; otherwise bn_part is untouched and
+ *        bn_taken = 0 (the caller falls back to cn_bn_train_fwd, which reads x itself).
+ *   bnb_* -> bnb_taken   BN-BACKWARD statistics from the kernel that PRODUCES the gradient (cn_conv2d_fwd_h with transposed
+ *        != 0): its output y is the gradient w.r.t. the output of a training-mode BN (+ ReLU: bnb_relu) with input bnb_x (NHWC,
+ *        pitch bnb_C == y_ld) and saved statistics bnb_stats = fp32 [4][C] mean | invstd | scale | shift; a kernel with the hook
+ *        (the 16-channel bf16 data-gradient kernels) adds per channel sum g and sum g * xhat of the values it stores to
+ *        bnb_part[bnb_slots][2][bnb_C] (all-zero on entry) — what cn_bn_bwd_stats computes in a pass of its own — and
+ *        bnb_taken = 1; otherwise 0 and the sink is untouched.
+ *   wgrad_blocks   number of workgroups the split-K weight-gradient kernels of this call spread over (<= 0: the default, 1536
+ *        = ~6 per CU).  A host that runs them on a second stream beside the data-gradient chain lowers it (~160) so they stay in
+ *        the background.  The scratch size of cn_conv2d_wgrad_direct depends on it: ask cn_conv2d_wgrad_direct_bytes_h
+ *        with the same value (a launch whose grid needs more scratch than it was given returns CN_EWORKSPACE). */
+typedef struct cn_hooks {
+    const float* pre_ss; int32_t pre_C; int32_t pre_relu;
+    float* bn_part; int32_t bn_slots; int32_t bn_C;
+    float* bnb_part; int32_t bnb_slots; int32_t bnb_C; const void* bnb_x; const float* bnb_stats; int32_t bnb_relu;
+    int32_t bn_taken; int32_t bnb_taken;
+    int32_t wgrad_blocks;
+} cn_hooks;
+/* sizeof(cn_hooks) as this library was built: a binding that mirrors the struct (ctypes.Structure, cgo, JNI) checks its own size
+ * against it once at load time */
+size_t cn_hooks_size(void);
+
 /* Implicit-GEMM convolution, NHWC.  y[n,oh,ow,co] = act(bias[co] + res[..] + sum_{t,ci} xg * Wp[co][t*Ci+ci])
  *   transposed == 0: xg = x[n, oh*stride - pad + kh, ow*stride - pad + kw, ci]       (nn.Conv2d)
  *   transposed == 1: xg = x[n, (oh + pad - kh)/stride, (ow + pad - kw)/stride, ci]   (nn.ConvTranspose2d /
@@ -91,6 +129,9 @@ int cn_unpack_wgrad_cols(const float* dwp, float* dw, int A, int B, int inner_pa
 int cn_conv2d_fwd(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                   int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
                   int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype, void* stream);
+int cn_conv2d_fwd_h(const void* x, const void* wp, const float* bias, const void* residual, void* y,
+                    int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int y_ld, int res_ld,
+                    int KH, int KW, int stride, int pad, int transposed, int relu, int dtype, int out_dtype, cn_hooks* hooks, void* stream);
 /* 1x1 conv with a tiny contraction (K <= 4 real input channels; x pitch x_ld, weights packed with 16-wide rows like
  * cn_pack_weight): the data gradient of the 1- and 2-channel heads' last conv (heads.py:9-15, backwards).  relu = 2 masks the
  * result with residual > 0 (fused ReLU backward), relu = 0 with residual adds it.  bf16, y_ld == Co. */
@@ -105,6 +146,9 @@ int cn_conv2d_variant(int Ci, int Co, int KH, int KW, int stride, int pad, int d
 int cn_conv2d_wgrad(const void* x, const void* dy, float* dwp, float* db,
                     int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                     int KH, int KW, int stride, int pad, int dtype, void* stream);
+int cn_conv2d_wgrad_h(const void* x, const void* dy, float* dwp, float* db,
+                      int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                      int KH, int KW, int stride, int pad, int dtype, cn_hooks* hooks, void* stream);
 /* The same gradient straight into the PARAMETER layout dw[Co][Ci][KH][KW] (fp32, accumulate != 0 adds — e.g. into the flat
  * gradient buffer), for the shapes whose kernel has the slab form (bf16, 3x3 / stride 1 or 2 / pad 1, Ci > 16): every workgroup
  * stores its split-K partial as a private slab in `ws` and one reduction launch sums them in a fixed order — no fp32 atomics
@@ -116,10 +160,11 @@ size_t cn_conv2d_wgrad_direct_bytes(int N, int H, int W, int Ci, int x_ld, int O
 int cn_conv2d_wgrad_direct(const void* x, const void* dy, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
                            int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
                            int KH, int KW, int stride, int pad, int dtype, void* stream);
-
-/* Tunable: number of workgroups the split-K weight-gradient kernels spread over (default 1536 = ~6 per CU).  A host that
- * runs them on a second stream beside the data-gradient chain lowers it (~384) so they stay in the background. */
-int cn_set_wgrad_parallelism(int blocks);
+size_t cn_conv2d_wgrad_direct_bytes_h(int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld, int KH, int KW,
+                                      int stride, int pad, int dtype, int wgrad_blocks);
+int cn_conv2d_wgrad_direct_h(const void* x, const void* dy, float* dw, float* db, int accumulate, void* ws, size_t ws_bytes,
+                             int N, int H, int W, int Ci, int x_ld, int OH, int OW, int Co, int dy_ld,
+                             int KH, int KW, int stride, int pad, int dtype, cn_hooks* hooks, void* stream);
 /* bias gradient alone: db[c] += sum_p dy[p][c] (db accumulated into; dy_ld a vector multiple) */
 int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype, void* stream);
 
@@ -128,41 +173,31 @@ int cn_colsum(const void* dy, float* db, int64_t P, int Co, int dy_ld, int dtype
  * and relu fold an eval-mode BN + ReLU into the epilogue: y = act(fma(conv, scale, bias)). */
 int cn_stem_conv_fwd(const float* x_nchw, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H, int W, int Co,
                      int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream);
+int cn_stem_conv_fwd_h(const float* x_nchw, const float* w, const float* scale, const float* bias, void* y, int N, int Ci, int H, int W, int Co,
+                       int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, cn_hooks* hooks, void* stream);
 /* cn_stem_conv_wgrad through the training-mode BN (+ ReLU) behind the stem: dy = gradient w.r.t. the BN output, y_raw = the stem's raw
  * output, coef from cn_bn_bwd_coef_sink; the BN input gradient is formed on load and never stored (bf16, 7x7 / pad 3, Co % 16 == 0). */
 int cn_stem_conv_wgrad_bn(const float* x_nchw, const void* dy, const void* y_raw, const float* coef, float* dw, int N, int Ci, int H,
                           int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, void* stream);
 int cn_stem_conv_wgrad(const float* x_nchw, const void* dy, float* dw, int N, int Ci, int H, int W, int Co,
                        int KH, int KW, int stride, int pad, int OH, int OW, int dtype, void* stream);
+int cn_stem_conv_wgrad_bn_h(const float* x_nchw, const void* dy, const void* y_raw, const float* coef, float* dw, int N, int Ci, int H,
+                            int W, int Co, int KH, int KW, int stride, int pad, int OH, int OW, int relu, int dtype, cn_hooks* hooks, void* stream);
+int cn_stem_conv_wgrad_h(const float* x_nchw, const void* dy, float* dw, int N, int Ci, int H, int W, int Co,
+                         int KH, int KW, int stride, int pad, int OH, int OW, int dtype, cn_hooks* hooks, void* stream);
 
 /* ---- batch norm (nn.BatchNorm2d, momentum 0.1) + ReLU + residual add ---------------------- */
 size_t cn_bn_workspace_bytes(int64_t npix, int C);
 /* Training-mode conv + BN (pose_dla_dcn.py:55-68, 435-454; msra_resnet.py:29-58): the kernel that PRODUCES the BN input also
- * accumulates the batch statistics.  cn_bn_stats_arm(part, slots, C) arms the NEXT forward launch of the calling host thread
- * (cn_conv2d_fwd, cn_conv1x1_cat_fwd, cn_dcn_fwd, cn_stem_conv_fwd): when the kernel it dispatches to has the hook (bf16, y_ld == C), every
- * workgroup adds per-channel sum / sum of squares of the values it stores (after rounding to bf16) to row (workgroup % slots) of
- * part[slots][2][C] (fp32 atomics) and cn_bn_stats_taken() then returns 1; otherwise `part` is untouched and it returns 0 (the
- * caller falls back to cn_bn_train_fwd, which reads x itself).  `part` must be all-zero when armed (slots <= 1024, use
- * cn_bn_stats_slots()); cn_bn_train_fwd_stats = cn_bn_train_fwd without the statistics pass over x: finalize from `part`
- * (handed back all-zero) + the apply pass. */
-/* Input pre-affine (training-mode BN + ReLU of the PREVIOUS layer applied by the consumer, so the normalised activation is never
- * written: pose_dla_dcn.py:283-296 base_layer -> level0 -> level1 are conv -> BN -> ReLU chains).  cn_conv_pre_affine_arm(ss, C, relu)
- * arms the NEXT cn_conv2d_fwd / cn_conv2d_wgrad of the calling host thread: x is then the raw output of the previous convolution and
- * the kernel uses x' = bf16(fma(x, ss[c], ss[C + c])) (relu: max(., 0)) — bit-identical to the tensor cn_bn_train_fwd_sink would have
- * stored — with zero padding applied to x'.  ss = fp32 [2][C] scale | shift in device memory (cn_bn_finalize_sink writes it).  Only
- * the 16-input-channel bf16 3x3 kernels have the hook; any other shape returns CN_EUNSUPPORTED (no silent fallback on the raw tensor). */
-int cn_conv_pre_affine_arm(const float* ss, int C, int relu);
+ * accumulates the batch statistics — cn_hooks.bn_part of the producing call (cn_conv2d_fwd_h, cn_conv1x1_cat_fwd_h, cn_dcn_fwd_h,
+ * cn_stem_conv_fwd_h).  cn_bn_train_fwd_stats = cn_bn_train_fwd without the statistics pass over x: finalize from `part` (handed
+ * back all-zero) + the apply pass.  The input pre-affine of the consumer (cn_hooks.pre_ss) and the BN-backward statistics of a
+ * data-gradient launch (cn_hooks.bnb_part) are described at cn_hooks. */
 /* BN backward for a consumer that applies it on load (the stem's weight gradient, cn_stem_conv_wgrad_bn): cn_bn_bwd_stats = the
  * statistics pass of cn_bn_train_bwd_sink alone; cn_bn_bwd_coef_sink = totals of the sink -> dgamma / dbeta and coef fp32 [5][C]
  * (ca | cp | cq | sc | sh: g = relu ? (fma(x, sc, sh) > 0 ? dy : 0) : dy, dx = fma(ca, g, fma(cp, x, cq))). */
-/* BN backward statistics from the kernel that PRODUCES dy: cn_bn_bwd_stats_arm(sink, slots, C, x, stats, relu) arms the next
- * cn_conv2d_fwd (transposed != 0) of the calling host thread; its output is the gradient w.r.t. the output of a training-mode BN (+ ReLU)
- * with input x (NHWC, pitch C == y_ld) and stats = fp32 [4][C] mean | invstd | scale | shift.  When the dispatched kernel has the hook
- * (the 16-channel bf16 data-gradient kernels) it fills sink[slots][2][C] (all-zero when armed) with what cn_bn_bwd_stats would compute
- * and cn_bn_bwd_stats_taken() returns 1; otherwise 0 and the sink is untouched.  cn_bn_train_bwd_apply = the apply half of
- * cn_bn_train_bwd_sink alone, on a sink that is already filled. */
-int cn_bn_bwd_stats_arm(float* sink, int slots, int C, const void* x, const float* stats, int relu);
-int cn_bn_bwd_stats_taken(void);
+/* cn_bn_train_bwd_apply = the apply half of cn_bn_train_bwd_sink alone, on a sink that is already filled (cn_hooks.bnb_part of the
+ * data-gradient call that produced dy, or cn_bn_bwd_stats). */
 int cn_bn_train_bwd_apply(const void* dy, const void* x, const void* y, const float* gamma, const float* save_mean,
                           const float* save_invstd, const float* scale_shift, void* dx, void* dres, const void* dres_acc,
                           float* dgamma, float* dbeta, int accumulate, const float* sink, int slots, float* clear, int64_t clear_n,
@@ -173,10 +208,8 @@ int cn_bn_bwd_coef_sink(const float* sink, int slots, const float* gamma, const 
                         const float* scale_shift, float* dgamma, float* dbeta, int accumulate, float* coef, float* clear,
                         int64_t clear_n, int64_t npix, int C, void* stream);
 int cn_bn_stats_slots(void);
-int cn_bn_stats_arm(float* part, int slots, int C);
-int cn_bn_stats_taken(void);
 /* cn_bn_finalize_sink: the statistics half of cn_bn_train_fwd_stats alone (mean / invstd / running stats / scale | shift from `part`,
- * handed back all-zero) — no apply pass: the consumer applies the affine map on load (cn_conv_pre_affine_arm). */
+ * handed back all-zero) — no apply pass: the consumer applies the affine map on load (cn_hooks.pre_ss). */
 int cn_bn_finalize_sink(float* part, int slots, const float* gamma, const float* beta, float* running_mean, float* running_var,
                         float* save_mean, float* save_invstd, float* save_scale_shift, int64_t npix, int C, float momentum,
                         float eps, void* stream);
@@ -259,6 +292,8 @@ int cn_dwdeconv_bwd_weight(const void* x, const void* dy, float* dw /* zeroed fp
 size_t cn_dwdeconv_wgrad_ws_bytes(int N, int OH, int C);
 int cn_dwdeconv_bwd_weight_rows(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
                                 int stride, int pad, int OH, int OW, int dtype, void* stream);
+int cn_dwdeconv_bwd_weight_rows_h(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, int N, int H, int W, int C, int k,
+                                  int stride, int pad, int OH, int OW, int dtype, cn_hooks* hooks, void* stream);
 
 /* A 2-channel task head (heads.py:9-15: conv3x3 + bias -> ReLU -> conv1x1 + bias; width_height / regression) in ONE launch, no-grad
  * path: out fp32 NCHW [N, 2, H, W] — ALL-ZERO at launch, the kernel adds — = conv1x1(relu(conv3x3(x) + b1)) + b2; x NHWC bf16, Ci = 64,
@@ -280,6 +315,10 @@ int cn_conv1x1_cat_fwd(const void* x0, const void* x1, const void* x2, const voi
                        int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
                        const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
                        int dtype, void* stream);
+int cn_conv1x1_cat_fwd_h(const void* x0, const void* x1, const void* x2, const void* x3, const void* x4, const void* x5,
+                         int c0, int c1, int c2, int c3, int c4, int c5, int nsrc, const void* wp, const float* bias,
+                         const void* residual, void* y, int N, int H, int W, int Co, int y_ld, int res_ld, int relu,
+                         int dtype, cn_hooks* hooks, void* stream);
 
 /* ---- DCNv2 (DCN.dcn_v2.DCN, pose_dla_dcn.py:441-449) --------------------- */
 /* om = conv_offset_mask(x) as NHWC FP32 [P][om_ld] in both compute modes — sampling coordinates stay exact —
@@ -301,10 +340,14 @@ int cn_dcn_variant(int entry, int Ci, int Co);
  * y = act(bias + sum_k W_k * sigmoid(om[18+k]) * bilinear_k(x)); wp = cn_pack_weight mode 1 ([Co_pad32][tap*Ci + ci]). */
 int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,
                int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, void* stream);
+int cn_dcn_fwd_h(const void* x, const float* om, const void* wp, const float* bias, void* y,
+                 int N, int H, int W, int Ci, int x_ld, int Co, int y_ld, int om_ld, int relu, int dtype, cn_hooks* hooks, void* stream);
 /* Fused DCNv2 weight gradient (bf16): dwp[co][tap*Ci+ci] += sum_p dy[p][co] * sampled_x[p,tap][ci], the sampled operand
  * rebuilt per tap in LDS (no column tensor).  dwp fp32 [Co_pad32][9*Ci], zeroed by the caller.  fp32 -> CN_EUNSUPPORTED. */
 int cn_dcn_wgrad(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
                  int Co, int dy_ld, int om_ld, int dtype, void* stream);
+int cn_dcn_wgrad_h(const void* x, const float* om, const void* dy, float* dwp, int N, int H, int W, int Ci, int x_ld,
+                   int Co, int dy_ld, int om_ld, int dtype, cn_hooks* hooks, void* stream);
 /* Fused DCNv2 backward (no column gradient in HBM), used instead of cn_dcn_col2im:
  *   cn_dcn_bwd_dom: GEMM dcol = dY x W^T (wpd2 = cn_pack_weight mode 2) whose epilogue reduces dcol against the bilinear
  *     corner differences of x -> dom fp32 [P][om_ld] (channels 0..26; zeroed by the caller when Ci > 128), and scatters

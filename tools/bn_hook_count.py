@@ -18,13 +18,13 @@ last = [None]
 orig = _hip.call
 
 
-def spy(name, *args):
+def spy(name, *args, **kw):
     if name in ("cn_bn_train_fwd", "cn_bn_train_fwd_stats"):
         npix, C = (args[10], args[11]) if name == "cn_bn_train_fwd" else (args[12], args[13])
         seen[(name, int(npix), int(C), last[0])] += 1
     elif name in ("cn_conv2d_fwd", "cn_conv1x1_cat_fwd", "cn_dcn_fwd", "cn_stem_conv_fwd"):
         last[0] = name
-    return orig(name, *args)
+    return orig(name, *args, **kw)
 
 
 _hip.call = spy

@@ -85,10 +85,10 @@ def tail():
     coef = torch.zeros(5, 16, device=DEV)
     npix = N * 512 * 512
     for blocks in (160, 1536):
-        _hip.call("cn_set_wgrad_parallelism", blocks) if False else _hip.query("cn_set_wgrad_parallelism", blocks)
-        us = timeit(lambda: _hip.call("cn_stem_conv_wgrad", img, dy, dw, N, 3, 512, 512, 16, 7, 7, 1, 3, 512, 512, code))
+        hk = _hip.Hooks().set(wgrad_blocks=blocks)
+        us = timeit(lambda: _hip.call("cn_stem_conv_wgrad", img, dy, dw, N, 3, 512, 512, 16, 7, 7, 1, 3, 512, 512, code, hooks=hk))
         print(f"stem wgrad              [wgrad blocks {blocks:4d}] {us:8.1f} us")
-        us = timeit(lambda: _hip.call("cn_stem_conv_wgrad_bn", img, dy, y, coef, dw, N, 3, 512, 512, 16, 7, 7, 1, 3, 512, 512, 1, code))
+        us = timeit(lambda: _hip.call("cn_stem_conv_wgrad_bn", img, dy, y, coef, dw, N, 3, 512, 512, 16, 7, 7, 1, 3, 512, 512, 1, code, hooks=hk))
         print(f"stem wgrad through BN   [wgrad blocks {blocks:4d}] {us:8.1f} us")
     def bwd():
         sink.zero_()

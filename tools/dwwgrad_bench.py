@@ -21,5 +21,5 @@ def bench(N, H, W, C):
     ts.sort(); b = (x.numel() + dy.numel()) * 2
     return ts[5], b / ts[5] / 1e6
 for g in (160, 1536):
-    _hip.lib().cn_set_wgrad_parallelism(g)
+    ops.SideGrads.grid = g        # cn_hooks.wgrad_blocks of the weight-gradient calls below
     print(f"grid target {g}: " + "   ".join(f"{c}: {bench(*c)[0]:.1f} us" for c in ((64, 64, 64, 64), (64, 32, 32, 128), (64, 16, 16, 256), (64, 32, 32, 64))))

@@ -12,7 +12,6 @@ dy = torch.randn(N, H, W, 16, device=dev).bfloat16()
 x16 = torch.randn(N, H, W, 16, device=dev).bfloat16()
 dw = torch.zeros(16, 3, 7, 7, device=dev)
 dwp = torch.zeros(32, 9 * 16, device=dev)
-call("cn_set_wgrad_parallelism", 1536)
 
 
 def timed(fn, reps=20):

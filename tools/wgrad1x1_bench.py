@@ -20,8 +20,8 @@ for (N, HW, Ci, Co) in [(64, 128, 256, 2), (64, 128, 256, 80), (64, 128, 64, 64)
     dy = torch.randn(N, HW, HW, ld, device=DEV).to(dt)
     dwp = torch.zeros((Co + 31) // 32 * 32, Ci, device=DEV)
     for b in blocks:
-        _hip.query("cn_set_wgrad_parallelism", b)
-        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad", x, dy, dwp, None, N, HW, HW, Ci, Ci, HW, HW, Co, ld, 1, 1, 1, 0, code), n=10)
+        hk = _hip.Hooks().set(wgrad_blocks=b)
+        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad", x, dy, dwp, None, N, HW, HW, Ci, Ci, HW, HW, Co, ld, 1, 1, 1, 0, code, hooks=hk), n=10)
         nbytes = (x.numel() + dy.numel()) * 2
         print(f"wgrad 1x1 {Ci:3d}->{Co:3d} @{HW:3d}^2  blocks {b:5d}: {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s", flush=True)
     del x, dy, dwp

@@ -1,5 +1,5 @@
 """Isolated timing of cn_conv2d_wgrad on the 3x3 / stride-1 layers of a DLA-34 step (batch 64) at several split-K grid sizes
-(cn_set_wgrad_parallelism: 384 = what the train step uses next to the data-gradient chain, 1536 = alone).
+(cn_hooks.wgrad_blocks: 384 = what the train step uses next to the data-gradient chain, 1536 = alone).
     python tools/wgrad_bench.py [blocks ...]"""
 import os
 import sys
@@ -23,8 +23,8 @@ for (N, HW, Ci, Co) in SHAPES:
     dwp = torch.zeros((Co + 31) // 32 * 32, 9 * Ci, device=DEV)
     flops = 2.0 * N * HW * HW * Ci * Co * 9
     for b in blocks:
-        _hip.query("cn_set_wgrad_parallelism", b)
-        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad", x, dy, dwp, None, N, HW, HW, Ci, Ci, HW, HW, Co, ld, 3, 3, 1, 1, code), n=10)
+        hk = _hip.Hooks().set(wgrad_blocks=b)
+        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad", x, dy, dwp, None, N, HW, HW, Ci, Ci, HW, HW, Co, ld, 3, 3, 1, 1, code, hooks=hk), n=10)
         print(f"wgrad 3x3s1 {Ci:3d}->{Co:3d} @{HW:3d}^2  blocks {b:5d}: {us:8.1f} us (min {mn:8.1f})  {flops / us / 1e6:7.1f} TF", flush=True)
     del x, dy, dwp
 
@@ -36,12 +36,12 @@ for (N, HW, Ci, Co) in SHAPES:
     dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
     flops = 2.0 * N * HW * HW * Ci * Co * 9
     for b in blocks:
-        _hip.query("cn_set_wgrad_parallelism", b)
-        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes", N, HW, HW, Ci, Ci, HW, HW, Co, ld, 3, 3, 1, 1, code))
+        hk = _hip.Hooks().set(wgrad_blocks=b)
+        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes_h", N, HW, HW, Ci, Ci, HW, HW, Co, ld, 3, 3, 1, 1, code, b))
         if not n:
             continue
         ws = torch.empty(n, dtype=torch.uint8, device=DEV)
-        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad_direct", x, dy, dw, None, 1, ws, n, N, HW, HW, Ci, Ci, HW, HW, Co, ld, 3, 3, 1, 1, code), n=10)
+        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad_direct", x, dy, dw, None, 1, ws, n, N, HW, HW, Ci, Ci, HW, HW, Co, ld, 3, 3, 1, 1, code, hooks=hk), n=10)
         print(f"wgrad 3x3s1 {Ci:3d}->{Co:3d} @{HW:3d}^2  blocks {b:5d}: {us:8.1f} us (min {mn:8.1f})  {flops / us / 1e6:7.1f} TF   slabs {n / 1e6:6.1f} MB", flush=True)
     del x, dy, dw
 
@@ -54,10 +54,10 @@ for (N, HW, Ci, Co) in [(64, 256, 32, 64), (64, 128, 64, 128), (64, 64, 128, 256
     dw = torch.zeros(Co, Ci, 3, 3, device=DEV)
     flops = 2.0 * N * OHW * OHW * Ci * Co * 9
     for b in blocks:
-        _hip.query("cn_set_wgrad_parallelism", b)
-        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad", x, dy, dwp, None, N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code), n=10)
-        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes", N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code))
+        hk = _hip.Hooks().set(wgrad_blocks=b)
+        us, mn = timeit(lambda: _hip.call("cn_conv2d_wgrad", x, dy, dwp, None, N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code, hooks=hk), n=10)
+        n = int(_hip.query("cn_conv2d_wgrad_direct_bytes_h", N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code, b))
         ws = torch.empty(max(n, 16), dtype=torch.uint8, device=DEV)
-        us2, mn2 = timeit(lambda: _hip.call("cn_conv2d_wgrad_direct", x, dy, dw, None, 1, ws, n, N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code), n=10) if n else (float("nan"), 0)
+        us2, mn2 = timeit(lambda: _hip.call("cn_conv2d_wgrad_direct", x, dy, dw, None, 1, ws, n, N, HW, HW, Ci, Ci, OHW, OHW, Co, Co, 3, 3, 2, 1, code, hooks=hk), n=10) if n else (float("nan"), 0)
         print(f"wgrad 3x3s2 {Ci:3d}->{Co:3d} @{HW:3d}^2  blocks {b:5d}: generic {us:8.1f} us   slab {us2:8.1f} us  ({flops / us2 / 1e6:6.1f} TF)", flush=True)
     del x, dy, dwp, dw

@@ -24,9 +24,9 @@ labels = []
 orig = _hip.call
 dummy = torch.zeros(4, dtype=torch.uint8, device=dev)
 MARK = os.environ.get("MARK_BN", "1") == "1"      # a 4-byte cn_zero behind every BN backward: the launch stream's timeline through the backbone
-def call(name, *a):
+def call(name, *a, **kw):
     if MARK and recording[0] and name in ("cn_bn_train_bwd_sink", "cn_bn_train_bwd", "cn_bn_train_bwd_acc"):
-        r = orig(name, *a)
+        r = orig(name, *a, **kw)
         labels.append(("main", 4, f"after {name} C={a[-3] if len(a) > 3 else ''}"))
         orig("cn_zero", dummy, 4)
         return r
@@ -34,7 +34,7 @@ def call(name, *a):
         side = ops.SideGrads.stream is not None and torch.cuda.current_stream() == ops.SideGrads.stream
         fr = [f for f in traceback.extract_stack()[:-1] if "centernet" in f.filename][-3:]
         labels.append(("side" if side else "main", a[1], " <- ".join(f"{f.name}:{f.lineno}" for f in reversed(fr))))
-    return orig(name, *a)
+    return orig(name, *a, **kw)
 recording = [False]
 _hip.call = call; ops.call = call
 import centernet_amd.engine as eng
