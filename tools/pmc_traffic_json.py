@@ -17,7 +17,7 @@ KERNELS = {
     "conv3x3_ws_kernel<64, false, 0, true, 0>": ("conv3x3_ws_kernel<64>", CSRC + "conv3x3_ws.hip",
                                               "weight-stationary kernel, ReLU variant = the three 64->256 head convs: 134 MB in (x 1.27 halo, x 4 channel blocks through L2) + 537 MB out"),
     "dcn_bwd_dom_kernel<64>": ("dcn_bwd_dom_kernel<64>", CSRC + "dcn_fused.hip", "offset/mask gradient of the 64-output-channel DCN layers"),
-    "dcn_dom_bm_kernel<64>": ("dcn_dom_bm_kernel<64>", CSRC + "dcn_dom_bm.hip", "offset/mask gradient of the DCN layers with 64 output channels (matrix-core corner dots)"),
+    "dcn_dom_bm_kernel<64, true>": ("dcn_dom_bm_kernel<64>", CSRC + "dcn_dom_bm.hip", "offset/mask gradient of the DCN layers with 64 output channels (gathered corner pixels + dot2; round 5)"),
     "dcn_dx_bm_kernel<2>": ("dcn_dx_bm_kernel<2>", CSRC + "dcn_bm.hip", "data gradient of the 64->64 DCN layers"),
     "dcn_fwd_bm_kernel<2>": ("dcn_fwd_bm_kernel<2>", CSRC + "dcn_bm.hip", "forward of the 64->64 DCN layers"),
     "dcn_wgrad_bm_kernel": ("dcn_wgrad_bm_kernel", CSRC + "dcn_bm.hip", "weight gradient of the DCN layers (launch mix)"),
