@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256, S == 2 ? 2 : 3) void conv3x3_c16r_kernel(const
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cb][4], __builtin_bit_cast(bf16x8_t, p.b[gq]), acc, 0, 0, 0);
                 const int ch = cb * 16 + 4 * kc;
                 if (FAST || (ow < g.OW && ch < g.y_ld)) {      // y_ld is a multiple of 4; padding channels are written as zeros
-                    float v[4] = {fmaxf(acc[0], relu_lo), fmaxf(acc[1], relu_lo), fmaxf(acc[2], relu_lo), fmaxf(acc[3], relu_lo)};
+                    // ReLU as a lower bound (0, or -inf when off) that keeps a NaN (fmaxf returns the non-NaN operand: a NaN accumulator
+                    // would be stored as -inf / 0 and an isnan screen further down would miss it; round-4 ADVICE)
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[r] < relu_lo ? relu_lo : acc[r];
                     if constexpr (!FAST) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)

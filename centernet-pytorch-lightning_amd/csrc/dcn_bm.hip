@@ -5,7 +5,7 @@
 //
 // The gather kernels (dcn_fused.hip) blend on the VALU: per (pixel, tap, 8 channels) 4 L2 gathers, 32 bf16 unpacks, 32 FMAs, 4
 // converts — ~580 VALU instructions per thread and tap against ~20 MFMAs; PMC and instruction counts say they are bound by that
-// stream.  Here the blend is a second MFMA: one WAVE owns a 4x8 group of output pixels and keeps the x WINDOW that
+// stream (docs/NEGATIVE_RESULTS.md).  Here the blend is a second MFMA: one WAVE owns a 4x8 group of output pixels and keeps the x WINDOW that
 // group can sample (12 rows x 16 columns: +-4 pixels, i.e. offsets up to |d| <= 3 px for every tap) as TRANSPOSED MFMA
 // fragments in registers for all nine taps (loaded once per group with ds_read_b64_tr_b16 from the workgroup's halo image in
 // LDS).  One window row = 16 source pixels = the K of one v_mfma_f32_32x32x16_bf16, so per tap and touched window row

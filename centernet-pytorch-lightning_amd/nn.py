@@ -16,7 +16,9 @@ import os
 from . import ops
 
 STEM_BN_FUSED = not (os.environ.get("CN_DISABLE_STEM_BN_FUSED") or os.environ.get("CN_DISABLE_WGRAD_C16"))   # stem conv + BN as one autograd node
-BN_DEFER = not os.environ.get("CN_DISABLE_BN_DEFER")     # training-mode BN of the 16-channel 512^2 layers applied by the consuming conv
+# training-mode BN of the 16-channel 512^2 layers applied by the consuming conv: needs the kernels with the pre-affine hook, so the
+# switches that turn those kernels off turn this off too (round-4 ADVICE: they used to end in CN_EUNSUPPORTED instead of the unfused chain)
+BN_DEFER = not (os.environ.get("CN_DISABLE_BN_DEFER") or os.environ.get("CN_DISABLE_CONV_C16R") or os.environ.get("CN_DISABLE_WGRAD_C16"))
 
 
 class Conv2d(nn.Module):

@@ -1615,6 +1615,8 @@ def head2_infer(x, hidden, out):
     Ch = hidden.weight.shape[0]
     if Cx != 64 or hidden.weight.shape[1] != 64 or Ch % 64 or out.weight.shape[0] != 2:
         return None
+    if _os.environ.get("CN_DISABLE_HEAD2") or torch.are_deterministic_algorithms_enabled():
+        return None                 # the one-launch form sums per-wave partials with fp32 atomics: not bit-reproducible run to run
     c = hidden.infer_key(x)
     y = zeros((N, 2, H, W), torch.float32, x.device)
     w2 = out.weight.detach().reshape(2, Ch)
@@ -1698,7 +1700,7 @@ class HeadFn(Function):
         assert (KH, KW) == (3, 3) and tuple(w2.shape[1:]) == (Ch, 1, 1) and Cx == rup(Ci, 16)
         wp1 = pack_weight(w1, 1, x.dtype)
         h = out = None
-        if (HeadFn.fused2 and C == 2 and x.dtype == torch.bfloat16 and Ci == 64 and Cx == 64 and Ch % 64 == 0 and b1 is not None
+        if (HeadFn.fused2 and not torch.are_deterministic_algorithms_enabled() and C == 2 and x.dtype == torch.bfloat16 and Ci == 64 and Cx == 64 and Ch % 64 == 0 and b1 is not None
                 and b2 is not None):
             # a 2-channel head (width_height / regression) in ONE launch: ReLU + 1x1 in the 3x3 kernel's epilogue, the hidden
             # activation (537 MB at C3) is never stored; its backward recomputes the few hidden rows it needs from the input patches

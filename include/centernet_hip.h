@@ -44,7 +44,7 @@ int cn_copy_channels(const void* src, int src_ld, int src_off, void* dst, int ds
 int cn_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 /* p[0 .. nbytes) = 0 (any alignment).  Replaces the ATen fills (`torch.zeros`, `.zero_()`) in front of the split-K weight-gradient
  * accumulators, the DCN far-sample buffers and the flat gradient buffer (engine.FlatAdam.zero_grad): same position in the stream,
- * so the accumulator is still L2-resident for the atomics that follow, but the step holds no at::native launch. */
+ * so the accumulator is still L2-resident for the atomics that follow (docs/NEGATIVE_RESULTS.md), but the step holds no at::native launch. */
 int cn_zero(void* p, int64_t nbytes, void* stream);
 /* measurement aid (tools/tail_stamps.py): *dst = the device's constant-rate wall clock (100 MHz ticks) when this launch runs */
 int cn_stamp(int64_t* dst, void* stream);
@@ -298,7 +298,10 @@ int cn_dwdeconv_bwd_weight_rows_h(const void* x, const void* dy, float* dw, void
 /* A 2-channel task head (heads.py:9-15: conv3x3 + bias -> ReLU -> conv1x1 + bias; width_height / regression) in ONE launch, no-grad
  * path: out fp32 NCHW [N, 2, H, W] — ALL-ZERO at launch, the kernel adds — = conv1x1(relu(conv3x3(x) + b1)) + b2; x NHWC bf16, Ci = 64,
  * wp1 = cn_pack_weight(hidden weight, mode 1), w2 fp32 [2][Ch] (the 1x1 weight as stored), Ch a multiple of 64.  The hidden activation
- * (537 MB at bs 64, 128x128) is never written or re-read.  CN_EUNSUPPORTED when the weight-stationary kernel declines the shape. */
+ * (537 MB at bs 64, 128x128) is never written or re-read.  CN_EUNSUPPORTED when the weight-stationary kernel declines the shape.
+ * NOT bit-reproducible run to run: every pixel is the fp32-atomic sum of Ch/32 per-wave partials in arrival order (differences in the
+ * last bits of the map; the two-launch pair cn_conv2d_fwd + cn_conv1x1_nchw_fwd is the deterministic form — the host mirror takes it
+ * under torch.use_deterministic_algorithms(True) or CN_DISABLE_HEAD2). */
 int cn_head2_fwd(const void* x, const void* wp1, const float* b1, const float* w2, const float* b2, float* out, int N, int H, int W,
                  int Ci, int x_ld, int Ch, int dtype, void* stream);
 /* A head's last layer (heads.py:15-17: nn.Conv2d(head_conv, out_channels, 1) on the hidden activation) straight into the public

@@ -64,7 +64,7 @@ def test_network_fp32_vs_reference_golden(golden, arch, size, train):
                 got = strided(params[n].grad, 512).cpu().numpy().astype(np.float64)
                 # Deep gradients pass through batch-statistic BN + ReLU / max-pool: a single activation whose sign
                 # flips (|y| ~ 1e-7, summation order) perturbs a handful of entries by O(1e-2); the oracle's own
-                # fp32-vs-fp64 run shows the same (tools/debug_grads.py).  Layer-exact parity lives in test_gpu_ops.py;
+                # fp32-vs-fp64 run shows the same (tools/grad_modes.py).  Layer-exact parity lives in test_gpu_ops.py;
                 # here: small relative L2 error and an accurate bulk.
                 rel_l2 = np.linalg.norm(got - ref) / max(1e-30, np.linalg.norm(ref))
                 med = np.median(np.abs(got - ref)) / max(1e-30, np.abs(ref).max())

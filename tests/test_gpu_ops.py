@@ -306,7 +306,7 @@ def test_conv3x3_k_pipelined(cfg, monkeypatch):
         torch.cuda.synchronize()
         return y.detach().float().cpu(), xg.grad.detach().float().cpu()
 
-    monkeypatch.setenv("CN_ENABLE_CONV_KP", "1")          # the kernel is opt-in (experimental)
+    monkeypatch.setenv("CN_ENABLE_CONV_KP", "1")          # the kernel is opt-in (experimental, docs/NEGATIVE_RESULTS.md)
     if force:
         monkeypatch.setenv("CN_CONV_KP_FORCE", str(force))
     runs = [run() for _ in range(3)]
