@@ -268,6 +268,49 @@ def test_two_channel_head_in_one_launch(cfg, monkeypatch):
         assert float((f2 - fused[0]).abs().max()) <= 1e-5 * sc, "runs differ only by the order of the eight fp32 partial sums"
 
 
+def test_two_channel_head_is_bit_reproducible_under_the_determinism_flag():
+    """round-4 ADVICE: cn_head2_fwd sums eight per-wave partials per pixel with fp32 atomics, so its maps differ in the last bits from
+    run to run.  Under torch.use_deterministic_algorithms(True) the host mirror takes the two-launch pair (no atomics): bit-identical
+    runs, no-grad and HeadFn (training) forward alike."""
+    from centernet_amd.models.heads import HeadConv
+    dt = torch.bfloat16
+    torch.manual_seed(3)
+    head = HeadConv(2, 64, 256).to(DEV)
+    xg = ops().mark_nhwc(to_nhwc(torch.randn(4, 64, 32, 64), dt), 64)
+    torch.use_deterministic_algorithms(True)
+    try:
+        with torch.no_grad():
+            a, b = head(xg).clone(), head(xg).clone()
+        c, d = head(xg).detach().clone(), head(xg).detach().clone()
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert torch.equal(a, b) and torch.equal(c, d)
+    with torch.no_grad():
+        fused = head(xg)
+    assert float((fused - a).abs().max()) <= 1.5e-2 * float(a.abs().max())
+
+
+def test_c16_conv_keeps_a_nan():
+    """round-4 ADVICE: conv3x3_c16r_kernel's 'ReLU as a lower bound' used fmaxf, which returns the non-NaN operand — a NaN accumulator
+    was stored as -inf (ReLU off) or 0 (on) and an isnan screen further down missed it.  The bound now keeps it, like torch's relu."""
+    o = ops()
+    dt = torch.bfloat16
+    x = torch.randn(1, 40, 70, 16).to(dt).to(DEV)
+    x[0, 20, 30, 5] = float("nan")
+    w = (torch.randn(16, 16, 3, 3) * 0.1).to(DEV)
+    wp = o.pack_weight(w, 1, dt)
+    for relu in (False, True):
+        y = o._igemm(x, wp, None, None, 16, 3, 3, 1, 1, False, relu, 40, 70).float()
+        torch.cuda.synchronize()
+        assert torch.isnan(y[0, 19:22, 29:32]).all(), "every output whose 3x3 window contains the NaN is NaN"
+        assert not torch.isinf(y).any(), "a NaN must not come out as -inf"
+        # (the kernel's K packing multiplies zero weights with neighbouring rows, so 0 * NaN may mark a few more outputs of the same
+        # columns as NaN — louder than the truth, never quieter; everything away from the spot stays finite)
+        far = y.clone()
+        far[0, 12:29, 22:39] = 0
+        assert torch.isfinite(far).all()
+
+
 KP_CONVS = [  # N,H,W,Ci,Co,bias,relu,force: >= 128 input channels on 16-aligned maps -> the K-pipelined persistent kernel (conv3x3_kp.hip)
     (4, 32, 32, 128, 128, False, False, 8),    # two channel slices, two tiles per workgroup at 8 workgroups: deferred epilogue + cross-tile prefetch
     (3, 16, 48, 256, 128, True, True, 8),      # four slices, bias + ReLU, nine tiles over eight workgroups (one gets two)
