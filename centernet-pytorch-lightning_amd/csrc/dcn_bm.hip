@@ -568,6 +568,9 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
     const int s_col = lane & 15, s_row0 = lane >> 4;
     const bool col_ok = s_col >= 1 && s_col <= 14;                           // |q - p| <= 3 needs window columns 1..14
     const int tcol = gcol + s_col - 1;                                       // table column (tile-window column - 1)
+    bool src_ok[3];                                                          // pass j: this lane's window position is a source (rows 1..10)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) src_ok[j] = col_ok && 4 * j + s_row0 >= 1 && 4 * j + s_row0 <= 10;
 
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
@@ -595,23 +598,31 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
                 if (z < 4 || lane < 32) *reinterpret_cast<u32x4v*>(T + (lane + 64 * z) * 16) = u32x4v{0u, 0u, 0u, 0u};
             __builtin_amdgcn_wave_barrier();
             const int s_row = 4 * j + s_row0;                                // group-window row of the source
-            const bool src_ok = col_ok && s_row >= 1 && s_row <= 10;
             bool any = false;
-            if (src_ok) {
+            if (src_ok[j]) {
                 const float pyt = tpy[j], pxt = tpx[j], m = tpm[j];
                 const float fy = floorf(pyt), fx = floorf(pxt);
                 const int y0 = (int)fy - grow, x0 = (int)fx - gcol;           // destination of corner 00, group-local
                 const float ly = pyt - fy, lx = pxt - fx;
                 const float wy[2] = {(1.f - ly) * m, ly * m}, wx[2] = {1.f - lx, lx};
                 const int sy_l = s_row - 4, sx_l = s_col - 4;                 // the source itself, group-local
+                // A corner (qy, qx) lands in the group and within reach iff qy in [0, 4), qx in [0, 8), |qy - sy_l| <= 3, |qx - sx_l| <= 3.
+                // One unsigned key per axis and corner row / column — (d + 3) | (out-of-range bits of q moved above 6) — and one
+                // v_max + compare per corner replace seven compares and six scalar ANDs (the hit test was half of a pass's instructions).
+                unsigned ky[2], kx[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int qy = y0 + i, qx = x0 + i;
+                    ky[i] = (unsigned)(qy - sy_l + 3) | ((unsigned)(qy & ~3) << 1);
+                    kx[i] = (unsigned)(qx - sx_l + 3) | (unsigned)(qx & ~7);
+                }
+                const int tbase = (y0 * 8 + x0) * DXB_TP + lane * 2;
 #pragma unroll
                 for (int cnr = 0; cnr < 4; ++cnr) {
-                    const int qy = y0 + (cnr >> 1), qx = x0 + (cnr & 1);
                     const float w = wy[cnr >> 1] * wx[cnr & 1];
-                    const int ddy = qy - sy_l, ddx = qx - sx_l;
-                    const bool hit = (unsigned)qy < 4u && (unsigned)qx < 8u && ddy >= -3 && ddy <= 3 && ddx >= -3 && ddx <= 3 && w > 0.f;
+                    const bool hit = max(ky[cnr >> 1], kx[cnr & 1]) <= 6u && w > 0.f;
                     if (hit) {
-                        *reinterpret_cast<bf16_t*>(T + (qy * 8 + qx) * DXB_TP + lane * 2) = f2bf(w);
+                        *reinterpret_cast<bf16_t*>(T + tbase + ((cnr >> 1) * 8 + (cnr & 1)) * DXB_TP) = f2bf(w);
                         any = true;
                     }
                 }
@@ -619,11 +630,15 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             const uint64_t hits = __builtin_amdgcn_ballot_w64(any);
             __builtin_amdgcn_wave_barrier();
             // ---- G^T[co][q] += dY^T[co][window row] * T^T   (one MFMA pair per window row that has a hit) ----
+            // (the four row slices of T are read in ONE batch — rows without a hit are zeros and are skipped by the MFMAs only: a
+            // read per hit row cost one LDS round trip each, up to four per pass)
+            u32x4v tb[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) tb[rr] = *reinterpret_cast<const u32x4v*>(T + nl * DXB_TP + (rr * 16 + hh * 8) * 2);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 if (!(hits & (0xFFFFull << (16 * rr)))) continue;
-                const u32x4v b = *reinterpret_cast<const u32x4v*>(T + nl * DXB_TP + (rr * 16 + hh * 8) * 2);
-                const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, b);
+                const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, tb[rr]);
                 st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[4 * j + rr][0], bf, st[0], 0, 0, 0);
                 st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf[4 * j + rr][1], bf, st[1], 0, 0, 0);
             }
