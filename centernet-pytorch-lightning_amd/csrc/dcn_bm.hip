@@ -599,11 +599,17 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             __builtin_amdgcn_wave_barrier();
             const int s_row = 4 * j + s_row0;                                // group-window row of the source
             bool any = false;
-            if (src_ok[j]) {
-                const float pyt = tpy[j], pxt = tpx[j], m = tpm[j];
-                const float fy = floorf(pyt), fx = floorf(pxt);
-                const int y0 = (int)fy - grow, x0 = (int)fx - gcol;           // destination of corner 00, group-local
-                const float ly = pyt - fy, lx = pxt - fx;
+            // Row test first: a source whose two sampling rows (floor(py), and floor(py) + 1 when py has a fraction) miss the group's
+            // four rows has nothing to scatter.  When that holds for every lane of the pass — with offsets near zero a tap's sources
+            // sit in 4-6 of the 12 window rows, i.e. in one or two of the three passes — the wave skips the rest of the geometry.
+            const float pyt = tpy[j];
+            const float fy = floorf(pyt), ly = pyt - fy;
+            const int y0 = (int)fy - grow;                                    // destination row of corner 00, group-local
+            if (src_ok[j] && ((unsigned)y0 <= 3u || (y0 == -1 && ly > 0.f))) {
+                const float pxt = tpx[j], m = tpm[j];
+                const float fx = floorf(pxt);
+                const int x0 = (int)fx - gcol;
+                const float lx = pxt - fx;
                 const float wy[2] = {(1.f - ly) * m, ly * m}, wx[2] = {1.f - lx, lx};
                 const int sy_l = s_row - 4, sx_l = s_col - 4;                 // the source itself, group-local
                 // A corner (qy, qx) lands in the group and within reach iff qy in [0, 4), qx in [0, 8), |qy - sy_l| <= 3, |qx - sx_l| <= 3.
