@@ -421,8 +421,8 @@ bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const flo
 // The source geometry of all nine taps (tile-relative sampling position, sigmoid(mask)) is computed once per tile into an LDS
 // table that re-uses the halo image once the fragments are loaded.
 #ifdef DXB_PROBE   // development build only (tools/dxbm_probe.py)
-__device__ unsigned long long dxb_ts[1024 * 32];
-#define DXB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) dxb_ts[blockIdx.x * 32 + (k)] = clock64(); } while (0)
+__device__ unsigned long long dxb_ts[1024 * 40];
+#define DXB_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) dxb_ts[blockIdx.x * 40 + (k)] = clock64(); } while (0)
 extern "C" int dxb_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dxb_ts), sizeof(dxb_ts)); }
 #else
 #define DXB_STAMP(k) do { } while (0)
@@ -513,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
         st16(Yw + bm_lds_ofs(pix / BM_WC, pix % BM_WC, q * 8), hv[i]);
     }
     __syncthreads();
+    DXB_STAMP(32);
 
     // ---- the group's dY window as transposed fragments (rows = co) ----
     bf16x8_t yf[BM_GR][2];
@@ -534,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void dcn_dx_bm_kernel(const DxBmGeom g) {
             }
     }
     __syncthreads();        // the halo image is dead: geometry table + T tiles + first weight slice go in
+    DXB_STAMP(33);
 
     // table entry 2k / 2k+1 of a source: sampling position of tap k relative to the TILE origin (row - ty0 - 1 + ky + dy),
     // entry 18+k: sigmoid(mask logit), 0 for sources outside the image

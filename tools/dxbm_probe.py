@@ -43,13 +43,16 @@ else:
     e0.record(); run(); e1.record()
     torch.cuda.synchronize()
     lib = ctypes.CDLL(SO)
-    buf = np.zeros(1024 * 32, dtype=np.uint64)
+    buf = np.zeros(1024 * 40, dtype=np.uint64)
     assert lib.dxb_probe_dump(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    ts = buf.reshape(1024, 32).astype(np.int64)
+    ts = buf.reshape(1024, 40).astype(np.int64)
     ts = ts[ts[:, 31] != 0]
     print(f"launch {e0.elapsed_time(e1) * 1e3:.1f} us, offsets sigma {sigma}, {len(ts)} workgroups stamped")
     med = lambda v: f"median {np.median(v):8.0f}  p10 {np.percentile(v, 10):8.0f}  p90 {np.percentile(v, 90):8.0f}"
     print("  prologue (halo, fragments, table)", med(ts[:, 1] - ts[:, 0]))
+    print("    loads -> halo image in LDS      ", med(ts[:, 32] - ts[:, 0]))
+    print("    window fragments                ", med(ts[:, 33] - ts[:, 32]))
+    print("    geometry table                  ", med(ts[:, 1] - ts[:, 33]))
     a = np.stack([ts[:, 3 + 3 * t] - ts[:, 2 + 3 * t] for t in range(9)], 1)
     b = np.stack([ts[:, 4 + 3 * t] - ts[:, 3 + 3 * t] for t in range(9)], 1)
     c = np.stack([(ts[:, 5 + 3 * t] if t < 8 else ts[:, 29]) - ts[:, 4 + 3 * t] for t in range(9)], 1)
