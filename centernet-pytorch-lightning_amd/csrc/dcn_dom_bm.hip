@@ -394,7 +394,10 @@ __global__ __launch_bounds__(256, 2) void dcn_dom_bm_kernel(const DomBmGeom g) {
         const int dh0 = wr - DB_MG - prow, dw0 = wc - DB_MG - pcol;                     // corner 00 relative to the pixel itself
         const bool far_h0 = dh0 > DCN_FAR_R || dh0 < -DCN_FAR_R, far_h1 = dh0 + 1 > DCN_FAR_R || dh0 + 1 < -DCN_FAR_R;
         const bool far_w0 = dw0 > DCN_FAR_R || dw0 < -DCN_FAR_R, far_w1 = dw0 + 1 > DCN_FAR_R || dw0 + 1 < -DCN_FAR_R;
-        const bool scatter = active && direct_far && (far_h0 || far_h1 || far_w0 || far_w1);
+        // any of the four: d0 outside [-R, R - 1] on either axis — one unsigned key per axis, one max, one compare (the eight signed
+        // compares and their scalar ORs sat in every tap of every lane)
+        const bool scatter = active && direct_far &&
+                             max((unsigned)(dh0 + DCN_FAR_R), (unsigned)(dw0 + DCN_FAR_R)) > (unsigned)(2 * DCN_FAR_R - 1);
         if (__builtin_amdgcn_ballot_w64(winmiss || scatter) != 0) {
             if (winmiss || scatter) {
                 const bool in_h0 = (unsigned)h0 < (unsigned)g.H, in_h1 = (unsigned)(h0 + 1) < (unsigned)g.H;
