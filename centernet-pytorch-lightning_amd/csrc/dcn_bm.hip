@@ -38,7 +38,7 @@ extern "C" int bm_probe_dump(void* dst) { return (int)hipMemcpyFromSymbol(dst, H
 
 struct BmGeom {
     const bf16_t* x; const float* om; const bf16_t* wp; const float* bias; bf16_t* y;
-    int N, H, W, x_ld, y_ld, om_ld, ktot, Co, relu;
+    int N, H, W, x_ld, y_ld, om_ld, ktot, Co, relu, Ci;
     float* bn_part; int bn_slots;        // BatchNorm statistics sink (cn_hooks.bn_part), nullable
 };
 
@@ -52,7 +52,7 @@ __device__ static inline int bm_lds_ofs(int wr, int wc, int c) {
     return (wr * BM_WC + wc) * BM_PIXB + ((((c >> 5) ^ (wc >> 1)) & 1) << 6) + (c & 31) * 2;
 }
 
-template <int NCB>   // 32-channel output blocks (Co = 32 * NCB)
+template <int NCB, bool MB = false>   // 32-channel output blocks (Co = 32 * NCB); MB: more than one 64-channel block of x
 __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
     CN_MAIN_PRIO_SET();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -87,13 +87,19 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
     constexpr int WSLOTS = 4 * 2 * 32 * NCB;
     constexpr int WPT = (WSLOTS + 255) / 256;
     uint2 wr_[WPT][2];
+    // Ci = 64 * nblk (round 5: 128 / 256 input channels with Co <= 64 — the 128 -> 64 and 256 -> 64 projections of IDAUp — used to run on
+    // the gather kernel at 0.08 of the MFMA peak): the 64-channel blocks of x one after the other, each with its own halo image, window
+    // fragments and nine taps, all adding into the same accumulators; the geometry table and the selector table are built once.
+    // (a separate instantiation: the one-block kernel sits at 256 registers and the loop around it costs it 50 spilled dwords)
+    const int nblk = MB ? g.Ci >> 6 : 1;
+    int blk = 0;
     auto wload = [&](int tap) {
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int slot = tid + i * 256;
             const int co = slot % (32 * NCB), sh = slot / (32 * NCB), h = sh & 1, s = sh >> 1;
             const int ci0 = 32 * (s >> 1) + 16 * (s & 1) + 4 * h;
-            const bf16_t* p = g.wp + (int64_t)co * g.ktot + tap * 64 + ci0;
+            const bf16_t* p = g.wp + (int64_t)co * g.ktot + tap * g.Ci + blk * 64 + ci0;
             wr_[i][0] = *reinterpret_cast<const uint2*>(p);
             wr_[i][1] = *reinterpret_cast<const uint2*>(p + 8);
         }
@@ -127,15 +133,26 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
     // halo image of the tile: rows ty0-4 .. ty0+11, columns tx0-4 .. tx0+19, zeros outside the image; all twelve loads in flight
     constexpr int NV = BM_WR * BM_WC * 8 / 256;     // 16-byte vectors per thread
     uint4 hv[NV];
+    auto hload = [&]() {                            // halo image of channel block `blk`: global -> registers
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256;
-        const int pix = v >> 3, q = v & 7;
-        const int wr = pix / BM_WC, wc = pix % BM_WC;
-        const int hy = ty0 - BM_MG + wr, hx = tx0 - BM_MG + wc;
-        const bool ok = (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
-        hv[i] = ldg16_masked(X, (((int64_t)hy * g.W + hx) * g.x_ld + q * 8) * 2, ok);
-    }
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            const int pix = v >> 3, q = v & 7;
+            const int wr = pix / BM_WC, wc = pix % BM_WC;
+            const int hy = ty0 - BM_MG + wr, hx = tx0 - BM_MG + wc;
+            const bool ok = (unsigned)hy < (unsigned)g.H && (unsigned)hx < (unsigned)g.W;
+            hv[i] = ldg16_masked(X, (((int64_t)hy * g.W + hx) * g.x_ld + blk * 64 + q * 8) * 2, ok);
+        }
+    };
+    auto hstore = [&]() {                           // ... -> LDS
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + i * 256;
+            const int pix = v >> 3, q = v & 7;
+            st16(Xw + bm_lds_ofs(pix / BM_WC, pix % BM_WC, q * 8), hv[i]);
+        }
+    };
+    hload();
     wload(0);
     // the bias is the accumulators' initial value (lane = pixel, register v of block cb = channel 32 cb + 8 (v >> 2) + 4 hh + (v & 3))
     f32x16_t acc[NCB];
@@ -180,17 +197,15 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
             if (part < 7) { d[0] = tv[i][0]; d[1] = tv[i][1]; d[2] = tv[i][2]; if (part < 6) d[3] = tv[i][3]; }
         }
     }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256;
-        const int pix = v >> 3, q = v & 7;
-        st16(Xw + bm_lds_ofs(pix / BM_WC, pix % BM_WC, q * 8), hv[i]);
-    }
+    hstore();
     wstore(0);
     __syncthreads();
     BM_STAMP(1);
     wload(1);
 
+    const float* const orow = Om + nl * 29;
+#pragma unroll 1
+    for (;;) {          // channel blocks of x
     // ---- the group's window fragments ----
     bf16x8_t xf[BM_GR][2];
     {
@@ -211,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
                 xf[r][mb] = __builtin_bit_cast(bf16x8_t, v);
             }
     }
-    const float* const orow = Om + nl * 29;
     float ro[3] = {orow[0], orow[1], orow[18]};
     BM_STAMP(2);
     __syncthreads();        // every wave holds its fragments: the halo image is dead (re-used as far-sample scratch, 8 KB per wave)
@@ -285,10 +299,10 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
                 const float w10 = (h1ok && w0ok) ? wbt * (1.f - lx) : 0.f, w11 = (h1ok && w1ok) ? wbt * lx : 0.f;
                 const int hc0 = min(max(h0, 0), g.H - 1), hc1 = min(max(h0 + 1, 0), g.H - 1);
                 const int wc0 = min(max(w0, 0), g.W - 1), wc1 = min(max(w0 + 1, 0), g.W - 1);
-                const bf16_t* p00 = X + ((int64_t)hc0 * g.W + wc0) * g.x_ld + 32 * hh;
-                const bf16_t* p01 = X + ((int64_t)hc0 * g.W + wc1) * g.x_ld + 32 * hh;
-                const bf16_t* p10 = X + ((int64_t)hc1 * g.W + wc0) * g.x_ld + 32 * hh;
-                const bf16_t* p11 = X + ((int64_t)hc1 * g.W + wc1) * g.x_ld + 32 * hh;
+                const bf16_t* p00 = X + ((int64_t)hc0 * g.W + wc0) * g.x_ld + blk * 64 + 32 * hh;
+                const bf16_t* p01 = X + ((int64_t)hc0 * g.W + wc1) * g.x_ld + blk * 64 + 32 * hh;
+                const bf16_t* p10 = X + ((int64_t)hc1 * g.W + wc0) * g.x_ld + blk * 64 + 32 * hh;
+                const bf16_t* p11 = X + ((int64_t)hc1 * g.W + wc1) * g.x_ld + blk * 64 + 32 * hh;
 #pragma unroll 1
                 for (int q = 0; q < 8; ++q) {          // this lane's half of the row: channels 32*hh + 4q .. +3
                     const uint2 a = *reinterpret_cast<const uint2*>(p00 + 4 * q), b = *reinterpret_cast<const uint2*>(p01 + 4 * q);
@@ -334,6 +348,15 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
         __syncthreads();
         wload(tap < 7 ? tap + 2 : 8);
     }
+    if (!MB || ++blk == nblk) break;
+    // next 64-channel block: everybody is behind tap 8's barrier — the halo image (far-sample scratch included) and weight buffer 0 are free
+    hload();
+    wload(0);
+    hstore();
+    wstore(0);
+    __syncthreads();
+    wload(1);
+    }   // channel blocks
 
     BM_STAMP(3);
     // ---- epilogue: lane = pixel, registers = 4 consecutive channels per (block, quad): ReLU, 8-byte stores (the bias was the initial value) ----
@@ -379,30 +402,32 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_bm_kernel(const BmGeom g) {
 
 bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld) {
     static const bool disabled = getenv("CN_DISABLE_DCN_BM") != nullptr || getenv("CN_DISABLE_DCN_FWD_BM") != nullptr;
-    return !disabled && Ci == 64 && x_ld == 64 && om_ld == 32 && (Co == 64 || Co == 32) && y_ld == Co;
+    static const bool no_blocks = getenv("CN_DCN_FWD_BM_ONE_BLOCK") != nullptr;      // A/B: Ci = 128 / 256 on the gather kernel as before round 5
+    return !disabled && (Ci == 64 || (!no_blocks && (Ci == 128 || Ci == 256))) && x_ld == Ci && om_ld == 32 && (Co == 64 || Co == 32) && y_ld == Co;
 }
 
 // returns false when the shape is not handled here (caller falls back to the gather / LDS-tile kernels)
 bool dcn_fwd_bm_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
                        int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st) {
-    if (!dcn_fwd_bm_shape_ok(Ci, x_ld, Co, y_ld, om_ld) || bias == nullptr || ((uintptr_t)om & 15) || ktot != 9 * 64 || N > 65535) return false;
+    if (!dcn_fwd_bm_shape_ok(Ci, x_ld, Co, y_ld, om_ld) || bias == nullptr || ((uintptr_t)om & 15) || ktot != 9 * Ci || N > 65535) return false;
     if (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) return false;
     if ((uintptr_t)bias & 15) return false;
     BmGeom g;
     g.x = (const bf16_t*)x; g.om = om; g.wp = (const bf16_t*)wp; g.bias = bias; g.y = (bf16_t*)y;
-    g.N = N; g.H = H; g.W = W; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.Co = Co; g.relu = relu;
+    g.N = N; g.H = H; g.W = W; g.x_ld = x_ld; g.y_ld = y_ld; g.om_ld = om_ld; g.ktot = ktot; g.Co = Co; g.relu = relu; g.Ci = Ci;
     g.bn_part = bn_part; g.bn_slots = bn_slots;
     if (bn_part) mark_taken(bn_taken);
     const dim3 grid(((H + BM_TH - 1) / BM_TH) * ((W + BM_TW - 1) / BM_TW), N);
+#define CN_FWDBM(NCB_, MB_, SMEM_) do { (void)hipFuncSetAttribute((const void*)dcn_fwd_bm_kernel<NCB_, MB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SMEM_)); \
+                                        hipLaunchKernelGGL((dcn_fwd_bm_kernel<NCB_, MB_>), grid, dim3(256), (SMEM_), st, g); } while (0)
     if (Co == 64) {
         const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 64 * 16) + 512 + 4 * 32 * 29 * 4;
-        (void)hipFuncSetAttribute((const void*)dcn_fwd_bm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(dcn_fwd_bm_kernel<2>, grid, dim3(256), smem, st, g);
+        if (Ci > 64) CN_FWDBM(2, true, smem); else CN_FWDBM(2, false, smem);
     } else {
         const size_t smem = (size_t)BM_WR * BM_WC * BM_PIXB + 2 * (4 * 2 * 32 * 16) + 512 + 4 * 32 * 29 * 4;
-        (void)hipFuncSetAttribute((const void*)dcn_fwd_bm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(dcn_fwd_bm_kernel<1>, grid, dim3(256), smem, st, g);
+        if (Ci > 64) CN_FWDBM(1, true, smem); else CN_FWDBM(1, false, smem);
     }
+#undef CN_FWDBM
     return true;
 }
 

@@ -143,6 +143,9 @@ if __name__ == "__main__":
     for (N, H, W, Co) in [(2, 16, 32, 64), (1, 13, 21, 64), (1, 8, 16, 32)]:
         for sigma in (0.0, 0.5, 1.5, 4.0):
             worst = max(worst, check(N, H, W, 64, Co, sigma))
+    for Ci in (128, 256):                              # channel blocks of x one after the other (round 5)
+        for sigma in (0.0, 1.5, 4.0):
+            worst = max(worst, check(2, 16, 32, Ci, 64, sigma))
     print("worst rel err", worst)
     worst = 0.0
     for (N, H, W, Ci) in [(2, 16, 32, 64), (1, 13, 21, 64), (1, 8, 16, 32)]:
