@@ -739,6 +739,11 @@ extern "C" int cn_dcn_fwd_h(const void* x, const float* om, const void* wp, cons
         CN_LAUNCH_CHECK("cn_dcn_fwd(gs)");
         return CN_OK;
     }
+    if (dtype == CN_BF16 && dcn_fwd_b2_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
+                                              sink.slots, taken, (hipStream_t)stream)) {
+        CN_LAUNCH_CHECK("cn_dcn_fwd(b2)");
+        return CN_OK;
+    }
     if (dtype == CN_BF16 && dcn_fwd_bm_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
                                               sink.slots, taken, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_fwd(bm)");
