@@ -367,8 +367,8 @@ __global__ __launch_bounds__(512, 4) void dcn_fwd_b2_kernel(const B2Geom g) {
 
 bool dcn_fwd_b2_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld, int H, int W) {
     static const bool disabled = getenv("CN_DISABLE_DCN_B2") != nullptr || getenv("CN_DISABLE_DCN_FWD_B2") != nullptr;
-    // 16x16 tiles: below 64x64 maps a batch-64 launch has fewer workgroups than the chip has slots (2 per CU) — the 8x16 kernel stays
-    static const int min_hw = [] { const char* e = getenv("CN_DCN_B2_MIN_HW"); return e ? atoi(e) : 64 * 64; }();
+    // 16x16 tiles: measured ahead of the 8x16 kernel down to 32x32 maps at batch 64 (256->64 @32^2: 74 vs 88 us); 16x16 maps stay there
+    static const int min_hw = [] { const char* e = getenv("CN_DCN_B2_MIN_HW"); return e ? atoi(e) : 32 * 32; }();
     return !disabled && (Ci == 64 || Ci == 128 || Ci == 256) && x_ld == Ci && om_ld == 32 && Co == 64 && y_ld == Co && H * W >= min_hw;
 }
 
@@ -400,3 +400,4 @@ bool dcn_fwd_b2_launch(const void* x, const float* om, const void* wp, const flo
     }
     return true;
 }
+
