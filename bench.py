@@ -124,7 +124,10 @@ def _kernel_name(hip, name, a, tn):
     if name in dcn and tn == "bf16":
         entry, pick = dcn[name]
         Ci, Co = pick(a)
-        v = hip.lib().cn_dcn_variant(entry, int(Ci), int(Co))
+        H, W = (a[2], a[3]) if name == "cn_dcn_bwd_dom" else (a[1], a[2])
+        v = hip.lib().cn_dcn_variant_hw(entry, int(Ci), int(Co), int(H), int(W))
+        if entry == 0 and v == 5000000:
+            return "dcn_fwd_b2_kernel"
         if entry == 0:
             return (f"dcn_fwd_bm_kernel<{v - 1000000}>" if v < 2000000 else f"dcn_fwd_tile_kernel<{v - 2000000}>" if v < 3000000
                     else f"dcn_fwd_kernel<bf16,{(v - 3000000) // 1000},{v % 1000}>")
@@ -230,23 +233,43 @@ def pmc_traffic(kernel):
     return None
 
 
-def rocprof_avg_us(kernel):
-    """Average duration of `kernel` in the newest committed rocprofv3 kernel-trace summary of this bench command
-    (profiles/rNN_bench_kernel_stats.txt: launches of the replayed steps, i.e. WITH the other stream's kernels next to it) — the
-    number the judge can check `roofline.avg_launch_us` (HIP events around eager, serialised launches) against."""
+def _norm_kernel(name):
+    """rocprofv3's and _kernel_name()'s spellings of a template on common ground: no spaces, no `void`, bf16 = unsigned short"""
+    return name.replace("void ", "").replace(" ", "").replace("bf16", "unsignedshort").replace("f32", "float")
+
+
+def rocprof_avg_us(kernel, args):
+    """Average duration of `kernel` in the committed rocprofv3 kernel-trace summary of THIS bench command on THIS build, or None.
+    The summary (profiles/rNN_bench_kernel_stats.txt) is only used when its sidecar (profiles/rNN_bench_trace_meta.json, written by
+    tools/trace_meta.py next to the trace) says that (a) the traced command had the same --arch / --batch / --size / --dtype /
+    --dcn-offsets, (b) every kernel source under csrc/ still has the git blob hash it had when the trace was taken, and (c) exactly
+    ONE instantiation in the summary carries the full template name bench.py derives for the launch (`dcn_dom_bm_kernel<64` never
+    borrows the duration of `<128, true>`).  Otherwise the line keeps the live HIP-event number alone (round-5 ADVICE, medium)."""
     import glob
     import re
     root = os.path.dirname(os.path.abspath(__file__))
-    for fn in sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_kernel_stats.txt")), reverse=True):
+    want = {"arch": args.arch, "batch": args.batch, "size": args.size, "dtype": args.dtype, "dcn_offsets": args.dcn_offsets}
+    for mf in sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_trace_meta.json")), reverse=True):
         try:
-            best = None
-            for ln in open(fn):
+            with open(mf) as f:
+                meta = json.load(f)
+            if meta.get("cmd_args") != want:
+                continue
+            if any(_git_blob_sha(os.path.join(root, src)) != sha for src, sha in meta["sources"].items()):
+                continue
+            key = _norm_kernel(kernel).rstrip(">")
+            hits = []
+            for ln in open(os.path.join(root, meta["stats_file"])):
                 m = re.match(r"^(?:void )?(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s+[\d.]+\s+[\d.]+%", ln)
-                if m and kernel.split("<")[0] in m.group(1) and (best is None or int(m.group(2)) > best[1]):
-                    best = (m.group(1).strip(), int(m.group(2)), float(m.group(4)))
-            if best:
-                return {"file": os.path.relpath(fn, root), "kernel": best[0], "calls": best[1], "avg_us": best[2]}
-        except OSError:
+                if not m:
+                    continue
+                nm = _norm_kernel(m.group(1).strip())
+                if nm == key + ">" or nm.startswith(key + ",") or (("<" not in key) and nm.startswith(key + "<")) or nm == key:
+                    hits.append((m.group(1).strip(), int(m.group(2)), float(m.group(4))))
+            if len(hits) == 1:
+                return {"file": meta["stats_file"], "kernel": hits[0][0], "calls": hits[0][1], "avg_us": hits[0][2],
+                        "meta": os.path.relpath(mf, root)}
+        except (OSError, KeyError, ValueError):
             continue
     return None
 
@@ -272,9 +295,11 @@ def pmc_sq(kernel):
     return None
 
 
-def inference_rate(model, x, steps=20):
+def inference_rate(model, x, steps=20, materialise=False):
     """The north-star inference figure, driver-timed: eval forward (BN folded into the conv epilogues) + sigmoid + ctdet_decode of
-    the SAME config (same weights, batch, resolution, bf16), one hipGraph, `steps` replays between two synchronisations."""
+    the SAME config (same weights, batch, resolution, bf16), one hipGraph, `steps` replays between two synchronisations.
+    materialise: the reference's test_step_end (centernet_detection.py:183-187) leaves `sigmoid_()` in out["heatmap"]; this variant
+    writes that map (sigmoid_clamped: one more pass over the 335 MB tensor) and decodes from it instead of from the logits."""
     from centernet_amd.decode.ctdet import ctdet_decode
     from centernet_amd.utils.decode import sigmoid_clamped
     was_training = model.training
@@ -283,6 +308,9 @@ def inference_rate(model, x, steps=20):
     def infer():
         with torch.no_grad():
             out = model(x)[-1]
+            if materialise:
+                out["heatmap"] = sigmoid_clamped(out["heatmap"])
+                return ctdet_decode(out["heatmap"], out["width_height"], reg=out["regression"])
             # sigmoid + clamp applied by the top-K kernel on load (cn_ctdet_decode_logits): bit-identical detections to
             # ctdet_decode(sigmoid_clamped(hm), ...), without the separate pass over the 335 MB map
             return ctdet_decode(out["heatmap"], out["width_height"], reg=out["regression"], logits_clamp=1e-4)
@@ -404,6 +432,46 @@ def set_trained_offsets(model, seed=4321):
     return n
 
 
+def _smi_start():
+    """rocm-smi clocks + power, started asynchronously (the timed loop does not wait for it); -> Popen | None"""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if not exe:
+        return None
+    try:
+        return subprocess.Popen([exe, "-d", "0", "--showclocks", "--showpower", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except OSError:
+        return None
+
+
+def _smi_collect(p):
+    """-> {"sclk_mhz": ..., "mclk_mhz": ..., "power_w": ...} (whatever rocm-smi reported) | None"""
+    if p is None:
+        return None
+    try:
+        out, _ = p.communicate(timeout=20)
+        card = next(iter(json.loads(out).values()))
+    except Exception:      # noqa: BLE001 - a box without a working rocm-smi must not lose the headline
+        return None
+    import re
+    rec = {"when": "sampled once during the second timed block"}
+    for k, v in card.items():
+        kl = k.lower()
+        m = re.search(r"([\d.]+)\s*mhz", str(v).lower())
+        if "sclk" in kl and m:
+            rec["sclk_mhz"] = float(m.group(1))
+        elif "mclk" in kl and m:
+            rec["mclk_mhz"] = float(m.group(1))
+        elif "power" in kl and "(w)" in kl:
+            try:
+                rec["power_w"] = float(v)
+            except ValueError:
+                pass
+    rec["raw"] = {k: str(v)[:40] for k, v in list(card.items())[:12]}
+    return rec
+
+
 def timed_steps(step, batch, steps, warmup, fence):
     for _ in range(warmup):
         step(batch)
@@ -489,6 +557,7 @@ def main():
     ap.add_argument("--stamps", action="store_true",
                     help="capture four device wall-clock stamps (cn_stamp) into the step's graph: where the launch-stream chain and the "
                          "weight-gradient stream end in a REPLAYED step, no profiler attached -> `stream_tail` in the line")
+    ap.add_argument("--blocks", type=int, default=3, help="back-to-back timed blocks of --steps steps; the median block is reported")
     ap.add_argument("--probe-steps", type=int, default=2)
     ap.add_argument("--probe-detail", default=None, help="write a per-shape table of every launch of a step to this file")
     args = ap.parse_args()
@@ -568,24 +637,38 @@ def main():
 
     for _ in range(args.warmup):
         step(batch)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(batch)
-    fence()
+    # The timed region: `--blocks` (default 3) back-to-back blocks of EXACTLY --steps steps, each bracketed by barrier + synchronize on
+    # both sides, each reduced to the slowest rank's time.  `value` / `ms_per_step` are the MEDIAN block (box-to-box and run-to-run
+    # spread is +-2 %, larger than most single changes: round-5 VERDICT #4); every block's time is in the line (`blocks_ms_per_step`,
+    # `value_min` / `value_max`), so ms_per_step x steps is the duration of one real, contiguous block of the run.
+    block_s, smi = [], None
+    for b in range(max(1, args.blocks)):
+        fence()
+        if b == 1 and rank == 0:
+            smi = _smi_start()                      # clocks / power while the GPU is under this load (sampled once, asynchronously)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step(batch)
+        fence()
+        e = time.perf_counter() - t0
+        if dist.is_initialized():
+            t = torch.tensor([e], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)     # the slowest rank's time
+            block_s.append((float(t.item()), e))
+        else:
+            block_s.append((e, e))
     if feed is not None:
         step = run
-    elapsed = time.perf_counter() - t0
+    order = sorted(range(len(block_s)), key=lambda i: block_s[i][0])
+    mid = order[(len(order) - 1) // 2]                  # the median block (the lower one of an even count)
+    elapsed, mine_s = block_s[mid]
     ranks_info = None
     if dist.is_initialized():
         # value = all ranks' images / the SLOWEST rank's time; each rank's own rate and the world the backend itself reports go
         # into the line next to it (all_gather over RCCL: the collective path is exercised even when a rank's step is local)
-        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        mine = torch.tensor([mine_s], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        t = mine.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         ranks_info = {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size(),
                       "per_rank_images_per_s": [round(args.batch * args.steps / float(e.item()), 2) for e in every]}
     det = step.post_out
@@ -626,12 +709,16 @@ def main():
     inference = None
     if rank == 0 and world == 1 and not args.no_inference and args.host_input == "none":
         dt_inf = inference_rate(model, x)
+        dt_mat = inference_rate(model, x, materialise=True)
         inference = {"metric": "images/sec (eval forward + ctdet_decode), same config", "value": round(args.batch / dt_inf, 1),
                      "unit": "images/s", "ms_per_batch": round(dt_inf * 1e3, 3), "launch": "hipGraph replay", "dtype": args.dtype,
                      "target": 3000.0,
                      "decode": "fused logits decode (cn_ctdet_decode_logits: sigmoid + clamp applied by the top-K kernel on load, detections "
                                "bit-identical to decode/ctdet.py:6-38); the sigmoid heat map itself is NOT materialised in the timed region "
-                               "(the reference's test_step leaves it in out['heatmap'])"}
+                               "(the reference's test_step leaves it in out['heatmap']) - `materialised_heatmap` is the rate with it written",
+                     "materialised_heatmap": {"value": round(args.batch / dt_mat, 1), "unit": "images/s", "ms_per_batch": round(dt_mat * 1e3, 3),
+                                              "what": "same graph with out['heatmap'] = sigmoid_clamped(logits) stored (as centernet_detection.py:183-187 "
+                                                      "leaves it) and ctdet_decode reading that map: the figure comparable with the reference's test step"}}
 
     # ---- secondary measurements (single GPU only; never `value`) ----
     extras = {}
@@ -740,12 +827,14 @@ def main():
                               "flop_per_byte": round(v[0] / v[3], 1)})
                 return r
 
-            # The line leads with the number a reader can recompute from the committed trace: the kernel's average duration in the
-            # newest profiles/rNN_bench_kernel_stats.txt (replayed steps, the other stream's kernels next to it).  The HIP-event time of
-            # the serialised eager launches measured here is kept as *_eager (it ran 11 % optimistic in round 4: 341 vs 378 us).
-            rp = rocprof_avg_us(kern)
-            t_launch = rp["avg_us"] * 1e-6 if rp else tt / n
+            # `frac` / `achieved` are measured by THIS run: HIP events around the dominant template's launches of the eagerly launched probe
+            # steps (round-5 ADVICE, medium: the committed trace is a cross-check, not the source).  `rocprof` carries the same kernel's
+            # average duration in the committed rocprofv3 summary of this command (replayed steps, the other stream's kernels next to
+            # it) when that summary provably belongs to this build and these arguments (rocprof_avg_us), with `frac_trace` from it.
+            rp = rocprof_avg_us(kern, args)
+            t_launch = tt / n
             ach_t, gbps_t = fl / n / t_launch / 1e12, nbytes / n / t_launch / 1e9
+            t_trace = rp["avg_us"] * 1e-6 if rp else None
             # which roof is the nearer one is a label, not a finding: when neither is close the kernel is bound by instruction issue
             # around its MFMAs, and the machine-readable field says so (SQ counters of the committed pass next to it)
             far = max(gbps_t / PEAK_HBM_GBPS, ach_t / peak) < 0.25
@@ -757,9 +846,10 @@ def main():
                     "achieved": round(gbps_t, 1) if hbm_bound else round(ach_t, 2),
                     "peak": PEAK_HBM_GBPS if hbm_bound else peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round(gbps_t / PEAK_HBM_GBPS, 4) if hbm_bound else round(ach_t / peak, 4),
-                    "frac_from": "rocprof.avg_us (committed kernel trace)" if rp else "avg_launch_us (HIP events, eager launches: no committed trace found)",
-                    "achieved_eager": round(gbps, 1) if hbm_bound else round(ach, 2),
-                    "frac_eager": round(gbps / PEAK_HBM_GBPS, 4) if hbm_bound else round(ach / peak, 4),
+                    "frac_from": "avg_launch_us (HIP events around this run's own launches of the dominant template)",
+                    "achieved_trace": (None if not rp else round(nbytes / n / t_trace / 1e9, 1) if hbm_bound else round(fl / n / t_trace / 1e12, 2)),
+                    "frac_trace": (None if not rp else round(nbytes / n / t_trace / 1e9 / PEAK_HBM_GBPS, 4) if hbm_bound
+                                   else round(fl / n / t_trace / 1e12 / peak, 4)),
                     "traffic": pmc_traffic(kern),
                     "rocprof": rp,
                     "how": f"HIP events around each launch, {args.probe_steps} eagerly launched step(s) of the same workload right after "
@@ -787,6 +877,10 @@ def main():
         line = {"metric": "images/sec (train step + decode) DLA-34 512\u00d7512 bs=64 at 1/2/4/8 MI355X",
                 "value": round(total_images / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+                "blocks": len(block_s), "blocks_ms_per_step": [round(b[0] / args.steps * 1e3, 3) for b in block_s],
+                "value_min": round(total_images / max(b[0] for b in block_s), 2), "value_max": round(total_images / min(b[0] for b in block_s), 2),
+                "value_is": f"median of {len(block_s)} back-to-back blocks of {args.steps} steps, each bracketed by barrier + synchronize",
+                "gpu_state": _smi_collect(smi),
                 "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" if args.host_input == "none" else f"synthetic, pinned host input ({args.host_input}) copied inside the timed region",
                 "config": {"workload": f"{args.arch} ctdet (80 classes) train step (fwd+loss+bwd+Adam) + ctdet_decode, "
                                        f"{args.size}x{args.size}, batch {args.batch}/GPU, {args.dtype} compute / fp32 master weights",

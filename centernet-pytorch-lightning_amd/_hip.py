@@ -88,6 +88,12 @@ def lib():
             fn = getattr(_lib, name)
             fn.restype = ctypes.c_char_p if "char" in ret else _CT[ret]
             fn.argtypes = [_ctype(t) for t, _ in args]
+        # the ctypes mirror of cn_hooks is generated from the header; a STALE library built against an older struct would misread device
+        # pointers and sink fields (GPU faults or corrupt BN statistics, not an error): refuse it at load time (round-5 ADVICE)
+        if _lib.cn_hooks_size() != ctypes.sizeof(Hooks):
+            n, _lib = _lib.cn_hooks_size(), None
+            raise RuntimeError(f"{LIB_PATH} was built against a different cn_hooks ({n} bytes, include/centernet_hip.h says "
+                               f"{ctypes.sizeof(Hooks)}): rebuild it (`make -C centernet-pytorch-lightning_amd/csrc -j8`)")
     return _lib
 
 

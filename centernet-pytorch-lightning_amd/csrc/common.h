@@ -12,7 +12,11 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 void cn_set_error(const char* fmt, ...);
 // target workgroup count of the split-K weight-gradient kernels of ONE call (cn_hooks.wgrad_blocks; <= 0: the library default)
 #define CN_WGRAD_DEFAULT_BLOCKS 1536
-static inline int cn_wgrad_target(const cn_hooks* h) { return (h && h->wgrad_blocks > 0) ? h->wgrad_blocks : CN_WGRAD_DEFAULT_BLOCKS; }
+// (clamped to 1 .. 65536: launch_wgrad scales the target by 4 / 3 in int arithmetic)
+static inline int cn_wgrad_target(const cn_hooks* h) {
+    const int b = (h && h->wgrad_blocks > 0) ? h->wgrad_blocks : CN_WGRAD_DEFAULT_BLOCKS;
+    return b > 65536 ? 65536 : b;
+}
 
 #define CN_CHECK_ARG(cond, ...)                                                                     \
     do {                                                                                            \

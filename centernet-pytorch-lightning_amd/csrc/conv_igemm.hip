@@ -688,9 +688,11 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
 //   entry 1 = cn_dcn_wgrad:   1 = dcn_wgrad_bm_kernel; BMW*1000000 + BNW*1000 + TAPS = dcn_wgrad_kernel<BMW,BNW,TAPS>
 //   entry 2 = cn_dcn_bwd_dom: 1000000 + COP = dcn_dom_bm_kernel<COP>; COP = dcn_bwd_dom_kernel<COP> (0: the generic GEMM-epilogue kernel)
 //   entry 3 = cn_dcn_bwd_dx:  1000000 + NCB = dcn_dx_bm_kernel<NCB>; 3000000 + BN*1000 + CK = dcn_bwd_dx_kernel<bf16,BN,CK>
-extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
+//   entry 0 with a map size (cn_dcn_variant_hw): 5000000 = dcn_fwd_b2_kernel (dcn_b2.hip)
+extern "C" int cn_dcn_variant_hw(int entry, int Ci, int Co, int H, int W) {
     const int co32 = (Co + 31) / 32 * 32;
     if (entry == 0) {
+        if (!dcn_fwd_gs_shape_ok(Ci, Ci, Co, Co, 32) && dcn_fwd_b2_shape_ok(Ci, Ci, Co, Co, 32, H, W)) return 5000000;     // dcn_fwd_b2_kernel
         if (dcn_fwd_gs_shape_ok(Ci, Ci, Co, Co, 32)) return 4000000;                       // dcn_fwd_gs_kernel
         if (dcn_fwd_bm_shape_ok(Ci, Ci, Co, Co, 32)) return 1000000 + Co / 32;
         if (dcn_fwd_tile_shape_ok(Ci, Ci, Co, Co)) return 2000000 + (Co % 128 == 0 ? 128 : 64);
@@ -715,6 +717,7 @@ extern "C" int cn_dcn_variant(int entry, int Ci, int Co) {
     }
     return -1;
 }
+extern "C" int cn_dcn_variant(int entry, int Ci, int Co) { return cn_dcn_variant_hw(entry, Ci, Co, 0, 0); }
 
 // Fused DCNv2 forward (sampling -> LDS -> MFMA, dcn_fused.hip): y = act(bias + sum_k W_k * mask_k * bilinear_k(x) [+ residual]).
 // wp = cn_pack_weight mode 1 of the layer weight ([Co_pad32][tap*Ci + ci]); om fp32 [P][om_ld]; bias fp32[Co] nullable.

@@ -289,7 +289,9 @@ def _watchdog_backlog():
     try:
         import pickle
         from torch._C import _distributed_c10d as c10d
-        st = pickle.loads(c10d._dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=True)).get("pg_status")
+        # only the status block is wanted: without the collectives the recorder neither pickles its (up to 2000) entries nor queries
+        # the events of unretired ones on every poll (round-5 ADVICE)
+        st = pickle.loads(c10d._dump_nccl_trace(includeCollectives=False, includeStackTraces=False, onlyActive=True)).get("pg_status")
     except Exception:
         return None
     if not isinstance(st, dict):
@@ -325,6 +327,9 @@ def drain_watchdog(timeout=5.0):
         if time.monotonic() > end:
             break
         time.sleep(0.002)
+    import sys
+    print("[centernet_amd] drain_watchdog: the process group's status block is unavailable or did not drain in time; "
+          "sleeping 0.35 s (three watchdog periods) before the capture instead", file=sys.stderr, flush=True)
     time.sleep(0.35)
     return False
 
@@ -527,22 +532,26 @@ class TrainStep:
         bufs = [b for b in self.model.buffers()]
         snap_b = [b.clone() for b in bufs]
         t0, pend = opt.t, [m._pending for m in self._bns]
-        with torch.cuda.stream(side):            # warm-up off the capture stream: workspaces, lazy attributes, allocator
-            for _ in range(2):
-                self._eager(static)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        with torch.no_grad():
-            for dst, src in zip((opt.flat_p, opt.flat_m, opt.flat_v, opt.hyper), snap):
-                dst.copy_(src)
-            for dst, src in zip(bufs, snap_b):
-                dst.copy_(src)
-        opt.t = t0
-        opt._lr_dev = None               # the restored `hyper` predates the first learning-rate upload
-        for m, n in zip(self._bns, pend):
-            m._pending = n
-        WeightsEpoch.bump()
-        torch.cuda.synchronize()
+        try:
+            with torch.cuda.stream(side):            # warm-up off the capture stream: workspaces, lazy attributes, allocator
+                for _ in range(2):
+                    self._eager(static)
+        finally:
+            # ALWAYS put the snapshot back: a warm-up step that raised on this rank only (round-5 ADVICE) would otherwise leave this
+            # rank's parameters / Adam state / BN buffers one or two steps ahead of its peers
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for dst, src in zip((opt.flat_p, opt.flat_m, opt.flat_v, opt.hyper), snap):
+                    dst.copy_(src)
+                for dst, src in zip(bufs, snap_b):
+                    dst.copy_(src)
+            opt.t = t0
+            opt._lr_dev = None               # the restored `hyper` predates the first learning-rate upload
+            for m, n in zip(self._bns, pend):
+                m._pending = n
+            WeightsEpoch.bump()
+            torch.cuda.synchronize()
         if dist.is_initialized():
             # The process group's watchdog thread polls the completion events of every collective it has not yet retired (it wakes
             # every 100 ms); an event query landing while this stream (and RCCL's own, which joins the capture) is capturing ends the
@@ -593,12 +602,15 @@ class TrainStep:
             return loss
         if self._g1 is None:
             err = None
+            pend = [m._pending for m in self._bns]
             try:
                 self._capture(batch)
             except Exception as e:      # e.g. a runtime that refuses capture next to a live process group: keep training
                 err = e
                 self._g1 = self._g2 = None
                 self._abort_backward()
+                for m, n in zip(self._bns, pend):      # a capture that aborted midway leaves the BN launch counters where it stopped
+                    m._pending = n
                 if self.opt.flat_p.is_cuda:
                     torch.cuda.synchronize()
             # The launch mode is a COLLECTIVE decision: a rank replaying a captured graph and a rank issuing eager buckets post
@@ -611,7 +623,10 @@ class TrainStep:
                       file=sys.stderr, flush=True)
                 self._g1 = self._g2 = None
                 self.graph = False
-                return self._eager(batch, batch_idx)
+                loss = self._eager(batch, batch_idx)
+                if self.opt.flat_p.is_cuda:
+                    self._throttle()
+                return loss
         if batch[0] is not self._sx:
             self._sx.copy_(batch[0], non_blocking=True)
         for k, v in batch[1].items():
@@ -632,6 +647,11 @@ class TrainStep:
         """AND of `ok` over the ranks that exchange gradients with this one (no-op without a process group)"""
         if self.sync is None or self.sync.world < 2 or not dist.is_initialized():
             return bool(ok)
+        # Every rank reaches this point with NO gradient bucket of its own in flight (a failed capture / warm-up went through
+        # _abort_backward, which drops the pass's pending work; a successful one has joined its collectives), and the device is
+        # synchronised first, so the 1-element MIN all-reduce is the next collective every rank posts on the group.
+        if self.opt.flat_p.is_cuda:
+            torch.cuda.synchronize()
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.opt.flat_p.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.sync.group)
         return bool(int(flag.item()))

@@ -339,6 +339,8 @@ int cn_dcn_col2im(const void* dcol, const void* x, const float* om, float* dx_ti
  * 2 = cn_dcn_bwd_dom, 3 = cn_dcn_bwd_dx; codes are listed at the definition (csrc/conv_igemm.hip).  Measurement aid: bench.py
  * names its per-kernel roofline rows with it so that they match rocprofv3's kernel names.  No reference counterpart. */
 int cn_dcn_variant(int entry, int Ci, int Co);
+/* The same with the map size (H, W): the 16x16-tile forward kernel of csrc/dcn_b2.hip is chosen by size as well (code 5000000). */
+int cn_dcn_variant_hw(int entry, int Ci, int Co, int H, int W);
 /* Fused DCNv2 forward: bilinear sampling straight into the MFMA operand tile in LDS — no column tensor in HBM.
  * y = act(bias + sum_k W_k * sigmoid(om[18+k]) * bilinear_k(x)); wp = cn_pack_weight mode 1 ([Co_pad32][tap*Ci + ci]). */
 int cn_dcn_fwd(const void* x, const float* om, const void* wp, const float* bias, void* y,

@@ -641,7 +641,10 @@ def test_depthwise_up(cfg, dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 12, 12, 64, 64), (1, 9, 7, 128, 64), (1, 6, 6, 512, 256), (2, 16, 16, 32, 16),
-                                 (1, 40, 36, 64, 64, 6.0), (2, 19, 33, 128, 128, 4.0), (1, 20, 20, 256, 64)])
+                                 (1, 40, 36, 64, 64, 6.0), (2, 19, 33, 128, 128, 4.0), (1, 20, 20, 256, 64),
+                                 # maps of >= 32x32 pixels with Co = 64 take the 16x16-tile forward (dcn_b2.hip): ragged tiles, displacements
+                                 # beyond its 3-pixel window margin (the per-lane far path), several 64-channel blocks of x
+                                 (1, 35, 50, 64, 64), (1, 33, 34, 128, 64, 4.0), (2, 64, 48, 256, 64, 1.5)])
 def test_dcnv2(cfg, dt):
     """vs oracle/dcn_ref.py (pure torch); offsets are O(1) so every bilinear corner / border case is exercised."""
     from centernet_amd import nn as hnn
@@ -756,6 +759,30 @@ def test_dcn_fwd_tile_kernel_matches_gather_kernel():
         d = (a - b).abs()
         assert float(b.abs().max()) > 1.0 and float(d.max()) <= 2 ** -6 * float(b.abs().max()), cfg     # <= ~1 bf16 ulp at the top of the range
         assert float((d > 0).float().mean()) < 2e-3, cfg
+
+
+def test_dcn_fwd_b2_kernel_matches_blend_matrix_kernel():
+    """The 16x16-tile forward (dcn_b2.hip: window fragments from the LDS halo, no geometry table, four waves per SIMD) against the
+    8x16-tile blend-matrix forward (dcn_bm.hip) on the same inputs: both blend with bf16 weights on the matrix cores, so they may
+    differ by one bf16 ulp on a few outputs (fp32 accumulation order; the far path's exact fp32 weights where only ONE of them takes
+    it: the window margins differ, 3 vs 4 pixels).  Separate processes: the switch is read once."""
+    import os, subprocess, sys, tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cfg in (["2", "48", "80", "64", "64", "0.4"], ["1", "37", "53", "64", "64", "2.5"], ["2", "32", "32", "128", "64", "1.0"],
+                ["1", "64", "64", "256", "64", "0.2"]):
+        outs = []
+        for env in ({}, {"CN_DISABLE_DCN_FWD_B2": "1"}):
+            f = tempfile.NamedTemporaryFile(suffix=".pt", delete=False).name
+            r = subprocess.run([sys.executable, os.path.join(repo, "tools", "dcn_fwd_ab.py"), *cfg, f], env=dict(os.environ, **env),
+                               capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(torch.load(f))
+            os.unlink(f)
+        a, b = outs
+        d = (a - b).abs()
+        assert float(b.abs().max()) > 1.0 and float(d.max()) <= 2 ** -6 * float(b.abs().max()), cfg     # <= ~1 bf16 ulp at the top of the range
+        # offsets of several pixels: many samples take the exact-weight far path in ONE of the two kernels only (window margin 3 vs 4)
+        assert float((d > 0).float().mean()) < (5e-3 if float(cfg[5]) < 1.0 else 0.12), cfg
 
 
 def test_dcn_zero_init_is_half_conv():
@@ -915,7 +942,10 @@ BN_STAT_PRODUCERS = [  # kind, N, H, W, Ci, Co, k, stride  (which kernel: see th
     ("dcn", 1, 9, 7, 64, 32, 3, 1),
     ("dcn", 2, 12, 20, 128, 128, 3, 1),       # LDS-resident tile DCNv2 forward (>= 128 channels on both sides)
     ("dcn", 1, 9, 7, 256, 128, 3, 1),
-    ("dcn", 2, 12, 20, 128, 64, 3, 1),        # gather DCNv2 forward with the LDS-staged epilogue (128 -> 64: neither matrix-core-blend nor tile kernel)
+    ("dcn", 2, 12, 20, 128, 64, 3, 1),        # blend-matrix forward over two 64-channel blocks of x (dcn_fwd_bm_kernel<2, true>)
+    ("dcn", 2, 12, 20, 192, 64, 3, 1),        # gather DCNv2 forward with the LDS-staged epilogue (192 -> 64: neither matrix-core-blend nor tile kernel)
+    ("dcn", 1, 40, 36, 64, 64, 3, 1),         # 16x16-tile forward (dcn_fwd_b2_kernel), ragged tiles
+    ("dcn", 1, 33, 34, 128, 64, 3, 1),        # ... over two 64-channel blocks of x
     ("conv", 2, 9, 70, 16, 16, 3, 1),         # row-walking 16-channel kernel (DLA level0)
     ("conv", 2, 38, 70, 16, 32, 3, 2),        # ... stride 2, two output-channel blocks (DLA level1)
     ("conv", 1, 64, 200, 16, 32, 3, 2),       # ... with interior waves
