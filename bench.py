@@ -217,7 +217,7 @@ def pmc_traffic(kernel):
     collected in separate rocprofv3 --pmc runs; recipe and the gfx950 correction are in the JSON).  The record is stamped with the
     git blob hash of the kernel's source file: when the source has changed since the measurement the number is stale -> None."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for fn in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(root, "profiles", fn)) as f:
                 rec = json.load(f)

@@ -20,6 +20,8 @@ KERNELS = {
     "dcn_dom_bm_kernel<64, true>": ("dcn_dom_bm_kernel<64>", CSRC + "dcn_dom_bm.hip", "offset/mask gradient of the DCN layers with 64 output channels (gathered corner pixels + dot2; round 5)"),
     "dcn_dx_bm_kernel<2>": ("dcn_dx_bm_kernel<2>", CSRC + "dcn_bm.hip", "data gradient of the 64->64 DCN layers"),
     "dcn_fwd_bm_kernel<2>": ("dcn_fwd_bm_kernel<2>", CSRC + "dcn_bm.hip", "forward of the 64->64 DCN layers"),
+    "dcn_fwd_b2_kernel<false>": ("dcn_fwd_b2_kernel", CSRC + "dcn_b2.hip", "forward of the 64->64 DCN layers, 16x16-tile kernel (round 6): 134 MB x (x 1.9 halo through L2) + 134 MB offsets + 134 MB y algorithmic"),
+    "dcn_fwd_b2_kernel<true>": ("dcn_fwd_b2_kernel<MB>", CSRC + "dcn_b2.hip", "forward of the 128->64 / 256->64 DCN layers (launch mix)"),
     "dcn_wgrad_bm_kernel": ("dcn_wgrad_bm_kernel", CSRC + "dcn_bm.hip", "weight gradient of the DCN layers (launch mix)"),
     "topk_map128_kernel": ("topk_map128_kernel<true>", CSRC + "topk_stream.h", "B=64, C=80, 128x128 fp32 maps: 335.5 MB algorithmic read (SURVEY 8d)"),
     "bn_bwd_apply_kernel<unsigned short": ("bn_bwd_apply_kernel<bf16>", CSRC + "bn.hip", "launch mix of all BN layers"),

@@ -3,7 +3,7 @@
 #   bench line + per-launch table, rocprofv3 kernel-trace summary of the same bench command, FETCH_SIZE / WRITE_SIZE of the
 #   dominant kernel in two separate counter-only passes, isolated op timings.
 # usage: tools/profile_round.sh r03
-tag=${1:-r05}
+tag=${1:-r06}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -17,7 +17,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python - <<PY >> $out/pmc_traffic_raw.txt
 import sqlite3, glob
 c = sqlite3.connect(glob.glob('$out/pmc/*.db')[0])
-for pat in ('conv3x3s1_kernel<unsigned short, 128, 64, 8, 1>', 'conv3x3_ws_kernel<64, false, 0, true, 0>', 'dcn_dom_bm_kernel<64, true>', 'dcn_dx_bm_kernel<2>', 'dcn_fwd_bm_kernel<2>', 'dcn_wgrad_bm_kernel', 'topk_map128_kernel', 'bn_bwd_apply_kernel<unsigned short', 'conv3x3_c16r_kernel<1, 1, 2>', 'conv3x3_c16r_kernel<1, 1, 0>', 'conv3x3_c16r_kernel<2, 2, 2>', 'stem7_rows_kernel', 'pack_weight_batch_kernel'):
+for pat in ('conv3x3s1_kernel<unsigned short, 128, 64, 8, 1>', 'conv3x3_ws_kernel<64, false, 0, true, 0>', 'dcn_dom_bm_kernel<64, true>', 'dcn_dx_bm_kernel<2>', 'dcn_fwd_bm_kernel<2>', 'dcn_fwd_b2_kernel<false>', 'dcn_fwd_b2_kernel<true>', 'dcn_wgrad_bm_kernel', 'topk_map128_kernel', 'bn_bwd_apply_kernel<unsigned short', 'conv3x3_c16r_kernel<1, 1, 2>', 'conv3x3_c16r_kernel<1, 1, 0>', 'conv3x3_c16r_kernel<2, 2, 2>', 'stem7_rows_kernel', 'pack_weight_batch_kernel'):
     rows = c.execute("select dispatch_id, sum(value) from counters_collection where kernel_name like ? and counter_name='$c' group by dispatch_id", ('%' + pat + '%',)).fetchall()
     print('$c', pat, 'launches', len(rows), 'avg_kib', sum(r[1] for r in rows) / max(1, len(rows)))
 PY
@@ -28,6 +28,7 @@ python tools/pmc_traffic_json.py $out/pmc_traffic_raw.txt > $out/pmc_traffic.jso
 # kernel source's blob hash), so the line of this run carries the traffic measured on this very tree
 cp $out/pmc_traffic.json profiles/${tag}_pmc_traffic.json
 [ -s $out/bench_kernel_stats.txt ] && cp $out/bench_kernel_stats.txt profiles/${tag}_bench_kernel_stats.txt    # roofline.rocprof of the line below reads it
+[ -s profiles/${tag}_bench_kernel_stats.txt ] && python tools/trace_meta.py profiles/${tag}_bench_kernel_stats.txt && cp profiles/${tag}_bench_trace_meta.json $out/     # ... only with this sidecar (args + source hashes)
 python bench.py --steps 20 --warmup 5 --probe-detail $out/ops_by_shape.txt > $out/bench.log 2>&1
 tail -1 $out/bench.log > $out/bench_line.json
 python tools/opbench.py decode bn conv > $out/opbench.txt 2>&1
