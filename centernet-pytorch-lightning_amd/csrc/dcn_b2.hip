@@ -26,11 +26,6 @@
 #define B2_PIXB 128                      // bytes per halo pixel (64 bf16)
 #define B2_NPIECE 61                     // 1 KB LDS-DMA pieces of the halo image (484 pixels = 60.5 pieces; the last one half slack)
 #define B2_XB (B2_NPIECE * 1024)
-#ifdef B2_ABL
-#define B2_ON(bit) (!(g.abl & (bit)))
-#else
-#define B2_ON(bit) true
-#endif
 #define B2_WSB 8192                      // bytes per weight buffer: [4 k-steps][2 halves][64 co][8] bf16
 
 #ifdef B2_PROBE   // development build only (tools/dev/b2_probe.py): cycle stamps of wave B2_PROBE_WAVE of the first workgroups
@@ -59,7 +54,6 @@ struct B2Geom {
     const bf16_t* x; const float* om; const bf16_t* wp; const float* bias; bf16_t* y;
     int N, H, W, x_ld, y_ld, ktot, Co, relu, Ci, tiles_w, tiles_img;
     float* bn_part; int bn_slots;
-    int abl;                             // development builds only (-DB2_ABL): ablation bit mask from CN_B2_ABL
 };
 
 // one 1 KB piece of the halo image by LDS-DMA: lane l fills physical 16-byte chunk l & 7 of pixel 8 J + (l >> 3)
@@ -179,9 +173,9 @@ __global__ __launch_bounds__(512, 4) void dcn_fwd_b2_kernel(const B2Geom g) {
         // next step's weights and geometry numbers on their way (consumed at the bottom of this iteration)
         {
             const int ns = step + 1 < nstep ? step + 1 : step;
-            if (B2_ON(2)) w_issue(ns);
+            w_issue(ns);
             const int nb = MB ? ns / 9 : 0;
-            if (B2_ON(1)) om_issue(ns - 9 * nb);
+            om_issue(ns - 9 * nb);
         }
         B2_STAMP(2 + 4 * (step % 9));
         // ---- geometry of (own pixel, tap): window position of corner 00 and the two packed weight pairs ----
@@ -233,7 +227,7 @@ __global__ __launch_bounds__(512, 4) void dcn_fwd_b2_kernel(const B2Geom g) {
                 for (int d = 0; d < 4; ++d) b[d] = t0 ? V0[d] : (t1 ? V1[d] : 0u);
                 return __builtin_bit_cast(bf16x8_t, b);
             };
-            if (rowmask != 0u && B2_ON(8)) {
+            if (rowmask != 0u) {
                 // the first touched row starts the accumulators (C = 0 is an inline constant: no 32 v_mov per tap).  (Requesting the next
                 // row's fragments before this row's MFMAs was tried: 8 more live registers spill at the 128-register cap, 280 -> 329 us.)
                 const int r = __builtin_ctz(rowmask);
@@ -251,7 +245,7 @@ __global__ __launch_bounds__(512, 4) void dcn_fwd_b2_kernel(const B2Geom g) {
                 for (int i = 0; i < 16; ++i) { st[0][i] = 0.f; st[1][i] = 0.f; }
             }
 #pragma unroll 1
-            while (rowmask && B2_ON(8)) {
+            while (rowmask) {
                 const int r = __builtin_ctz(rowmask);
                 rowmask &= rowmask - 1;
                 bf16x8_t x0, x1;
@@ -293,7 +287,6 @@ __global__ __launch_bounds__(512, 4) void dcn_fwd_b2_kernel(const B2Geom g) {
             }
             // ---- y^T[co][p] += W_k^T[co][ci] S^T[ci][p]: S^T's registers ARE the B operand (k-step s = registers 8*(s&1)..+7 of block s>>1) ----
             const unsigned char* wb = Ws + (step & 1) * B2_WSB;
-            if (B2_ON(4))
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 b2_u32x4 sb;
@@ -310,20 +303,17 @@ __global__ __launch_bounds__(512, 4) void dcn_fwd_b2_kernel(const B2Geom g) {
         B2_STAMP(5 + 4 * (step % 9));
         // ---- bottom: the next step's weights into the other buffer (last read a step ago, a barrier ago), its geometry numbers ----
         asm volatile("s_waitcnt vmcnt(2)" : "+v"(wq0), "+v"(wq1) :: "memory");      // younger: the two om loads
-        if (B2_ON(2)) w_store((step + 1) & 1);
+        w_store((step + 1) & 1);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(on_pos), "+v"(on_m) :: "memory");
-        if (B2_ON(1)) { oc_y = __uint_as_float((uint32_t)on_pos); oc_x = __uint_as_float((uint32_t)(on_pos >> 32)); oc_m = __uint_as_float(on_m); }
+        oc_y = __uint_as_float((uint32_t)on_pos); oc_x = __uint_as_float((uint32_t)(on_pos >> 32)); oc_m = __uint_as_float(on_m);
         if (MB && tap == 8 && blk + 1 < nblk) {
             // next 64-channel block of x: everybody is done with the halo image after this barrier
             __syncthreads();
             issue_halo(blk + 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (B2_ON(2)) __syncthreads();
+        __syncthreads();
     }
-#ifdef B2_ABL
-    __syncthreads();
-#endif
 
     B2_STAMP(38);
     // ---- epilogue: lane = pixel, registers = 4 consecutive channels per (block, quad): ReLU, through the wave's slice of the dead halo
@@ -385,10 +375,6 @@ bool dcn_fwd_b2_launch(const void* x, const float* om, const void* wp, const flo
     const int64_t tiles = (int64_t)g.tiles_img * N;
     if (tiles > 0x7fffffff) return false;
     g.bn_part = bn_part; g.bn_slots = bn_slots;
-    g.abl = 0;
-#ifdef B2_ABL
-    { const char* e = getenv("CN_B2_ABL"); g.abl = e ? atoi(e) : 0; }
-#endif
     if (bn_part) mark_taken(bn_taken);
     const size_t smem = (size_t)B2_XB + 2 * B2_WSB + 23 * 16;
     if (Ci > 64) {
