@@ -428,7 +428,6 @@ bool conv3x3s1_launch(const ConvGeom& g, int dtype, hipStream_t st) {
         return true;
     }
     if (conv3x3_ws_launch(g, dtype, st)) return true;  // 64 input channels, enough tiles: weight-stationary persistent kernel
-    if (conv3x3_kp_launch(g, dtype, st)) return true;  // >= 128 input channels on 16-pixel-aligned maps: K-pipelined persistent kernel (no BN statistics hook: the sink stays untaken)
     if (g.bn_part) {                                   // BN statistics sink: the LDS-staged epilogue has the hook
         if (g.epi_tile) mark_taken(g.bn_taken); else const_cast<ConvGeom&>(g).bn_part = nullptr;
     }

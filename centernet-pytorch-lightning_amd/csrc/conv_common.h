@@ -383,9 +383,6 @@ bool dcn_fwd_bm_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld);
 bool dcn_fwd_b2_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
                        int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st);   // dcn_b2.hip: 16x16 tiles, four waves per SIMD
 bool dcn_fwd_b2_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld, int H, int W);
-bool dcn_fwd_gs_launch(const void* x, const float* om, const void* wp, const float* bias, void* y, int N, int H, int W, int Ci, int x_ld,
-                       int Co, int y_ld, int om_ld, int ktot, int relu, float* bn_part, int bn_slots, int* bn_taken, hipStream_t st);   // dcn_gs.hip: gather-sample (dot2 on a pair image), W in registers
-bool dcn_fwd_gs_shape_ok(int Ci, int x_ld, int Co, int y_ld, int om_ld);
 bool dcn_dx_bm_shape_ok(int Ci, int dy_ld, int om_ld);
 bool dcn_fwd_tile_shape_ok(int Ci, int x_ld, int Co, int y_ld);
 bool dcn_wgrad_bm_shape_ok(int Ci, int x_ld, int Co, int dy_ld, int om_ld);
@@ -405,6 +402,5 @@ bool conv_c16r_launch(const ConvGeom& g, int dtype, int S, hipStream_t st);
 bool dgrad3x3s2_launch(const ConvGeom& g, int dtype, hipStream_t st);     // conv_dgrad_s2.hip: data gradient of the stride-2 3x3 convs, all four parity classes per workgroup
 bool conv3x3s2_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3.hip: the same halo-tile skeleton for the stride-2 forward convs
 bool conv3x3_ws_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3_ws.hip: 64 input channels, weights in registers
-bool conv3x3_kp_launch(const ConvGeom& g, int dtype, hipStream_t st);   // conv3x3_kp.hip: >= 128 input channels, both operands by LDS-DMA, phase-staggered waves
 bool conv1x1_stream_launch(const ConvGeom& g, int dtype, hipStream_t st); // conv1x1_stream.hip: weights in LDS, activations straight from global memory
 bool dgrad_s2_c32to16_launch(const ConvGeom& g, hipStream_t st);

@@ -684,7 +684,7 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
 
 // Which kernel template a DCNv2 entry point dispatches to for bf16 activations with the standard pitches (x_ld = Ci, y_ld = dy_ld = Co,
 // om_ld = 32); bench.py names its per-kernel roofline rows with it so that they agree with rocprofv3's kernel names.
-//   entry 0 = cn_dcn_fwd:     4000000 = dcn_fwd_gs_kernel; 1000000 + NCB = dcn_fwd_bm_kernel<NCB>; 2000000 + BN = dcn_fwd_tile_kernel<BN>; 3000000 + BN*1000 + CK = dcn_fwd_kernel<bf16,BN,CK>
+//   entry 0 = cn_dcn_fwd:     1000000 + NCB = dcn_fwd_bm_kernel<NCB>; 2000000 + BN = dcn_fwd_tile_kernel<BN>; 3000000 + BN*1000 + CK = dcn_fwd_kernel<bf16,BN,CK>
 //   entry 1 = cn_dcn_wgrad:   1 = dcn_wgrad_bm_kernel; BMW*1000000 + BNW*1000 + TAPS = dcn_wgrad_kernel<BMW,BNW,TAPS>
 //   entry 2 = cn_dcn_bwd_dom: 1000000 + COP = dcn_dom_bm_kernel<COP>; COP = dcn_bwd_dom_kernel<COP> (0: the generic GEMM-epilogue kernel)
 //   entry 3 = cn_dcn_bwd_dx:  1000000 + NCB = dcn_dx_bm_kernel<NCB>; 3000000 + BN*1000 + CK = dcn_bwd_dx_kernel<bf16,BN,CK>
@@ -692,8 +692,7 @@ extern "C" int cn_dcn_bwd_dom(const void* dy, const void* wpd2, const void* x, c
 extern "C" int cn_dcn_variant_hw(int entry, int Ci, int Co, int H, int W) {
     const int co32 = (Co + 31) / 32 * 32;
     if (entry == 0) {
-        if (!dcn_fwd_gs_shape_ok(Ci, Ci, Co, Co, 32) && dcn_fwd_b2_shape_ok(Ci, Ci, Co, Co, 32, H, W)) return 5000000;     // dcn_fwd_b2_kernel
-        if (dcn_fwd_gs_shape_ok(Ci, Ci, Co, Co, 32)) return 4000000;                       // dcn_fwd_gs_kernel
+        if (dcn_fwd_b2_shape_ok(Ci, Ci, Co, Co, 32, H, W)) return 5000000;     // dcn_fwd_b2_kernel
         if (dcn_fwd_bm_shape_ok(Ci, Ci, Co, Co, 32)) return 1000000 + Co / 32;
         if (dcn_fwd_tile_shape_ok(Ci, Ci, Co, Co)) return 2000000 + (Co % 128 == 0 ? 128 : 64);
         int bn = 32, bw = co32;
@@ -737,11 +736,6 @@ extern "C" int cn_dcn_fwd_h(const void* x, const float* om, const void* wp, cons
     g.ktot = 9 * Ci; g.co_pad = (Co + 31) / 32 * 32; g.relu = relu; g.so = 1; g.sm = 1;
     g.dcn_om = om; g.dcn_omld = om_ld;
     const bool sink_ok = sink.part && dtype == CN_BF16 && sink.C == y_ld;
-    if (dtype == CN_BF16 && dcn_fwd_gs_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
-                                              sink.slots, taken, (hipStream_t)stream)) {
-        CN_LAUNCH_CHECK("cn_dcn_fwd(gs)");
-        return CN_OK;
-    }
     if (dtype == CN_BF16 && dcn_fwd_b2_launch(x, om, wp, bias, y, N, H, W, Ci, x_ld, Co, y_ld, om_ld, g.ktot, relu, sink_ok ? sink.part : nullptr,
                                               sink.slots, taken, (hipStream_t)stream)) {
         CN_LAUNCH_CHECK("cn_dcn_fwd(b2)");

@@ -195,7 +195,7 @@ def test_conv1x1_streaming(cfg, monkeypatch):
 
 
 def test_dma_fed_conv_kernels_repeatable_under_contention():
-    """Race screen (tools/ws_stress.py, short form): conv3x3_ws_kernel reads halo tiles that another part of the workgroup
+    """Race screen (tools/attic/ws_stress.py, short form): conv3x3_ws_kernel reads halo tiles that another part of the workgroup
     wrote by LDS-DMA two tiles earlier; a read that races its data would show up as a rare differing tile.  The same full-size
     launch, 40 times, next to 512 MB copies on a second stream, must be bit-identical every time."""
     o = ops()
@@ -364,97 +364,6 @@ def test_c16_conv_keeps_a_nan():
         far = y.clone()
         far[0, 12:29, 22:39] = 0
         assert torch.isfinite(far).all()
-
-
-KP_CONVS = [  # N,H,W,Ci,Co,bias,relu,force: >= 128 input channels on 16-aligned maps -> the K-pipelined persistent kernel (conv3x3_kp.hip)
-    (4, 32, 32, 128, 128, False, False, 8),    # two channel slices, two tiles per workgroup at 8 workgroups: deferred epilogue + cross-tile prefetch
-    (3, 16, 48, 256, 128, True, True, 8),      # four slices, bias + ReLU, nine tiles over eight workgroups (one gets two)
-    (2, 16, 16, 512, 256, False, False, 0),    # eight slices, two channel blocks, one tile per workgroup: every halo side is the image border
-    (5, 32, 16, 128, 200, True, False, 16),    # ragged last channel block (200 = 128 + 72), ten tiles
-    (1, 48, 64, 192, 128, False, True, 8),     # three slices, twelve tiles
-]
-
-
-@pytest.mark.parametrize("cfg", KP_CONVS)
-def test_conv3x3_k_pipelined(cfg, monkeypatch):
-    """bf16 3x3/s1 conv with >= 128 input channels AND its data gradient (mirrored taps; Ci == Co cases run it through the same
-    kernel) through conv3x3_kp_kernel — LDS-DMA weight ring with counted vmcnt waits, phase-staggered waves, epilogue deferred
-    into the next tile — against torch fp32 on bf16-rounded operands and against the halo-tile kernel (CN_DISABLE_CONV_KP): same
-    bf16 products, fp32 accumulation in a different order -> at most one output ulp apart.  Run three times: a race between
-    the DMA ring and the fragment reads would show up as run-to-run differences."""
-    N, H, W, Ci, Co, bias, relu, force = cfg
-    dt = torch.bfloat16
-    x = rng.t_normal(7, f"x{cfg}", (N, Ci, H, W))
-    w = rng.t_normal(7, f"w{cfg}", (Co, Ci, 3, 3), 0, (2.0 / (9 * Ci)) ** 0.5)
-    b = rng.t_normal(7, f"b{cfg}", (Co,), 0, 0.1) if bias else None
-    gy = rng.t_normal(7, f"g{cfg}", (N, Co, H, W))
-    xr, wr = rnd(x, dt).requires_grad_(True), rnd(w, dt).requires_grad_(True)
-    yr = F.conv2d(xr, wr, b, 1, 1)
-    if relu:
-        yr = F.relu(yr)
-    yr.backward(rnd(gy, dt))
-
-    def run():
-        xg = to_nhwc(x, dt).requires_grad_(True)
-        wg = w.to(DEV).requires_grad_(True)
-        y = ops().conv2d(xg, wg, b.to(DEV) if bias else None, 1, 1, relu)
-        gyp = torch.zeros(y.shape, dtype=dt, device=DEV)
-        gyp[..., :Co] = to_nhwc(gy, dt)
-        y.backward(gyp)
-        torch.cuda.synchronize()
-        return y.detach().float().cpu(), xg.grad.detach().float().cpu()
-
-    monkeypatch.setenv("CN_ENABLE_CONV_KP", "1")          # the kernel is opt-in (experimental, docs/NEGATIVE_RESULTS.md)
-    if force:
-        monkeypatch.setenv("CN_CONV_KP_FORCE", str(force))
-    runs = [run() for _ in range(3)]
-    monkeypatch.delenv("CN_CONV_KP_FORCE", raising=False)
-    monkeypatch.setenv("CN_DISABLE_CONV_KP", "1")
-    y_tile, dx_tile = run()
-    monkeypatch.delenv("CN_DISABLE_CONV_KP")
-    y_kp, dx_kp = runs[0]
-    for y2, dx2 in runs[1:]:
-        assert torch.equal(y2, y_kp) and torch.equal(dx2, dx_kp), "run-to-run difference: a race in the DMA ring"
-    close(y_kp.permute(0, 3, 1, 2)[:, :Co], yr, dt, "kp conv fwd")
-    close(dx_kp.permute(0, 3, 1, 2), xr.grad, dt, "kp conv dgrad")
-    if y_kp.shape[-1] != Co:
-        assert float(y_kp[..., Co:].abs().max()) == 0.0, "channel padding must stay zero"
-    for a_, b_, what in ((y_kp, y_tile, "fwd"), (dx_kp, dx_tile, "dgrad")):
-        s_ = float(b_.abs().max())
-        assert float((a_ - b_).abs().max()) <= 2.0 ** -7 * s_, f"kp vs tile kernel, {what}"
-
-
-@pytest.mark.parametrize("mode", ["residual_add", "residual_add_relu", "relu_mask", "mirrored_taps"])
-def test_conv3x3_k_pipelined_epilogues(mode, monkeypatch):
-    """The epilogue variants of conv3x3_kp_kernel (residual add, + ReLU, ReLU-backward mask, mirrored taps of a data gradient)
-    against the halo-tile kernel on the same operands through cn_conv2d_fwd: at most one output ulp apart."""
-    o = ops()
-    N, H, W, Ci, Co = 3, 32, 48, 128, 128
-    dt = torch.bfloat16
-    x = rng.t_normal(9, f"x{mode}", (N, H, W, Ci)).to(dt).to(DEV)
-    w = rng.t_normal(9, f"w{mode}", (Co, Ci, 3, 3), 0, (2.0 / (9 * Ci)) ** 0.5).to(DEV)
-    b = rng.t_normal(9, f"b{mode}", (Co,), 0, 0.1).to(DEV)
-    res = rng.t_normal(9, f"r{mode}", (N, H, W, Co)).to(dt).to(DEV)
-    transposed = mode == "mirrored_taps"
-    wp = o.pack_weight(w, 0 if transposed else 1, dt)
-    args = dict(residual_add=(b, res, 0), residual_add_relu=(None, res, 1), relu_mask=(None, res, 2), mirrored_taps=(None, None, 0))[mode]
-
-    def run():
-        y = o._igemm(x, wp, args[0], args[1], Co, 3, 3, 1, 1, transposed, args[2], H, W)
-        torch.cuda.synchronize()
-        return y.float().cpu()
-
-    monkeypatch.setenv("CN_ENABLE_CONV_KP", "1")
-    monkeypatch.setenv("CN_CONV_KP_FORCE", "8")
-    y_kp = run()
-    monkeypatch.delenv("CN_CONV_KP_FORCE")
-    monkeypatch.setenv("CN_DISABLE_CONV_KP", "1")
-    y_tile = run()
-    monkeypatch.delenv("CN_DISABLE_CONV_KP")
-    assert float(y_tile.abs().max()) > 0.5
-    assert float((y_kp - y_tile).abs().max()) <= 2.0 ** -7 * float(y_tile.abs().max()), mode
-    if mode == "relu_mask":
-        assert bool(((y_kp == 0) == (y_tile == 0)).all())
 
 
 @pytest.mark.parametrize("mode", ["residual_add", "residual_add_relu", "relu_mask", "fp32_rows", "mirrored_taps"])

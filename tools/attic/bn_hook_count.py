@@ -1,5 +1,5 @@
 """Which training-mode BatchNorms of a DLA-34 step get their statistics from the producer's epilogue (cn_bn_train_fwd_stats) and which
-still read their input twice (cn_bn_train_fwd), by tensor shape.   python tools/bn_hook_count.py [arch]"""
+still read their input twice (cn_bn_train_fwd), by tensor shape.   python tools/attic/bn_hook_count.py [arch]"""
 import collections
 import os
 import sys

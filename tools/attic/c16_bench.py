@@ -1,6 +1,6 @@
 """Level0 / level1 convolutions of DLA-34 at batch 64 (16 input channels, 512^2): forward 16->16, its data gradient (mirrored taps),
 forward 16->32 stride 2.  A/B: CN_DISABLE_CONV_C16R=1 (read once per process) puts them back on the strip / implicit-GEMM kernels.
-usage: python tools/c16_bench.py [N]"""
+usage: python tools/attic/c16_bench.py [N]"""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 """Development check of the gather-sample DCNv2 kernels (csrc/dcn_gs.hip): the entry points on random inputs at several offset scales
 (zero, sub-pixel, >= 2 px = the spare-slot path, 6 px = several passes per tile) and odd image sizes against oracle/dcn_ref.py on the
 CPU, then isolated timings at the bench shape (run again with CN_DISABLE_DCN_GS=1 for the blend-matrix kernels).
-    python tools/dcn_gs_check.py [fwd|dom|dw|all] [time]
+    python tools/attic/dcn_gs_check.py [fwd|dom|dw|all] [time]
 """
 import os
 import sys

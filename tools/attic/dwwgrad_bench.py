@@ -1,4 +1,4 @@
-"""depthwise up-conv weight gradient at the DLA-34 shapes: python tools/dwwgrad_bench.py  (CN_DISABLE_DWDECONV_ROWS=1: the tap-per-lane kernel)"""
+"""depthwise up-conv weight gradient at the DLA-34 shapes: python tools/attic/dwwgrad_bench.py  (CN_DISABLE_DWDECONV_ROWS=1: the tap-per-lane kernel)"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from centernet_amd import _hip, ops

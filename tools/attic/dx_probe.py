@@ -1,5 +1,5 @@
 """Development aid for dcn_bwd_dx_kernel: builds the library with -DDX_PROBE into tools/_ab/, runs one 64->64 @128^2 launch and
-prints the median cycles of the three phases of a tap (hit lists | G tile | MFMA).   python tools/dx_probe.py build | run [sigma]"""
+prints the median cycles of the three phases of a tap (hit lists | G tile | MFMA).   python tools/attic/dx_probe.py build | run [sigma]"""
 import ctypes
 import os
 import subprocess

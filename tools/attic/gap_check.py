@@ -1,5 +1,5 @@
 """From a rocprofv3 kernel-trace db of bench.py: idle time between consecutive kernels of every hardware queue in the last
-replayed step, and the largest gaps with the kernels on either side.   python tools/gap_check.py <db>"""
+replayed step, and the largest gaps with the kernels on either side.   python tools/attic/gap_check.py <db>"""
 import sqlite3
 import sys
 

@@ -1,6 +1,6 @@
 """Development aid for dcn_fwd_gs_kernel: builds the library with -DGS_PROBE into tools/_ab/, runs one 64->64 @128^2 launch and prints
 the median cycles of the phases of a tile (waves 0 = role 0 and 1 = role 1 of the first 64 workgroups, their first 4 tiles).
-    python tools/gs_probe.py build | run [sigma]"""
+    python tools/attic/gs_probe.py build | run [sigma]"""
 import ctypes
 import os
 import subprocess

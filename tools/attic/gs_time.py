@@ -1,4 +1,4 @@
-"""One entry point of the 64->64 @128^2 batch-64 DCNv2 layer a few times (for rocprofv3 counter passes): python tools/gs_time.py fwd|dom|dw [sigma]"""
+"""One entry point of the 64->64 @128^2 batch-64 DCNv2 layer a few times (for rocprofv3 counter passes): python tools/attic/gs_time.py fwd|dom|dw [sigma]"""
 import os
 import sys
 

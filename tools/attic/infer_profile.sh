@@ -1,10 +1,10 @@
 #!/bin/bash
-# kernel-level breakdown of an inference batch (eval forward + decode, hipGraph): rocprofv3 kernel trace of tools/infer_bench.py
+# kernel-level breakdown of an inference batch (eval forward + decode, hipGraph): rocprofv3 kernel trace of tools/attic/infer_bench.py
 out=$GRAFT_REPO_ROOT/gpurun_out/infer_prof
 mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python tools/infer_bench.py --steps 30 | tail -1
+python tools/attic/infer_bench.py --steps 30 | tail -1
 rm -rf $out/kt
-timeout 600 rocprofv3 --kernel-trace -d $out/kt -o p -- python tools/infer_bench.py --steps 20 > $out/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $out/kt -o p -- python tools/attic/infer_bench.py --steps 20 > $out/kt.log 2>&1
 db=$(ls $out/kt/*.db | head -1)
 python - <<PY > $out/infer_kernels.txt
 import sqlite3, re

@@ -1,4 +1,4 @@
-"""A/B of conv3x3_kp variants on ONE box: python tools/kp_bench.py lib1.so lib2.so ...   ("old" = the default library with
+"""A/B of conv3x3_kp variants on ONE box: python tools/attic/kp_bench.py lib1.so lib2.so ...   ("old" = the default library with
 CN_DISABLE_CONV_KP=1, "cur" = the default library).  Each variant runs in its own process, three interleaved rounds."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

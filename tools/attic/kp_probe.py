@@ -1,6 +1,6 @@
 """Development aid for csrc/conv3x3_kp.hip: builds the library with -DKP_PROBE into tools/_ab/, runs one conv and prints the median
 cycle count of every phase of a step (waves 0 and 4 of each workgroup, steps 4..35).
-    python tools/kp_probe.py build      # here (hipcc)         python tools/kp_probe.py run [Ci HW]     # on the GPU box"""
+    python tools/attic/kp_probe.py build      # here (hipcc)         python tools/attic/kp_probe.py run [Ci HW]     # on the GPU box"""
 import ctypes
 import os
 import subprocess

@@ -1,5 +1,5 @@
 """The batched weight pack of a DLA-34 training step (the first kernel of every step): records, workgroups, bytes, time in a hipGraph.
-usage: python tools/pack_bench.py"""
+usage: python tools/attic/pack_bench.py"""
 import os
 import sys
 

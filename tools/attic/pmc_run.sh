@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mode=$1; pat=$2; shift 2
 rm -rf gpurun_out/pmc_x
-timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d gpurun_out/pmc_x -o p -- python tools/prof_conv.py $mode > gpurun_out/pmc_x.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d gpurun_out/pmc_x -o p -- python tools/attic/prof_conv.py $mode > gpurun_out/pmc_x.log 2>&1
 python - <<PY
 import sqlite3,glob
 from collections import defaultdict

@@ -1,6 +1,6 @@
 """How long does the HOST spend inside one replayed step (hipGraphLaunch of the ~700-kernel step graph + the optimizer graph)?
 If the runtime enqueues a graph's kernel nodes one by one in a main-chain-first order, the side branch (weight gradients) cannot
-start before the host has walked the whole launch-stream chain.   python tools/replay_host_time.py"""
+start before the host has walked the whole launch-stream chain.   python tools/attic/replay_host_time.py"""
 import os
 import sys
 import time

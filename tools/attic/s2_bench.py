@@ -1,4 +1,4 @@
-"""stride-2 3x3 forward convs and their data gradients at the DLA-34 shapes (hipGraph of 10 launches each): python tools/s2_bench.py
+"""stride-2 3x3 forward convs and their data gradients at the DLA-34 shapes (hipGraph of 10 launches each): python tools/attic/s2_bench.py
 (CN_DISABLE_CONV3X3_S2=1 / CN_DISABLE_DGRAD3X3_S2=1: implicit GEMM)"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Isolated timing of the two 512x512 weight-gradient launches that end a step (stem 7x7 3->16 on the fp32 NCHW image, level0 3x3
-16->16) at full width: python tools/stem_wgrad_bench.py   (CN_LIB_PATH: another build)"""
+16->16) at full width: python tools/attic/stem_wgrad_bench.py   (CN_LIB_PATH: another build)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,6 @@
 """From a rocprofv3 --kernel-trace db of `bench.py --no-probe`: the first and the last kernels of the last replayed step (adam_kernel ->
 adam_kernel) with start offsets and durations — the two ends of a step are where only ONE stream has work (forward: no weight gradients
-yet; tail: the data-gradient chain of the first layers).   python tools/step_edges.py <db> [n_head] [n_tail]"""
+yet; tail: the data-gradient chain of the first layers).   python tools/attic/step_edges.py <db> [n_head] [n_tail]"""
 import re
 import sqlite3
 import sys

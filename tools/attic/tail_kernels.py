@@ -1,5 +1,5 @@
 """From a rocprofv3 --kernel-trace db of `bench.py --no-probe`: the side-stream (weight-gradient) kernels of the last replayed step that
-START after the launch stream's last kernel has ended — the step's tail — with their grids.   python tools/tail_kernels.py <db>"""
+START after the launch stream's last kernel has ended — the step's tail — with their grids.   python tools/attic/tail_kernels.py <db>"""
 import re
 import sqlite3
 import sys

@@ -1,5 +1,5 @@
 """From a rocprofv3 kernel-trace db of bench.py (graph replay, --no-probe): the side-stream kernels of the last step that run after
-the launch-stream chain of backward has finished (the step's tail).   python tools/tail_side.py <db>"""
+the launch-stream chain of backward has finished (the step's tail).   python tools/attic/tail_side.py <db>"""
 import sqlite3
 import sys
 

@@ -1,6 +1,6 @@
 """Where do the two streams of a REPLAYED step end?  Device wall-clock stamps (cn_stamp, 100 MHz) captured into the step's graph:
 step start, end of the launch-stream chain, end of the weight-gradient stream, after the join.  No profiler attached.
-    python tools/tail_stamps.py [arch] [batch]"""
+    python tools/attic/tail_stamps.py [arch] [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 #!/bin/bash
-# replay trace under a set of env assignments: tools/trace_env.sh <tag> "A=1 B=2"
+# replay trace under a set of env assignments: tools/attic/trace_env.sh <tag> "A=1 B=2"
 out=$GRAFT_REPO_ROOT/gpurun_out/trace_$1
 mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf $out/kt

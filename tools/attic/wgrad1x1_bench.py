@@ -1,5 +1,5 @@
 """Isolated timing of the generic split-K weight-gradient kernel (cn_conv2d_wgrad) on the 1x1 layers of a DLA-34 step (batch 64).
-    python tools/wgrad1x1_bench.py [blocks ...]"""
+    python tools/attic/wgrad1x1_bench.py [blocks ...]"""
 import os
 import sys
 

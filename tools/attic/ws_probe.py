@@ -1,6 +1,6 @@
 """Development aid for csrc/conv3x3_ws.hip: builds the library with -DWS_PROBE into tools/_ab/, runs one head-shaped conv and prints
 the median cycle count of every phase of the tile loop (wave 0 of each workgroup, tiles 1..7).
-    python tools/ws_probe.py build      # here (hipcc)         python tools/ws_probe.py run      # on the GPU box"""
+    python tools/attic/ws_probe.py build      # here (hipcc)         python tools/attic/ws_probe.py run      # on the GPU box"""
 import ctypes
 import os
 import subprocess

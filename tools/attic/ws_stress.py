@@ -1,6 +1,6 @@
 """Race screen for conv3x3_ws_kernel / conv1x1_stream_kernel: the same launch repeated under memory contention from a second
 stream must give bit-identical results every time (the kernels are deterministic; an LDS-DMA read that races its data shows up as
-a rare differing tile).  python tools/ws_stress.py [iterations]"""
+a rare differing tile).  python tools/attic/ws_stress.py [iterations]"""
 import os
 import sys
 

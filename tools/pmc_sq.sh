@@ -2,7 +2,7 @@
 # SQ counter pass over the bench step for the kernels that dominate it (round-3 VERDICT, evidence item 5b): one rocprofv3 run with
 # --kernel-trace --pmc only (no other trace domain), eager launches of the same workload (--no-graph: the counters are per dispatch),
 # per kernel template the per-launch averages and the derived ratios.   usage: tools/pmc_sq.sh <tag>
-tag=${1:-r05}
+tag=${1:-r06}
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_sq_$tag
 mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf $out/db
@@ -12,7 +12,7 @@ import sqlite3, glob, re
 from collections import defaultdict
 dbs = glob.glob('$out/db/*.db')
 c = sqlite3.connect(dbs[0])
-pats = ['dcn_wgrad_bm_kernel', 'dcn_dx_bm_kernel<2>', 'dcn_dom_bm_kernel<64, true>', 'dcn_fwd_bm_kernel<2>', 'conv3x3s1_kernel<unsigned short, 128, 64, 8, 1>', 'conv3x3_ws_kernel<64, false, 0, true, 0>',
+pats = ['dcn_wgrad_bm_kernel', 'dcn_dx_bm_kernel<2>', 'dcn_dom_bm_kernel<64, true>', 'dcn_fwd_b2_kernel<false>', 'dcn_fwd_b2_kernel<true>', 'dcn_fwd_bm_kernel<2>', 'conv3x3s1_kernel<unsigned short, 128, 64, 8, 1>', 'conv3x3_ws_kernel<64, false, 0, true, 0>',
         'bn_bwd_apply_kernel<unsigned short, true>', 'bn_partial_kernel<unsigned short, 1>', 'wgrad3x3s1_kernel<128, 64, 9, true, 8, 1>', 'conv1x1_stream_kernel<16, 3',
         'conv3x3_c16r_kernel<1, 1, 2>', 'conv3x3_c16r_kernel<1, 1, 0>', 'conv3x3_c16r_kernel<2, 2, 2>', 'stem7_rows_kernel', 'dgrad3x3s2_kernel<64, 64, 8>', 'dcn_fwd_tile_kernel<128>']
 print("# rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS")
