@@ -508,7 +508,7 @@ def test_decode_is_stable_next_to_other_streams():
     picked a second pivot bin and overran the survivor list (garbage indices -> GPU memory fault in the gather).  It needed the
     decode to share the GPU with another stream's kernels (about one map in 10^6), exactly what TrainStep's post_forward does.
     Here: 300 full-size decodes on a side stream while the main stream runs conv + BN forward/backward; every result must be
-    bit-identical (a stress test: the original fault needed ~4e5 maps under a real backward pass; tools/attic/long_run.py reproduces that)."""
+    bit-identical (a stress test: the original fault needed ~4e5 maps under a real backward pass; tools/long_run.py reproduces that)."""
     from centernet_amd.decode.ctdet import ctdet_decode
     B, C, H, W = 64, 80, 128, 128
     heat = torch.clamp(torch.sigmoid(rng.t_normal(70, "heat", (B, C, H, W)) * 2.0 - 6.0), 1e-4, 1 - 1e-4).to(DEV)
