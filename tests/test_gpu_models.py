@@ -415,6 +415,7 @@ for graph in (False, True, "between"):
         os.environ["CN_EXCHANGE_BETWEEN_GRAPHS"] = "1"
         step = TrainStep(m, lr=2e-4, graph=True)
         out["between"] = [float(step(batch)) for _ in range(4)]
+        out["drained_between"] = bool(getattr(step, "drained", False))
         del os.environ["CN_EXCHANGE_BETWEEN_GRAPHS"]
         continue
     step = TrainStep(m, lr=2e-4, graph=graph)
@@ -444,6 +445,7 @@ def test_rccl_exchange_next_to_graphs(tmp_path):
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res["is_graph_True"], "capture fell back to eager next to the process group:\n" + r.stderr[-2000:]
     assert res["drained_True"], "the watchdog was not drained by its own bookkeeping (timer fallback taken)"
+    assert res["drained_between"], "second capture in the same process (earlier captured collectives in the recorder): timer fallback taken"
     assert all(np.isfinite(res["eager"])) and all(np.isfinite(res["graph"]))
     for mode in ("eager", "graph"):
         log = res["log_" + mode]
