@@ -1006,18 +1006,14 @@ __global__ __launch_bounds__(NW * 64) void dcn_wgrad_bm_kernel(const WgBmGeom g)
                                (uint32_t)__builtin_amdgcn_readlane((int)rows, 32) | (uint32_t)__builtin_amdgcn_readlane((int)rows, 48);
 
             // ---- S[p][ci] = Bm[p][window row] X[window row][ci] over the touched rows (fragments straight from the halo image) ----
+            // (round 6: the first touched row STARTS the accumulators — C = 0 is an inline constant of the MFMA — instead of 32 v_mov per
+            // unit, a seventh of the unit's VALU instructions; a unit nobody samples in skips its MFMAs altogether)
             f32x16_t st[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[mb][r] = 0.f;
+            const bool any_row = rowmask != 0u;
             const int wc0 = gcol + 8 * (g16 >> 1) + (r16 >> 2);
             const unsigned char* const b0 = Xw + bm_lds_ofs(grow, wc0, 16 * (g16 & 1) + 4 * (r16 & 3));
             const unsigned char* const b1 = Xw + bm_lds_ofs(grow, wc0, 32 + 16 * (g16 & 1) + 4 * (r16 & 3));
-#pragma unroll 1
-            while (rowmask) {
-                const int r = __builtin_ctz(rowmask);
-                rowmask &= rowmask - 1;
+            auto row_mfma = [&](const int r, const f32x16_t& c0, const f32x16_t& c1) {
                 const bool t0 = wr_top == r, t1 = wr_bot == r;
                 u32x4v b;
 #pragma unroll
@@ -1030,8 +1026,22 @@ __global__ __launch_bounds__(NW * 64) void dcn_wgrad_bm_kernel(const WgBmGeom g)
                 const s16x4_t_ h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(b1 + ro_ + 4 * BM_PIXB));
                 const s16x8_t_ x0 = {l0[0], l0[1], l0[2], l0[3], h0[0], h0[1], h0[2], h0[3]};
                 const s16x8_t_ x1 = {l1[0], l1[1], l1[2], l1[3], h1[0], h1[1], h1[2], h1[3]};
-                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8_t, x0), st[0], 0, 0, 0);
-                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8_t, x1), st[1], 0, 0, 0);
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8_t, x0), c0, 0, 0, 0);
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, __builtin_bit_cast(bf16x8_t, x1), c1, 0, 0, 0);
+            };
+            if (any_row) {
+                const int r = __builtin_ctz(rowmask);
+                rowmask &= rowmask - 1;
+                f32x16_t z;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                row_mfma(r, z, z);
+            }
+#pragma unroll 1
+            while (rowmask) {
+                const int r = __builtin_ctz(rowmask);
+                rowmask &= rowmask - 1;
+                row_mfma(r, st[0], st[1]);
             }
             // ---- samples that leave the window (rare): pixel by pixel, every lane blends ITS channel of S from global memory (exact fp32
             //      weights) and applies the rank-1 update dW[.][ci] += dY[p][.] * S[p][ci] to its accumulator columns directly ----
@@ -1067,6 +1077,7 @@ __global__ __launch_bounds__(NW * 64) void dcn_wgrad_bm_kernel(const WgBmGeom g)
                     }
             }
             // ---- dW[co][ci] += dY^T[co][p] S[p][ci]   (K = the group's 32 pixels in the accumulator's row order) ----
+            if (any_row)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 u32x4v sb[2];
