@@ -553,7 +553,9 @@ def test_depthwise_up(cfg, dt):
                                  (1, 40, 36, 64, 64, 6.0), (2, 19, 33, 128, 128, 4.0), (1, 20, 20, 256, 64),
                                  # maps of >= 32x32 pixels with Co = 64 take the 16x16-tile forward (dcn_b2.hip): ragged tiles, displacements
                                  # beyond its 3-pixel window margin (the per-lane far path), several 64-channel blocks of x
-                                 (1, 35, 50, 64, 64), (1, 33, 34, 128, 64, 4.0), (2, 64, 48, 256, 64, 1.5)])
+                                 (1, 35, 50, 64, 64), (1, 33, 34, 128, 64, 4.0), (2, 64, 48, 256, 64, 1.5),
+                                 # ... and a small map keeps the 8x16-tile kernel: far samples in its SECOND 64-channel block (round-5 ADVICE)
+                                 (1, 20, 20, 128, 64, 4.0)])
 def test_dcnv2(cfg, dt):
     """vs oracle/dcn_ref.py (pure torch); offsets are O(1) so every bilinear corner / border case is exercised."""
     from centernet_amd import nn as hnn

@@ -628,3 +628,29 @@ def test_sparse_rows_registry_only_matches_the_untouched_tensor():
         assert not reg.entries
     finally:
         reg.entries = saved
+
+
+def test_bench_uses_a_committed_trace_only_when_it_provably_belongs_to_the_build_and_the_command():
+    """round-5 ADVICE (medium): `roofline.frac` is measured live; the committed rocprofv3 summary is a cross-check that bench.py accepts
+    only with the sidecar of tools/trace_meta.py (same arguments, same kernel sources, exactly one instantiation with the full
+    template name)."""
+    import argparse
+    import json
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    metas = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f.endswith("_bench_trace_meta.json"))
+    assert metas, "profiles/rNN_bench_trace_meta.json is part of a committed profile set"
+    meta = json.load(open(os.path.join(root, "profiles", metas[-1])))
+    args = argparse.Namespace(**meta["cmd_args"])
+    fresh = all(bench._git_blob_sha(os.path.join(root, src)) == sha for src, sha in meta["sources"].items())
+    hit = bench.rocprof_avg_us("dcn_wgrad_bm_kernel", args)
+    if fresh:
+        assert hit and hit["kernel"].startswith("dcn_wgrad_bm_kernel<") and hit["avg_us"] > 0
+        one = bench.rocprof_avg_us("dcn_dom_bm_kernel<64>", args)
+        assert one and "<64," in one["kernel"].replace(" ", ""), "never the duration of another instantiation"
+        assert bench.rocprof_avg_us("dcn_dom_bm_kernel", args) is None, "two instantiations carry the bare name: ambiguous -> no cross-check"
+    else:
+        assert hit is None, "a kernel source changed after the trace was taken: the summary must not be used"
+    other = argparse.Namespace(**dict(meta["cmd_args"], batch=meta["cmd_args"]["batch"] // 2))
+    assert bench.rocprof_avg_us("dcn_wgrad_bm_kernel", other) is None, "a different --batch is a different command"
+    assert bench._norm_kernel("void conv3x3s1_kernel<unsigned short, 128, 64, 8, 1>") == bench._norm_kernel("conv3x3s1_kernel<bf16,128,64,8,1>")
