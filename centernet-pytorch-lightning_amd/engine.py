@@ -346,8 +346,10 @@ def init_distributed():
         os.environ.setdefault("MASTER_PORT", "29500")
         # the flight recorder's status block is how drain_watchdog learns that the watchdog has retired the warm-up collectives
         # (the group only keeps it when a trace buffer is configured at creation)
-        os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")
-        os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
+        # (CN_NO_FLIGHT_RECORDER=1 leaves the recorder as the user configured it: drain_watchdog then falls back to its timer and says so)
+        if not os.environ.get("CN_NO_FLIGHT_RECORDER"):
+            os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")
+            os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
         dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
     return rank, local, world
 
